@@ -1,0 +1,139 @@
+/*
+ * knn_mi355x.h — C-ABI of libknn_mi355x.so: brute-force nearest-neighbour
+ * search (1-NN, squared L2, fp32, first-minimum tie-break) on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of wu-kan/multicore-hw2: the
+ * global cudaCallback() of reference sources/src/core.h:71 (defined at
+ * sources/src/core.cu:1282-1297, which forwards to v8::cudaCallback,
+ * core.cu:856-958).  Plain pointers and sizes only; no HIP, torch or C++ types.
+ *
+ * Results are bit-identical to the reference's serial v0 path
+ * (core.cu:27-62): squared distance accumulated in fp32 in dimension order,
+ * one rounding per operation (no FMA), and the lowest index among equal
+ * minima.
+ *
+ * There is NO CPU fallback in this library.  Where the reference silently
+ * computes on the CPU when no GPU is present (core.cu:869-870), this library
+ * reports the error and exits like the reference's CHECK macro does for any
+ * other runtime error (core.h:77-87).
+ */
+#ifndef KNN_MI355X_H
+#define KNN_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * 1. The drop-in entry point.  Replaces: core.h:71 / core.cu:1282-1297.
+ *
+ *   k, m, n            dimensions, #queries, #references (all >= 1)
+ *   searchPoints       host, fp32, row-major [m][k]   (read-only, not freed)
+ *   referencePoints    host, fp32, row-major [n][k]   (read-only, not freed)
+ *   *results           set to a malloc()'d int[m]; caller free()s it
+ *                      (core.cu:35,59,935; main.cu:98,175)
+ *
+ * results[j] = 0-based index of the reference nearest to query j.
+ * Synchronous: all device work has finished on return.  The reference set is
+ * split over every visible GPU in contiguous index ranges (the scheme of
+ * core.cu:873-883) and the per-GPU winners are min-reduced as packed
+ * (distance, global index) keys.  On a runtime error prints
+ * "Error: <file>:<line>, code:<c>, reason: <text>" and exit(1)s (core.h:77-87).
+ * ---------------------------------------------------------------------- */
+void cudaCallback(int k, int m, int n, float *searchPoints, float *referencePoints,
+                  int **results);
+
+/* ------------------------------------------------------------------------
+ * 2. Device-resident index API (not in the reference; cudaCallback is
+ *    create + query + destroy over all GPUs).  Lets a caller keep the
+ *    reference set in HBM across calls and time the kernels without PCIe.
+ *    All functions return 0 on success, a negative KNN_E* code on failure;
+ *    knn_last_error() gives the message for the calling thread.
+ * ---------------------------------------------------------------------- */
+typedef struct knn_index knn_index;
+
+enum {
+    KNN_OK = 0,
+    KNN_EINVAL = -1,   /* bad argument */
+    KNN_ENODEV = -2,   /* no usable GPU */
+    KNN_EHIP = -3,     /* HIP runtime error */
+    KNN_ENOMEM = -4
+};
+
+/* Packed result key: (float_bits(dist2) << 32) | global_index.  dist2 >= +0 so
+ * unsigned order == lexicographic (distance, index) order == v0's first strict
+ * minimum.  KNN_KEY_INIT = (+INF, index 0): what v0 returns when nothing
+ * beats +INF (core.cu:39-40,50). */
+#define KNN_KEY_INIT 0x7F80000000000000ull
+
+int knn_device_count(void);
+const char *knn_last_error(void);
+const char *knn_version(void);
+
+/* Build an index over one contiguous shard of the reference set on `device`.
+ *   refs           fp32 row-major [n_local][k]; host pointer if
+ *                  refs_on_device == 0 (copied to the GPU), else a device
+ *                  pointer on `device` that must stay valid until destroy
+ *                  (borrowed, not copied)
+ *   base_index     global index of refs[0] (the shard offset that
+ *                  core.cu:932-933 adds on the host; here it is folded into the
+ *                  keys on the GPU)
+ *   stream         hipStream_t as void* (NULL = default stream) used for the
+ *                  layout-preparation kernels
+ * n_local may be 0 (an empty shard: queries leave the keys untouched). */
+int knn_index_create(knn_index **out, int device, int k, long long n_local, const float *refs,
+                     int refs_on_device, long long base_index, void *stream);
+void knn_index_destroy(knn_index *idx);
+
+/* Fill keys_dev[0..m) with KNN_KEY_INIT (async on stream). */
+int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream);
+
+/* keys_dev[j] = min(keys_dev[j], key of the nearest reference of this shard to
+ * query j).  queries_dev: device fp32 [m][k].  Asynchronous on `stream`.
+ * Several shards (or GPUs, after an all-reduce MIN) may fold into one key
+ * array; the minimum is the global answer. */
+int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
+                         unsigned long long *keys_dev, void *stream);
+
+/* out_dev[j] = (int)(keys_dev[j] & 0xFFFFFFFF) (async on stream). */
+int knn_keys_to_indices(int device, const unsigned long long *keys_dev, int m, int *out_dev,
+                        void *stream);
+
+/* Convenience: host queries in, host indices out, synchronous. */
+int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *out_host);
+
+/* Tuning / test hooks.  Known names:
+ *   "path"    0 = auto, 1 = exact VALU kernels only, 2 = force the MFMA filter
+ *             (+ exact re-rank) where its preconditions hold
+ *   "shards"  cudaCallback only: split the reference set into this many
+ *             shards (0 = one per visible GPU).  Shards beyond the GPU count
+ *             wrap around the devices — exercises the partition + merge logic
+ *             on a single GPU.
+ * Returns KNN_EINVAL for an unknown name or value. */
+int knn_set_option(const char *name, long long value);
+long long knn_get_option(const char *name);
+
+/* Statistics of the most recent knn_index_query_keys on this index (filled
+ * when the stream has completed; call after synchronising):
+ *   [0] path taken (1 exact, 2 filter)   [1] candidates re-ranked exactly
+ *   [2] candidate-buffer overflow fallbacks   [3] reserved */
+int knn_index_last_stats(knn_index *idx, long long stats[4]);
+
+/* Bench support: time the index's dominant kernel (the one the roofline is quoted for) with a
+ * HIP event pair recorded on the caller's stream around each launch.  enable != 0 starts
+ * recording for every later knn_index_query_keys, 0 stops and drops the record. */
+int knn_index_timing(knn_index *idx, int enable);
+/* Waits for the recorded events, returns how many launches were timed and their summed
+ * duration in milliseconds, and clears the record. */
+int knn_index_timing_read(knn_index *idx, int *launches, double *total_ms);
+
+/* Bench support: x[i] = (float)((splitmix64-style hash of (seed, first + i)) >> 40) * 2^-24,
+ * uniform in [0,1), written on the device (same values as the oracle's
+ * knn_synth_fill for the same seed/first). */
+int knn_synth_fill_device(int device, float *dst_dev, long long count, unsigned long long seed,
+                          long long first, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNN_MI355X_H */

@@ -1,0 +1,196 @@
+"""multicore_hw2_amd — host-side mirror of the reference's operator boundary for ONE hot path:
+brute-force nearest-neighbour search behind ``cudaCallback(k, m, n, searchPoints,
+referencePoints, results)`` (reference sources/src/core.h:71, sources/src/core.cu:1282-1297).
+
+The product is ``libknn_mi355x.so`` (hand-written HIP for gfx950 + a C-ABI, see
+``include/knn_mi355x.h``).  This package only binds it with ctypes so that tests and
+``bench.py`` drive exactly the entry points a C/C++ caller would.  There is no CPU fallback:
+importing works anywhere, but every compute entry raises if the library is missing or no GPU
+is visible.  PyTorch is *not* imported here; callers that hold torch tensors pass
+``tensor.data_ptr()`` / ``torch.cuda.current_stream().cuda_stream``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+__all__ = ["lib", "lib_path", "cudaCallback", "KnnIndex", "KnnError", "KEY_INIT", "set_option",
+           "get_option", "device_count", "EXPORTED_SYMBOLS", "shard_bounds"]
+
+KEY_INIT = 0x7F80000000000000
+
+# every symbol include/knn_mi355x.h declares
+EXPORTED_SYMBOLS = [
+    "cudaCallback", "knn_device_count", "knn_last_error", "knn_version", "knn_index_create",
+    "knn_index_destroy", "knn_keys_init", "knn_index_query_keys", "knn_keys_to_indices",
+    "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
+    "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libknn_mi355x.so")
+_lib = None
+
+
+class KnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libknn_mi355x.so (built in-tree by __graft_entry__.build()); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(lib_path):
+        raise KnnError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    L = ctypes.CDLL(lib_path)
+    c_int, c_ll, c_vp, c_ull = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_ulonglong
+    L.cudaCallback.argtypes = [c_int, c_int, c_int, c_vp, c_vp, ctypes.POINTER(ctypes.POINTER(c_int))]
+    L.cudaCallback.restype = None
+    L.knn_device_count.restype = c_int
+    L.knn_last_error.restype = ctypes.c_char_p
+    L.knn_version.restype = ctypes.c_char_p
+    L.knn_index_create.argtypes = [ctypes.POINTER(c_vp), c_int, c_int, c_ll, c_vp, c_int, c_ll, c_vp]
+    L.knn_index_destroy.argtypes = [c_vp]
+    L.knn_index_destroy.restype = None
+    L.knn_keys_init.argtypes = [c_int, c_vp, c_int, c_vp]
+    L.knn_index_query_keys.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
+    L.knn_keys_to_indices.argtypes = [c_int, c_vp, c_int, c_vp, c_vp]
+    L.knn_index_query_host.argtypes = [c_vp, c_int, c_vp, c_vp]
+    L.knn_set_option.argtypes = [ctypes.c_char_p, c_ll]
+    L.knn_get_option.argtypes = [ctypes.c_char_p]
+    L.knn_get_option.restype = c_ll
+    L.knn_index_last_stats.argtypes = [c_vp, ctypes.POINTER(c_ll)]
+    L.knn_synth_fill_device.argtypes = [c_int, c_vp, c_ll, c_ull, c_ll, c_vp]
+    L.knn_index_timing.argtypes = [c_vp, c_int]
+    L.knn_index_timing_read.argtypes = [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise KnnError(f"knn_mi355x error {rc}: {lib().knn_last_error().decode(errors='replace')}")
+
+
+def device_count():
+    return lib().knn_device_count()
+
+
+def set_option(name, value):
+    _check(lib().knn_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    return lib().knn_get_option(name.encode())
+
+
+def shard_bounds(n, shards):
+    """Contiguous index ranges of the reference set, one per shard: the partition of reference
+    core.cu:875-883 (ceil(n/G) per shard, the last takes the rest; possibly empty)."""
+    shards = max(1, min(int(shards), int(n)))
+    per = -(-n // shards)
+    return [(min(g * per, n), min(g * per + per, n)) for g in range(shards)]
+
+
+def _as_f32(a, count, name):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    if a.size != count:
+        raise ValueError(f"{name}: expected {count} floats, got {a.size}")
+    return a
+
+
+def cudaCallback(k, m, n, searchPoints, referencePoints):
+    """The drop-in entry with the reference's argument meaning (core.h:71): host fp32 arrays
+    ``searchPoints[m*k]``, ``referencePoints[n*k]`` row-major; returns the ``int[m]`` the C
+    function hands back through ``int **results`` (the malloc'd buffer is freed here, as the
+    reference's caller does at main.cu:98,175).  Runtime errors exit the process like the
+    reference's CHECK macro (core.h:77-87)."""
+    L = lib()
+    q = _as_f32(searchPoints, k * m, "searchPoints")
+    r = _as_f32(referencePoints, k * n, "referencePoints")
+    res = ctypes.POINTER(ctypes.c_int)()
+    L.cudaCallback(k, m, n, q.ctypes.data_as(ctypes.c_void_p), r.ctypes.data_as(ctypes.c_void_p),
+                   ctypes.byref(res))
+    out = np.ctypeslib.as_array(res, shape=(m,)).astype(np.int32, copy=True)
+    ctypes.CDLL(None).free(res)
+    return out
+
+
+class KnnIndex:
+    """Device-resident shard of the reference set (knn_index_* in include/knn_mi355x.h)."""
+
+    def __init__(self, k, refs, n_local=None, device=0, base_index=0, refs_on_device=False, stream=0):
+        self._h = ctypes.c_void_p()
+        self.k, self.device, self.base = int(k), int(device), int(base_index)
+        if refs_on_device:
+            if n_local is None:
+                raise ValueError("n_local is required with a device pointer")
+            ptr = ctypes.c_void_p(int(refs))
+            self._keep = None
+        else:
+            arr = np.ascontiguousarray(refs, dtype=np.float32).reshape(-1)
+            if n_local is None:
+                n_local = arr.size // self.k
+            if arr.size != n_local * self.k:
+                raise ValueError("refs size does not match n_local * k")
+            ptr = arr.ctypes.data_as(ctypes.c_void_p)
+            self._keep = arr
+        self.n = int(n_local)
+        _check(lib().knn_index_create(ctypes.byref(self._h), self.device, self.k, self.n, ptr,
+                                      1 if refs_on_device else 0, self.base, ctypes.c_void_p(stream)))
+        self._keep = None
+
+    def query_keys(self, m, queries_dev, keys_dev, stream=0):
+        """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m]."""
+        _check(lib().knn_index_query_keys(self._h, int(m), ctypes.c_void_p(int(queries_dev)),
+                                          ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream)))
+
+    def query(self, queries):
+        """Synchronous host-in/host-out query of this shard alone."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1)
+        m = q.size // self.k
+        out = np.empty(m, dtype=np.int32)
+        _check(lib().knn_index_query_host(self._h, m, q.ctypes.data_as(ctypes.c_void_p),
+                                          out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def last_stats(self):
+        st = (ctypes.c_longlong * 4)()
+        _check(lib().knn_index_last_stats(self._h, st))
+        return list(st)
+
+    def timing(self, enable):
+        _check(lib().knn_index_timing(self._h, 1 if enable else 0))
+
+    def timing_read(self):
+        """(launches, total_ms) of the dominant kernel since timing(True) / the last read."""
+        n, ms = ctypes.c_int(), ctypes.c_double()
+        _check(lib().knn_index_timing_read(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    def close(self):
+        if self._h:
+            lib().knn_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def keys_init(keys_dev, m, device=0, stream=0):
+    _check(lib().knn_keys_init(int(device), ctypes.c_void_p(int(keys_dev)), int(m), ctypes.c_void_p(stream)))
+
+
+def keys_to_indices(keys_dev, m, out_dev, device=0, stream=0):
+    _check(lib().knn_keys_to_indices(int(device), ctypes.c_void_p(int(keys_dev)), int(m),
+                                     ctypes.c_void_p(int(out_dev)), ctypes.c_void_p(stream)))
+
+
+def synth_fill_device(dst_dev, count, seed, first=0, device=0, stream=0):
+    _check(lib().knn_synth_fill_device(int(device), ctypes.c_void_p(int(dst_dev)), int(count), int(seed),
+                                       int(first), ctypes.c_void_p(stream)))

@@ -1,0 +1,445 @@
+// knn_api.cpp — host side of libknn_mi355x.so: the C-ABI of include/knn_mi355x.h.
+//
+// Mirrors the orchestration of the reference's v8::cudaCallback (sources/src/core.cu:856-958)
+// for ONE purpose — same inputs, same outputs, same error behaviour — without its structure:
+// one host thread per GPU like core.cu:873, but shard offsets are folded into packed keys on
+// the GPU (instead of the host-side `+= offset`, core.cu:932-933) and the final reduction is an
+// unsigned min over m keys per GPU (instead of the distance-recomputing CPU loop,
+// core.cu:935-957, whose indexing is wrong for m > 1 — SURVEY.md §8 a2').
+#include "../../include/knn_mi355x.h"
+#include "knn_common.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, const char *detail = nullptr)
+{
+    g_err = what;
+    if (detail) {
+        g_err += ": ";
+        g_err += detail;
+    }
+    return code;
+}
+
+#define HIP_TRY(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            char buf_[256];                                                                \
+            snprintf(buf_, sizeof buf_, "%s:%d, code:%d, reason: %s", __FILE__, __LINE__,  \
+                     (int)e_, hipGetErrorString(e_));                                      \
+            g_err = buf_;                                                                  \
+            return KNN_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+// Abort-on-error for the void drop-in entry (reference core.h:77-87: print and exit(1)).
+[[noreturn]] void die(const char *file, int line, int code, const char *reason)
+{
+    printf("Error: %s:%d, code:%d, reason: %s \n", file, line, code, reason);
+    fflush(stdout);
+    exit(1);
+}
+#define DIE_IF(rc)                                                \
+    do {                                                          \
+        int rc_ = (rc);                                           \
+        if (rc_ != KNN_OK)                                        \
+            die(__FILE__, __LINE__, rc_, g_err.c_str());          \
+    } while (0)
+
+std::atomic<long long> g_opt_path{0};
+std::atomic<long long> g_opt_shards{0};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct knn_index {
+    int device = 0;
+    int k = 0;
+    long long n = 0;
+    long long base = 0;
+    int num_cu = 256;
+    const float *refs = nullptr;  // device, AoS [n][k]
+    float *owned_refs = nullptr;  // set when the index copied the references itself
+    long long stats[4] = {0, 0, 0, 0};
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // one pair per timed launch
+    size_t events_used = 0;
+};
+
+extern "C" {
+
+const char *knn_last_error(void) { return g_err.c_str(); }
+
+const char *knn_version(void) { return "knn_mi355x 0.1 (gfx950)"; }
+
+int knn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int knn_set_option(const char *name, long long value)
+{
+    if (!name)
+        return fail(KNN_EINVAL, "knn_set_option: null name");
+    if (!strcmp(name, "path")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: path must be 0, 1 or 2");
+        g_opt_path = value;
+        return KNN_OK;
+    }
+    if (!strcmp(name, "shards")) {
+        if (value < 0 || value > 1024)
+            return fail(KNN_EINVAL, "knn_set_option: shards must be in [0, 1024]");
+        g_opt_shards = value;
+        return KNN_OK;
+    }
+    return fail(KNN_EINVAL, "knn_set_option: unknown option", name);
+}
+
+long long knn_get_option(const char *name)
+{
+    if (name && !strcmp(name, "path"))
+        return g_opt_path;
+    if (name && !strcmp(name, "shards"))
+        return g_opt_shards;
+    return -1;
+}
+
+int knn_index_create(knn_index **out, int device, int k, long long n_local, const float *refs,
+                     int refs_on_device, long long base_index, void *stream)
+{
+    if (!out)
+        return fail(KNN_EINVAL, "knn_index_create: null out");
+    *out = nullptr;
+    if (k < 1 || n_local < 0 || base_index < 0 || (n_local > 0 && !refs))
+        return fail(KNN_EINVAL, "knn_index_create: bad k, n_local, base_index or refs");
+    if (base_index + n_local > 0x7FFFFFFFll + 1)
+        return fail(KNN_EINVAL, "knn_index_create: global index exceeds int32 (results are int)");
+    int ndev = knn_device_count();
+    if (ndev < 1)
+        return fail(KNN_ENODEV, "knn_index_create: no HIP device visible");
+    if (device < 0 || device >= ndev)
+        return fail(KNN_EINVAL, "knn_index_create: device out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_index_create: hipSetDevice failed");
+
+    knn_index *idx = new (std::nothrow) knn_index();
+    if (!idx)
+        return fail(KNN_ENOMEM, "knn_index_create: out of host memory");
+    idx->device = device;
+    idx->k = k;
+    idx->n = n_local;
+    idx->base = base_index;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        idx->num_cu = prop.multiProcessorCount;
+
+    hipStream_t s = (hipStream_t)stream;
+    if (n_local > 0) {
+        if (refs_on_device) {
+            idx->refs = refs;
+        } else {
+            const size_t bytes = (size_t)n_local * (size_t)k * sizeof(float);
+            hipError_t e = hipMalloc((void **)&idx->owned_refs, bytes);
+            if (e != hipSuccess) {
+                delete idx;
+                return fail(KNN_ENOMEM, "knn_index_create: hipMalloc(refs)", hipGetErrorString(e));
+            }
+            e = hipMemcpyAsync(idx->owned_refs, refs, bytes, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(s);  // the host buffer may be freed right after return
+            if (e != hipSuccess) {
+                (void)hipFree(idx->owned_refs);
+                delete idx;
+                return fail(KNN_EHIP, "knn_index_create: H2D copy of refs", hipGetErrorString(e));
+            }
+            idx->refs = idx->owned_refs;
+        }
+    }
+    *out = idx;
+    return KNN_OK;
+}
+
+void knn_index_destroy(knn_index *idx)
+{
+    if (!idx)
+        return;
+    {
+        DeviceGuard guard(idx->device);
+        if (idx->owned_refs)
+            (void)hipFree(idx->owned_refs);
+        for (auto &ev : idx->events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    }
+    delete idx;
+}
+
+int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream)
+{
+    if (m < 0 || (m > 0 && !keys_dev))
+        return fail(KNN_EINVAL, "knn_keys_init: bad arguments");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_keys_init: hipSetDevice failed");
+    HIP_TRY(knn_keys_fill_launch((u64 *)keys_dev, m, (hipStream_t)stream));
+    return KNN_OK;
+}
+
+int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
+                         unsigned long long *keys_dev, void *stream)
+{
+    if (!idx || m < 0 || (m > 0 && (!queries_dev || !keys_dev)))
+        return fail(KNN_EINVAL, "knn_index_query_keys: bad arguments");
+    if (m == 0 || idx->n == 0)
+        return KNN_OK;
+    DeviceGuard guard(idx->device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_index_query_keys: hipSetDevice failed");
+    idx->stats[0] = 1;
+    idx->stats[1] = 0;
+    idx->stats[2] = 0;
+    hipStream_t s = (hipStream_t)stream;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (idx->timing) {
+        if (idx->events_used == idx->events.size()) {
+            std::pair<hipEvent_t, hipEvent_t> fresh;
+            HIP_TRY(hipEventCreate(&fresh.first));
+            HIP_TRY(hipEventCreate(&fresh.second));
+            idx->events.push_back(fresh);
+        }
+        ev = &idx->events[idx->events_used++];
+    }
+    if (ev)
+        HIP_TRY(hipEventRecord(ev->first, s));
+    HIP_TRY(knn_exact_launch(idx->k, m, idx->n, idx->base, queries_dev, idx->refs, (u64 *)keys_dev,
+                             idx->num_cu, s));
+    if (ev)
+        HIP_TRY(hipEventRecord(ev->second, s));
+    return KNN_OK;
+}
+
+int knn_index_timing(knn_index *idx, int enable)
+{
+    if (!idx)
+        return fail(KNN_EINVAL, "knn_index_timing: null index");
+    idx->timing = enable != 0;
+    idx->events_used = 0;
+    return KNN_OK;
+}
+
+int knn_index_timing_read(knn_index *idx, int *launches, double *total_ms)
+{
+    if (!idx || !launches || !total_ms)
+        return fail(KNN_EINVAL, "knn_index_timing_read: bad arguments");
+    DeviceGuard guard(idx->device);
+    double sum = 0.0;
+    for (size_t i = 0; i < idx->events_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(idx->events[i].second));
+        HIP_TRY(hipEventElapsedTime(&ms, idx->events[i].first, idx->events[i].second));
+        sum += ms;
+    }
+    *launches = (int)idx->events_used;
+    *total_ms = sum;
+    idx->events_used = 0;
+    return KNN_OK;
+}
+
+int knn_index_last_stats(knn_index *idx, long long stats[4])
+{
+    if (!idx || !stats)
+        return fail(KNN_EINVAL, "knn_index_last_stats: bad arguments");
+    memcpy(stats, idx->stats, sizeof idx->stats);
+    return KNN_OK;
+}
+
+int knn_keys_to_indices(int device, const unsigned long long *keys_dev, int m, int *out_dev,
+                        void *stream)
+{
+    if (m < 0 || (m > 0 && (!keys_dev || !out_dev)))
+        return fail(KNN_EINVAL, "knn_keys_to_indices: bad arguments");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_keys_to_indices: hipSetDevice failed");
+    HIP_TRY(knn_keys_unpack_launch((const u64 *)keys_dev, m, out_dev, (hipStream_t)stream));
+    return KNN_OK;
+}
+
+int knn_synth_fill_device(int device, float *dst_dev, long long count, unsigned long long seed,
+                          long long first, void *stream)
+{
+    if (count < 0 || (count > 0 && !dst_dev))
+        return fail(KNN_EINVAL, "knn_synth_fill_device: bad arguments");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_synth_fill_device: hipSetDevice failed");
+    HIP_TRY(knn_synth_fill_launch(dst_dev, count, seed, first, (hipStream_t)stream));
+    return KNN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Queries on the host, packed keys back on the host; everything else stays on `idx->device`.
+int query_keys_host(knn_index *idx, int m, const float *queries_host, u64 *keys_host)
+{
+    DeviceGuard guard(idx->device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "query: hipSetDevice failed");
+    float *q_dev = nullptr;
+    u64 *keys_dev = nullptr;
+    const size_t qbytes = (size_t)m * (size_t)idx->k * sizeof(float);
+    int rc = KNN_OK;
+    hipError_t e = hipMalloc((void **)&q_dev, qbytes);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&keys_dev, (size_t)m * sizeof(u64));
+    if (e == hipSuccess)
+        e = hipMemcpy(q_dev, queries_host, qbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        rc = fail(KNN_EHIP, "query: staging queries", hipGetErrorString(e));
+    if (rc == KNN_OK)
+        rc = knn_keys_init(idx->device, keys_dev, m, nullptr);
+    if (rc == KNN_OK)
+        rc = knn_index_query_keys(idx, m, q_dev, keys_dev, nullptr);
+    if (rc == KNN_OK) {
+        e = hipMemcpy(keys_host, keys_dev, (size_t)m * sizeof(u64), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = fail(KNN_EHIP, "query: D2H keys", hipGetErrorString(e));
+    }
+    (void)hipFree(q_dev);
+    (void)hipFree(keys_dev);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *out_host)
+{
+    if (!idx || m < 0 || (m > 0 && (!queries_host || !out_host)))
+        return fail(KNN_EINVAL, "knn_index_query_host: bad arguments");
+    if (m == 0)
+        return KNN_OK;
+    std::vector<u64> keys((size_t)m, kKeyInit);
+    if (idx->n > 0) {
+        int rc = query_keys_host(idx, m, queries_host, keys.data());
+        if (rc != KNN_OK)
+            return rc;
+    }
+    for (int j = 0; j < m; ++j)
+        out_host[j] = (int)(unsigned)(keys[(size_t)j] & 0xFFFFFFFFull);
+    return KNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The drop-in entry point (reference core.h:71, core.cu:1282-1297 -> v8, core.cu:856-958).
+// ---------------------------------------------------------------------------------------------
+extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *referencePoints,
+                             int **results)
+{
+    if (k < 1 || m < 1 || n < 1 || !searchPoints || !referencePoints || !results) {
+        fail(KNN_EINVAL, "cudaCallback: k, m, n must be >= 1 and pointers non-null");
+        die(__FILE__, __LINE__, KNN_EINVAL, g_err.c_str());
+    }
+    const int ndev = knn_device_count();
+    if (ndev < 1) {
+        // The reference computes on the CPU here (core.cu:869-870); this library has no CPU path.
+        fail(KNN_ENODEV, "cudaCallback: no HIP device visible (this library has no CPU fallback)");
+        die(__FILE__, __LINE__, KNN_ENODEV, g_err.c_str());
+    }
+    // core.cu:865-868: one shard per GPU, never more shards than points.
+    long long shards = g_opt_shards > 0 ? (long long)g_opt_shards : (long long)ndev;
+    if (shards > n)
+        shards = n;
+    // core.cu:875: thread_n = divup(n, num_gpus); the last shard takes what is left.  A shard
+    // past the end is empty here (the reference patches it to one overlapping point,
+    // core.cu:881-882; an empty shard gives the same minimum).
+    const long long per = (n + shards - 1) / shards;
+
+    std::vector<std::vector<u64>> shard_keys((size_t)shards);
+    std::vector<int> shard_rc((size_t)shards, KNN_OK);
+    std::vector<std::string> shard_err((size_t)shards);
+
+    auto run_shard = [&](long long g) {
+        const long long lo = std::min<long long>(g * per, n);
+        const long long hi = std::min<long long>(lo + per, n);
+        std::vector<u64> &keys = shard_keys[(size_t)g];
+        keys.assign((size_t)m, kKeyInit);
+        if (hi <= lo)
+            return;
+        knn_index *idx = nullptr;
+        int rc = knn_index_create(&idx, (int)(g % ndev), k, hi - lo,
+                                  referencePoints + (size_t)lo * (size_t)k, 0, lo, nullptr);
+        if (rc == KNN_OK)
+            rc = query_keys_host(idx, m, searchPoints, keys.data());
+        knn_index_destroy(idx);
+        shard_rc[(size_t)g] = rc;
+        if (rc != KNN_OK)
+            shard_err[(size_t)g] = g_err;
+    };
+
+    // One host thread per GPU (core.cu:873); shards that share a device run back to back.
+    const int nthreads = (int)std::min<long long>(shards, ndev);
+    if (nthreads <= 1) {
+        for (long long g = 0; g < shards; ++g)
+            run_shard(g);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] {
+                for (long long g = t; g < shards; g += nthreads)
+                    run_shard(g);
+            });
+        for (auto &th : pool)
+            th.join();
+    }
+    for (long long g = 0; g < shards; ++g)
+        if (shard_rc[(size_t)g] != KNN_OK)
+            die(__FILE__, __LINE__, shard_rc[(size_t)g], shard_err[(size_t)g].c_str());
+
+    // Final reduce: unsigned min of packed keys == lexicographic (distance, global index).
+    int *out = (int *)malloc(sizeof(int) * (size_t)m);  // caller free()s (main.cu:98,175)
+    if (!out)
+        die(__FILE__, __LINE__, KNN_ENOMEM, "malloc(results)");
+    for (int j = 0; j < m; ++j) {
+        u64 best = kKeyInit;
+        for (long long g = 0; g < shards; ++g)
+            best = std::min(best, shard_keys[(size_t)g][(size_t)j]);
+        out[j] = (int)(unsigned)(best & 0xFFFFFFFFull);
+    }
+    *results = out;
+}

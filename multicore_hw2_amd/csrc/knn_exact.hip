@@ -1,0 +1,449 @@
+// knn_exact.hip — exact fused distance + argmin kernels for gfx950 (MI355X).
+//
+// Every kernel here evaluates the squared L2 distance with the arithmetic of the reference's
+// serial path v0 (sources/src/core.cu:44-49): d = q - r; p = d * d; acc = acc + p for
+// dimension 0..k-1, each operation rounded once to binary32 (the file is compiled with
+// -ffp-contract=off and tests/test_build.py checks the code object holds no fused
+// multiply-add), and folds (distance, global index) into a packed 64-bit key with an unsigned
+// min, which reproduces v0's "first strict minimum" (core.cu:50-54) for any visiting order.
+//
+// Two shapes of kernel, chosen by m (host side: knn_exact_launch):
+//   * qreg  — many queries: each lane keeps 2*QP queries' coordinates in VGPRs (packed in
+//             float2 so sub/mul/add issue as v_pk_*_f32 on two queries at once) and every
+//             wave streams its block's slice of references through SGPRs (wave-uniform
+//             s_load of one AoS row = one k-vector).  The (min, argmin) pair lives in the
+//             lane, so no cross-lane reduction; one 64-bit atomic min per query per block.
+//             VALU-bound: 3k+3 lane-ops per (query, reference) pair.
+//   * rlane — few queries: each lane owns one reference row per step (read once from HBM),
+//             query coordinates are wave-uniform; wave64 shuffle reduction of the packed
+//             key at the end.  HBM-bound for m <~ 10.
+//
+// This is not a translation of the reference's one-block-per-query kernels (core.cu:808-855):
+// no SoA transpose pass, no per-block result array, no host second-level reduce.
+#include "knn_common.h"
+
+#include <math.h>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define KNN_BLOCK 256
+#define KNN_WAVES (KNN_BLOCK / KNN_WAVE)
+
+__device__ __forceinline__ u64 pack_key(float d2, unsigned idx)
+{
+    return ((u64)__float_as_uint(d2) << 32) | (u64)idx;
+}
+
+__device__ __forceinline__ void key_atomic_min(u64 *p, u64 key)
+{
+    // gfx950: global_atomic_umin_x2, device scope (all XCDs).
+    __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------
+// qreg: queries in VGPRs (pairs packed as float2), references streamed as wave-uniform rows.
+//   grid.x = reference slices, grid.y = groups of KNN_WAVES * 128 * QP queries, block = 256.
+// ------------------------------------------------------------------------------------------
+template <int K, int QP>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restrict__ Q,
+                                                            const float *__restrict__ R, int m,
+                                                            long long n, long long base,
+                                                            u64 *__restrict__ keys,
+                                                            long long refs_per_block)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & (KNN_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q0 = (blockIdx.y * KNN_WAVES + wave) * (2 * QP * KNN_WAVE);
+    if (q0 >= m)
+        return;
+
+    f2 q[QP][K];
+    f2 best[QP];
+    unsigned bidx[2 * QP];
+#pragma unroll
+    for (int p = 0; p < QP; ++p) {
+        const int qa = min(q0 + (2 * p) * KNN_WAVE + lane, m - 1);
+        const int qb = min(q0 + (2 * p + 1) * KNN_WAVE + lane, m - 1);
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            q[p][d].x = Q[(size_t)qa * K + d];
+            q[p][d].y = Q[(size_t)qb * K + d];
+        }
+        best[p].x = INFINITY;
+        best[p].y = INFINITY;
+        bidx[2 * p] = 0u;
+        bidx[2 * p + 1] = 0u;
+    }
+
+    const long long i0 = (long long)blockIdx.x * refs_per_block;
+    const long long i1 = min(n, i0 + refs_per_block);
+    unsigned gidx = (unsigned)(base + i0);  // global index of the current reference (low 32 bits)
+    const float *__restrict__ r = R + (size_t)i0 * K;
+
+#pragma unroll 2
+    for (long long i = i0; i < i1; ++i, ++gidx, r += K) {
+        float rv[K];
+#pragma unroll
+        for (int d = 0; d < K; ++d)
+            rv[d] = r[d];  // wave-uniform address -> scalar load
+#pragma unroll
+        for (int p = 0; p < QP; ++p) {
+            f2 acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                const f2 rr = {rv[d], rv[d]};
+                const f2 diff = q[p][d] - rr;
+                const f2 sq = diff * diff;
+                acc = acc + sq;
+            }
+            if (best[p].x > acc.x) {
+                best[p].x = acc.x;
+                bidx[2 * p] = gidx;
+            }
+            if (best[p].y > acc.y) {
+                best[p].y = acc.y;
+                bidx[2 * p + 1] = gidx;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int p = 0; p < QP; ++p) {
+        const int qa = q0 + (2 * p) * KNN_WAVE + lane;
+        const int qb = q0 + (2 * p + 1) * KNN_WAVE + lane;
+        // best == +INF means no reference beat +INF: leave the key alone (v0 keeps index 0).
+        if (qa < m && best[p].x < INFINITY)
+            key_atomic_min(&keys[qa], pack_key(best[p].x, bidx[2 * p]));
+        if (qb < m && best[p].y < INFINITY)
+            key_atomic_min(&keys[qb], pack_key(best[p].y, bidx[2 * p + 1]));
+    }
+}
+
+// One query per lane, no packing: m in [~48, 128*KNN_WAVES) where pairs would idle lanes.
+template <int K>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__restrict__ Q,
+                                                             const float *__restrict__ R, int m,
+                                                             long long n, long long base,
+                                                             u64 *__restrict__ keys,
+                                                             long long refs_per_block)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & (KNN_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q0 = (blockIdx.y * KNN_WAVES + wave) * KNN_WAVE;
+    if (q0 >= m)
+        return;
+    const int qi = q0 + lane;
+    const int qc = min(qi, m - 1);
+    float q[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+        q[d] = Q[(size_t)qc * K + d];
+    float best = INFINITY;
+    unsigned bidx = 0u;
+
+    const long long i0 = (long long)blockIdx.x * refs_per_block;
+    const long long i1 = min(n, i0 + refs_per_block);
+    unsigned gidx = (unsigned)(base + i0);
+    const float *__restrict__ r = R + (size_t)i0 * K;
+#pragma unroll 4
+    for (long long i = i0; i < i1; ++i, ++gidx, r += K) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const float diff = q[d] - r[d];
+            const float sq = diff * diff;
+            acc = acc + sq;
+        }
+        if (best > acc) {
+            best = acc;
+            bidx = gidx;
+        }
+    }
+    if (qi < m && best < INFINITY)
+        key_atomic_min(&keys[qi], pack_key(best, bidx));
+}
+
+// ------------------------------------------------------------------------------------------
+// rlane: one reference row per lane per step, QT wave-uniform queries per pass.
+//   grid.x = blocks striding over the references, grid.y = ceil(m / QT), block = 256.
+//   K > 0: compile-time dimension (rows read with the widest aligned loads the compiler
+//   finds); K == 0: run-time k.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 wave_min_u64(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_xor(v, off, KNN_WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int K, int QT>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__restrict__ Q,
+                                                             const float *__restrict__ R, int krt,
+                                                             int m, long long n, long long base,
+                                                             u64 *__restrict__ keys)
+{
+#pragma clang fp contract(off)
+    const int k = K > 0 ? K : krt;
+    const int q0 = blockIdx.y * QT;
+    float best[QT];
+    unsigned bidx[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        best[t] = INFINITY;
+        bidx[t] = 0u;
+    }
+    const float *__restrict__ qrow[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+        qrow[t] = Q + (size_t)min(q0 + t, m - 1) * k;  // wave-uniform
+
+    const long long stride = (long long)gridDim.x * KNN_BLOCK;
+    for (long long i = (long long)blockIdx.x * KNN_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float *__restrict__ r = R + (size_t)i * k;
+        float acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            acc[t] = 0.0f;
+        if (K > 0) {
+            float rv[K > 0 ? K : 1];
+#pragma unroll
+            for (int d = 0; d < K; ++d)
+                rv[d] = r[d];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                    const float diff = qrow[t][d] - rv[d];
+                    const float sq = diff * diff;
+                    acc[t] = acc[t] + sq;
+                }
+            }
+        } else {
+            for (int d = 0; d < k; ++d) {
+                const float rv = r[d];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const float diff = qrow[t][d] - rv;
+                    const float sq = diff * diff;
+                    acc[t] = acc[t] + sq;
+                }
+            }
+        }
+        const unsigned gidx = (unsigned)(base + i);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            if (best[t] > acc[t]) {
+                best[t] = acc[t];
+                bidx[t] = gidx;
+            }
+        }
+    }
+
+    const int lane = threadIdx.x & (KNN_WAVE - 1);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        // A lane that never updated carries (+INF, 0) == kKeyInit, neutral under min.
+        const u64 key = wave_min_u64(pack_key(best[t], bidx[t]));
+        if (lane == 0 && q0 + t < m && key < kKeyInit)
+            key_atomic_min(&keys[q0 + t], key);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact re-rank of a candidate list produced by the MFMA filter: one candidate per thread.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__restrict__ Q,
+                                                               const float *__restrict__ R, int k,
+                                                               long long base,
+                                                               const u64 *__restrict__ cand,
+                                                               const unsigned *__restrict__ count,
+                                                               unsigned capacity,
+                                                               u64 *__restrict__ keys)
+{
+#pragma clang fp contract(off)
+    const unsigned total = min(*count, capacity);
+    for (unsigned c = blockIdx.x * KNN_BLOCK + threadIdx.x; c < total; c += gridDim.x * KNN_BLOCK) {
+        const u64 e = cand[c];
+        const unsigned qi = (unsigned)(e >> 32);
+        const unsigned ri = (unsigned)(e & 0xFFFFFFFFu);
+        const float *__restrict__ q = Q + (size_t)qi * k;
+        const float *__restrict__ r = R + (size_t)ri * k;
+        float acc = 0.0f;
+        for (int d = 0; d < k; ++d) {
+            const float diff = q[d] - r[d];
+            const float sq = diff * diff;
+            acc = acc + sq;
+        }
+        if (acc < INFINITY)  // false for NaN too: v0 never selects those
+            key_atomic_min(&keys[qi], pack_key(acc, (unsigned)(base + ri)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small utility kernels.
+// ------------------------------------------------------------------------------------------
+__global__ void knn_keys_fill_kernel(u64 *keys, int m)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m)
+        keys[i] = kKeyInit;
+}
+
+__global__ void knn_keys_unpack_kernel(const u64 *__restrict__ keys, int m, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m)
+        out[i] = (int)(unsigned)(keys[i] & 0xFFFFFFFFull);
+}
+
+__global__ void knn_synth_fill_kernel(float *__restrict__ dst, long long count, u64 seed,
+                                      long long first)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        u64 z = seed + ((u64)(first + i) + 1ull) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        dst[i] = (float)(unsigned)(z >> 40) * 0x1.0p-24f;  // < 2^24: exact
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side dispatch.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct SliceGeom {
+    long long refs_per_block;
+    unsigned nslices;
+};
+
+// Slice the references so the grid has ~8 blocks per CU (each block 4 waves) but a slice is
+// never shorter than `min_refs` (below that the per-block atomics and query loads dominate).
+SliceGeom slice_refs(long long n, unsigned qgroups, int num_cu, long long min_refs)
+{
+    long long want = (long long)num_cu * 8 / (qgroups ? qgroups : 1);
+    if (want < 1)
+        want = 1;
+    long long per = (n + want - 1) / want;
+    if (per < min_refs)
+        per = min_refs;
+    SliceGeom g;
+    g.refs_per_block = per;
+    g.nslices = (unsigned)((n + per - 1) / per);
+    return g;
+}
+
+template <int K>
+hipError_t launch_qreg_k(int m, long long n, long long base, const float *q, const float *r,
+                         u64 *keys, int num_cu, hipStream_t s)
+{
+    // queries per block: 1024 (QP=2) when m fills most of it, else 512 (QP=1), else 256 (unpacked)
+    if (m > 3 * KNN_WAVE * KNN_WAVES) {
+        const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 4 * KNN_WAVE);
+        const SliceGeom g = slice_refs(n, qg, num_cu, 512);
+        hipLaunchKernelGGL((knn_exact_qreg<K, 2>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
+                           m, n, base, keys, g.refs_per_block);
+    } else if (m > KNN_WAVE * KNN_WAVES) {
+        const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 2 * KNN_WAVE);
+        const SliceGeom g = slice_refs(n, qg, num_cu, 512);
+        hipLaunchKernelGGL((knn_exact_qreg<K, 1>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
+                           m, n, base, keys, g.refs_per_block);
+    } else {
+        const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * KNN_WAVE);
+        const SliceGeom g = slice_refs(n, qg, num_cu, 512);
+        hipLaunchKernelGGL((knn_exact_qreg1<K>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r, m,
+                           n, base, keys, g.refs_per_block);
+    }
+    return hipGetLastError();
+}
+
+template <int K>
+hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float *q, const float *r,
+                          u64 *keys, int num_cu, hipStream_t s)
+{
+    constexpr int QT = 4;
+    const unsigned qt = (unsigned)knn_divup(m, QT);
+    long long blocks = (n + KNN_BLOCK - 1) / KNN_BLOCK;
+    const long long cap = (long long)num_cu * 8;
+    if (blocks > cap)
+        blocks = cap;
+    if (blocks < 1)
+        blocks = 1;
+    hipLaunchKernelGGL((knn_exact_rlane<K, QT>), dim3((unsigned)blocks, qt), dim3(KNN_BLOCK), 0, s, q,
+                       r, k, m, n, base, keys);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t knn_exact_launch(int k, int m, long long n, long long base, const float *q,
+                            const float *r, u64 *keys, int num_cu, hipStream_t s)
+{
+    if (n <= 0 || m <= 0)
+        return hipSuccess;
+    // Few queries: stream references once per 4 queries (HBM-bound).  Many: qreg (VALU-bound).
+    const bool many = m >= 48;
+    if (many) {
+        switch (k) {
+        case 1: return launch_qreg_k<1>(m, n, base, q, r, keys, num_cu, s);
+        case 2: return launch_qreg_k<2>(m, n, base, q, r, keys, num_cu, s);
+        case 3: return launch_qreg_k<3>(m, n, base, q, r, keys, num_cu, s);
+        case 4: return launch_qreg_k<4>(m, n, base, q, r, keys, num_cu, s);
+        case 8: return launch_qreg_k<8>(m, n, base, q, r, keys, num_cu, s);
+        case 16: return launch_qreg_k<16>(m, n, base, q, r, keys, num_cu, s);
+        default: break;
+        }
+    }
+    switch (k) {
+    case 1: return launch_rlane_k<1>(k, m, n, base, q, r, keys, num_cu, s);
+    case 2: return launch_rlane_k<2>(k, m, n, base, q, r, keys, num_cu, s);
+    case 3: return launch_rlane_k<3>(k, m, n, base, q, r, keys, num_cu, s);
+    case 4: return launch_rlane_k<4>(k, m, n, base, q, r, keys, num_cu, s);
+    case 8: return launch_rlane_k<8>(k, m, n, base, q, r, keys, num_cu, s);
+    case 16: return launch_rlane_k<16>(k, m, n, base, q, r, keys, num_cu, s);
+    default: return launch_rlane_k<0>(k, m, n, base, q, r, keys, num_cu, s);
+    }
+}
+
+hipError_t knn_rerank_launch(int k, const float *q, const float *r, long long base, const u64 *cand,
+                             const unsigned *count, unsigned capacity, u64 *keys, hipStream_t s)
+{
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3(256), dim3(KNN_BLOCK), 0, s, q, r, k, base, cand, count,
+                       capacity, keys);
+    return hipGetLastError();
+}
+
+hipError_t knn_keys_fill_launch(u64 *keys, int m, hipStream_t s)
+{
+    if (m <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(knn_keys_fill_kernel, dim3(knn_divup(m, 256)), dim3(256), 0, s, keys, m);
+    return hipGetLastError();
+}
+
+hipError_t knn_keys_unpack_launch(const u64 *keys, int m, int *out, hipStream_t s)
+{
+    if (m <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(knn_keys_unpack_kernel, dim3(knn_divup(m, 256)), dim3(256), 0, s, keys, m, out);
+    return hipGetLastError();
+}
+
+hipError_t knn_synth_fill_launch(float *dst, long long count, u64 seed, long long first, hipStream_t s)
+{
+    if (count <= 0)
+        return hipSuccess;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(knn_synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, count, seed,
+                       first);
+    return hipGetLastError();
+}

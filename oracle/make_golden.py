@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ta_indices.txt and pin the oracle to the reference.
+
+Runs in the build container only (needs /root/reference).  For the 8 TA samples
+of reference sources/src/main.cu:28-39 at seed 1000 (main.cu:43) it
+
+  1. draws the inputs with the oracle's from-scratch glibc-rand restatement and
+     cross-checks the stream against this machine's libc srand()/rand(),
+  2. runs the oracle (knn_oracle_v0),
+  3. asserts the result equals the index lines (1,3,...,15) of the reference's
+     golden file results.csv, and
+  4. writes those 8 index lines to tests/golden/ta_indices.txt (data only: the
+     expected outputs; inputs are regenerated from the seed at test time).
+
+Also writes tests/golden/ta_first_draws.txt: the first 16 rand() outputs for
+seed 1000, so the generator restatement is pinned on boxes whose libc differs.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF_CSV = "/root/reference/results.csv"
+SAMPLES = [(3, 1, 2), (3, 2, 8), (3, 1, 1024), (3, 1, 65536), (16, 1, 65536),
+           (3, 1024, 1024), (3, 1024, 65536), (16, 1024, 65536)]
+SEED = 1000
+
+
+def main():
+    lib = ctypes.CDLL(os.path.join(HERE, "libknn_oracle.so"))
+    lib.ta_rand.restype = ctypes.c_int
+    libc = ctypes.CDLL("libc.so.6")
+    libc.rand.restype = ctypes.c_int
+
+    # 1. generator restatement vs libc
+    lib.ta_srand(SEED)
+    libc.srand(SEED)
+    first = []
+    for i in range(100000):
+        a, b = lib.ta_rand(), libc.rand()
+        assert a == b, f"rand stream diverges from libc at draw {i}: {a} vs {b}"
+        if i < 16:
+            first.append(a)
+
+    with open(REF_CSV) as f:
+        ref_lines = f.read().splitlines()
+    assert len(ref_lines) == 16, len(ref_lines)
+
+    # 2-3. oracle vs results.csv
+    lib.ta_srand(SEED)
+    out_lines = []
+    for i, (k, m, n) in enumerate(SAMPLES):
+        Q = np.empty(k * m, dtype=np.float32)
+        R = np.empty(k * n, dtype=np.float32)
+        lib.ta_get_sample(k, m, n, Q.ctypes.data_as(ctypes.c_void_p), R.ctypes.data_as(ctypes.c_void_p))
+        out = np.empty(m, dtype=np.int32)
+        lib.knn_oracle_v0(k, m, ctypes.c_longlong(n), Q.ctypes.data_as(ctypes.c_void_p),
+                          R.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        gold = [int(t) for t in ref_lines[2 * i].split(",") if t.strip() != ""]
+        assert len(gold) == m, (i, len(gold), m)
+        assert gold == out.tolist(), f"sample {i} {(k, m, n)}: oracle differs from results.csv line {2 * i + 1}"
+        out_lines.append(" ".join(str(v) for v in gold))
+        print(f"sample {i} (k={k}, m={m}, n={n}): {m} indices match results.csv:{2 * i + 1}")
+
+    # 4. fixtures
+    gdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gdir, exist_ok=True)
+    with open(os.path.join(gdir, "ta_indices.txt"), "w") as f:
+        f.write("# nearest indices for the 8 TA samples (k,m,n) = " + " ".join(map(str, SAMPLES)) + "\n")
+        f.write("# seed 1000; = odd lines of the reference's results.csv (sha256 3b19edfb...0ded9); made by oracle/make_golden.py\n")
+        for line in out_lines:
+            f.write(line + "\n")
+    with open(os.path.join(gdir, "ta_first_draws.txt"), "w") as f:
+        f.write("# first 16 outputs of glibc rand() after srand(1000); made by oracle/make_golden.py\n")
+        f.write(" ".join(str(v) for v in first) + "\n")
+    print("wrote tests/golden/ta_indices.txt, ta_first_draws.txt")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

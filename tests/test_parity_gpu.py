@@ -1,0 +1,214 @@
+"""Parity tests proper: the HIP path (through the C-ABI of libknn_mi355x.so) against the CPU
+oracle and the committed golden vectors.  Bar: bit-exact nearest indices."""
+import os
+
+import numpy as np
+import pytest
+
+import multicore_hw2_amd as pkg
+from tests.oracle_lib import TA_SAMPLES
+from tests.test_oracle import read_golden_indices
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
+    assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
+    yield
+    pkg.set_option("path", 0)
+    pkg.set_option("shards", 0)
+
+
+@pytest.fixture(params=[1, 2, 0], ids=["exact", "filter", "auto"])
+def path(request):
+    pkg.set_option("path", request.param)
+    yield request.param
+    pkg.set_option("path", 0)
+
+
+def test_ta_samples_match_reference_golden_file(oracle, path):
+    """The reference's own test (main.cu:28-39, seed 1000) against its results.csv."""
+    gold = read_golden_indices()
+    for i, (k, m, n, Q, R) in enumerate(oracle.ta_samples()):
+        got = pkg.cudaCallback(k, m, n, Q, R)
+        np.testing.assert_array_equal(got, gold[i], err_msg=f"TA sample {i} {(k, m, n)}")
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 16, 17, 33])
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 2), (2, 8), (1, 1025), (3, 4097), (47, 1000), (48, 1000),
+                                 (64, 333), (130, 2049), (257, 5000), (700, 3001), (1024, 1024), (1500, 777)])
+def test_ragged_shapes_bit_exact(oracle, path, k, m, n):
+    rng = np.random.default_rng(k * 100003 + m * 1009 + n)
+    Q = rng.random((m, k), dtype=np.float32)
+    R = rng.random((n, k), dtype=np.float32)
+    got = pkg.cudaCallback(k, m, n, Q, R)
+    np.testing.assert_array_equal(got, oracle.v0(k, Q, R))
+
+
+@pytest.mark.parametrize("k,m,n", [(3, 1024, 65536), (16, 1024, 65536), (16, 64, 1 << 18), (3, 5, 1 << 20),
+                                   (16, 1, 1 << 20), (8, 300, 100000)])
+def test_synthetic_uniform_bit_exact(oracle, path, k, m, n):
+    Q, R = oracle.synth(m * k, 1000), oracle.synth(n * k, 1001)
+    got = pkg.cudaCallback(k, m, n, Q, R)
+    np.testing.assert_array_equal(got, oracle.v0(k, Q, R))
+
+
+def test_ties_pick_lowest_index_across_slices_and_shards(oracle, path):
+    k, m, n = 16, 1024, 40000
+    rng = np.random.default_rng(5)
+    R = rng.random((n, k), dtype=np.float32)
+    Q = rng.random((m, k), dtype=np.float32)
+    dup = rng.integers(0, n, size=m)
+    Q[:] = R[dup]                     # every query coincides with a reference ...
+    R[(dup + 7919) % n] = R[dup]      # ... that also appears a second time, far away
+    R[n - 1] = R[0]
+    want = oracle.v0(k, Q, R)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), want)
+    for shards in (2, 3, 8):
+        pkg.set_option("shards", shards)
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), want, err_msg=f"shards={shards}")
+    pkg.set_option("shards", 0)
+    # all references identical: index 0 for every query
+    R[:] = R[123]
+    np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), np.zeros(m, dtype=np.int32))
+
+
+def test_nan_inf_and_overflow_semantics(oracle, path):
+    k = 4
+    rng = np.random.default_rng(11)
+    R = rng.random((5000, k), dtype=np.float32)
+    Q = rng.random((100, k), dtype=np.float32)
+    R[::7, 1] = np.nan
+    R[5::11, 2] = np.inf
+    R[3::13, 0] = -np.inf
+    Q[3, 0] = np.nan          # NaN query: nothing beats +INF -> index 0
+    Q[4, 1] = np.inf
+    np.testing.assert_array_equal(pkg.cudaCallback(k, 100, 5000, Q, R), oracle.v0(k, Q, R))
+    big = np.full((64, k), 3e38, dtype=np.float32)
+    qneg = np.full((64, k), -3e38, dtype=np.float32)   # every distance overflows to +INF -> 0
+    np.testing.assert_array_equal(pkg.cudaCallback(k, 64, 64, qneg, big), np.zeros(64, dtype=np.int32))
+    Rn = np.full((300, k), np.nan, dtype=np.float32)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, 100, 300, Q, Rn), np.zeros(100, dtype=np.int32))
+
+
+def test_wide_dynamic_range_and_offsets(oracle, path):
+    """Data far from the origin / tiny / huge scales: the filter's error bound must hold or the
+    library must take the exact path; either way indices are bit-exact."""
+    k, m, n = 16, 256, 30000
+    rng = np.random.default_rng(3)
+    for scale, offset in [(1e-3, 1000.0), (1e6, -5e6), (1e-20, 0.0), (1e15, 1e15), (1.0, 0.0)]:
+        R = (rng.random((n, k), dtype=np.float32) * np.float32(scale) + np.float32(offset)).astype(np.float32)
+        Q = (rng.random((m, k), dtype=np.float32) * np.float32(scale) + np.float32(offset)).astype(np.float32)
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0(k, Q, R),
+                                      err_msg=f"scale={scale} offset={offset}")
+    # clustered data: many near-ties
+    centers = rng.random((8, k), dtype=np.float32)
+    R = (centers[rng.integers(0, 8, n)] + rng.normal(0, 1e-4, (n, k))).astype(np.float32)
+    Q = (centers[rng.integers(0, 8, m)] + rng.normal(0, 1e-4, (m, k))).astype(np.float32)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0(k, Q, R))
+    # integer lattice: massive exact ties
+    R = rng.integers(0, 4, (n, k)).astype(np.float32)
+    Q = rng.integers(0, 4, (m, k)).astype(np.float32)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0(k, Q, R))
+
+
+def test_sharded_callback_equals_single_shard(oracle, path):
+    """cudaCallback's partition + key merge (what the reference got wrong, core.cu:941-943)."""
+    k, m, n = 3, 200, 10007
+    Q, R = oracle.synth(m * k, 21), oracle.synth(n * k, 22)
+    want = oracle.v0(k, Q, R)
+    for shards in (1, 2, 4, 7, 8, 64):
+        pkg.set_option("shards", shards)
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), want, err_msg=f"shards={shards}")
+    pkg.set_option("shards", 0)
+    # more shards than points (core.cu:867-868)
+    pkg.set_option("shards", 8)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, m, 3, Q, R[:9]), oracle.v0(k, Q, R[:9]))
+    pkg.set_option("shards", 0)
+
+
+def test_index_api_keys_fold_across_shards_on_device(oracle, path):
+    """knn_index_*: device-resident shards folding into one key array (the bench.py data path)."""
+    import torch
+    k, m, n = 16, 512, 50000
+    Q, R = oracle.synth(m * k, 31), oracle.synth(n * k, 32)
+    dev = torch.device("cuda:0")
+    q_d = torch.from_numpy(Q).to(dev)
+    r_d = torch.from_numpy(R).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    pkg.keys_init(keys.data_ptr(), m, stream=stream)
+    idxs = []
+    for lo, hi in pkg.shard_bounds(n, 3):
+        ix = pkg.KnnIndex(k, r_d.data_ptr() + lo * k * 4, n_local=hi - lo, base_index=lo, refs_on_device=True,
+                          stream=stream)
+        ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=stream)
+        idxs.append(ix)
+    pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R))
+    # keys carry the exact v0 distance bits
+    kk = keys.cpu().numpy().view(np.uint64)
+    j = 17
+    d2 = np.array([kk[j] >> np.uint64(32)], dtype=np.uint64).astype(np.uint32).view(np.float32)[0]
+    assert d2 == np.float32(oracle.dist2(Q[j * k:(j + 1) * k], R[int(out[j]) * k:(int(out[j]) + 1) * k]))
+    for ix in idxs:
+        ix.close()
+
+
+def test_device_synth_fill_matches_oracle_generator(oracle):
+    import torch
+    x = torch.empty(100003, dtype=torch.float32, device="cuda:0")
+    pkg.synth_fill_device(x.data_ptr(), x.numel(), 1001, first=12345,
+                          stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(x.cpu().numpy(), oracle.synth(100003, 1001, first=12345))
+
+
+def test_headline_shape_properties(oracle, path):
+    """BASELINE config C3 (k=16, m=1024, n=2^24) at full size: checked through properties that do
+    not need a full CPU scan — (1) a seeded subset of queries against the full reference set with
+    the oracle, (2) planting an exact copy of each query makes that copy's index the answer,
+    (3) splitting the set into shards and min-merging keys gives the same indices."""
+    import torch
+    k, m, n = 16, 1024, 1 << 24
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
+    q_d = torch.empty(m * k, dtype=torch.float32, device=dev)
+    pkg.synth_fill_device(r_d.data_ptr(), n * k, 1001, stream=stream)
+    pkg.synth_fill_device(q_d.data_ptr(), m * k, 1000, stream=stream)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+
+    def run(shards):
+        pkg.keys_init(keys.data_ptr(), m, stream=stream)
+        held = []
+        for lo, hi in pkg.shard_bounds(n, shards):
+            ix = pkg.KnnIndex(k, r_d.data_ptr() + lo * k * 4, n_local=hi - lo, base_index=lo,
+                              refs_on_device=True, stream=stream)
+            ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=stream)
+            held.append(ix)
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        for ix in held:
+            ix.close()
+        return out.cpu().numpy().copy()
+
+    whole = run(1)
+    np.testing.assert_array_equal(run(8), whole)
+    # (1) 24 queries against all 2^24 references on the host
+    R = r_d.cpu().numpy()
+    Q = q_d.cpu().numpy()
+    sel = np.random.default_rng(0).choice(m, 24, replace=False)
+    want = oracle.v0(k, Q.reshape(m, k)[sel], R)
+    np.testing.assert_array_equal(whole[sel], want)
+    # (2) plant copies
+    pos = np.random.default_rng(1).choice(n, m, replace=False)
+    r2 = r_d.view(n, k)
+    r2[torch.from_numpy(pos).to(dev)] = q_d.view(m, k)
+    planted = run(1)
+    np.testing.assert_array_equal(planted, pos.astype(np.int32))
