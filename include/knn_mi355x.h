@@ -119,6 +119,14 @@ long long knn_get_option(const char *name);
  *   [2] candidate-buffer overflow fallbacks   [3] reserved */
 int knn_index_last_stats(knn_index *idx, long long stats[4]);
 
+/* Test hook for the filter's error bound: raw MFMA filter scores S[m][n_local] (row-major,
+ * device) for a query batch, the fp32 squared norms M[m] of the fp16 query rows (device), and
+ * consts = {sigma, eta, rho, Amax, Bmax, g2, gamma, #non-finite fp16 query coordinates}.  A pair's
+ * score obeys |S + M - sigma^2 d^2| <= 2 eta sigma d + eta^2 + rho (+ gamma M), d = real distance.
+ * Synchronous; needs an index that has filter layouts (else KNN_EINVAL). */
+int knn_debug_filter_scores(knn_index *idx, int m, const float *queries_dev, float *scores_dev,
+                            float *qnorm_dev, double consts[8]);
+
 /* Bench support: time the index's dominant kernel (the one the roofline is quoted for) with a
  * HIP event pair recorded on the caller's stream around each launch.  enable != 0 starts
  * recording for every later knn_index_query_keys, 0 stops and drops the record. */

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_destroy", "knn_keys_init", "knn_index_query_keys", "knn_keys_to_indices",
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
+    "knn_debug_filter_scores",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -64,6 +65,7 @@ def lib():
     L.knn_index_last_stats.argtypes = [c_vp, ctypes.POINTER(c_ll)]
     L.knn_synth_fill_device.argtypes = [c_int, c_vp, c_ll, c_ull, c_ll, c_vp]
     L.knn_index_timing.argtypes = [c_vp, c_int]
+    L.knn_debug_filter_scores.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_double)]
     L.knn_index_timing_read.argtypes = [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
@@ -160,6 +162,14 @@ class KnnIndex:
         st = (ctypes.c_longlong * 4)()
         _check(lib().knn_index_last_stats(self._h, st))
         return list(st)
+
+    def debug_filter_scores(self, m, queries_dev, scores_dev, qnorm_dev):
+        """Test hook (knn_debug_filter_scores): returns the 8 bound constants."""
+        consts = (ctypes.c_double * 8)()
+        _check(lib().knn_debug_filter_scores(self._h, int(m), ctypes.c_void_p(int(queries_dev)),
+                                             ctypes.c_void_p(int(scores_dev)), ctypes.c_void_p(int(qnorm_dev)),
+                                             consts))
+        return list(consts)
 
     def timing(self, enable):
         _check(lib().knn_index_timing(self._h, 1 if enable else 0))

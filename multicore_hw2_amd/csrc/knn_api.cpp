@@ -89,6 +89,7 @@ struct knn_index {
     const float *refs = nullptr;  // device, AoS [n][k]
     float *owned_refs = nullptr;  // set when the index copied the references itself
     long long stats[4] = {0, 0, 0, 0};
+    FilterState filter;           // MFMA filter layouts + workspace (usable == false: exact only)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // one pair per timed launch
     size_t events_used = 0;
@@ -188,6 +189,14 @@ int knn_index_create(knn_index **out, int device, int k, long long n_local, cons
             idx->refs = idx->owned_refs;
         }
     }
+    // MFMA filter layouts (skipped for small shards and when the exact path is forced)
+    if (n_local > 0 && g_opt_path != 1 && (g_opt_path == 2 || n_local >= 65536)) {
+        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s);
+        if (e != hipSuccess) {
+            knn_index_destroy(idx);
+            return fail(KNN_EHIP, "knn_index_create: building the filter layouts", hipGetErrorString(e));
+        }
+    }
     *out = idx;
     return KNN_OK;
 }
@@ -200,6 +209,7 @@ void knn_index_destroy(knn_index *idx)
         DeviceGuard guard(idx->device);
         if (idx->owned_refs)
             (void)hipFree(idx->owned_refs);
+        knn_filter_free(idx->filter);
         for (auto &ev : idx->events) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
@@ -243,12 +253,34 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
         }
         ev = &idx->events[idx->events_used++];
     }
+    const long long path = g_opt_path;
+    const bool use_filter = idx->filter.usable && (path == 2 || (path == 0 && m >= 128 && idx->n >= 65536));
+    if (use_filter) {
+        // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
+        idx->stats[0] = 2;
+        HIP_TRY(knn_filter_query(idx->filter, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
+                                 idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));
+        return KNN_OK;
+    }
     if (ev)
         HIP_TRY(hipEventRecord(ev->first, s));
     HIP_TRY(knn_exact_launch(idx->k, m, idx->n, idx->base, queries_dev, idx->refs, (u64 *)keys_dev,
-                             idx->num_cu, s));
+                             idx->num_cu, nullptr, s));
     if (ev)
         HIP_TRY(hipEventRecord(ev->second, s));
+    return KNN_OK;
+}
+
+int knn_debug_filter_scores(knn_index *idx, int m, const float *queries_dev, float *scores_dev,
+                            float *qnorm_dev, double consts[8])
+{
+    if (!idx || m < 1 || !queries_dev || !scores_dev || !qnorm_dev || !consts)
+        return fail(KNN_EINVAL, "knn_debug_filter_scores: bad arguments");
+    if (!idx->filter.usable)
+        return fail(KNN_EINVAL, "knn_debug_filter_scores: this index has no filter layouts");
+    DeviceGuard guard(idx->device);
+    HIP_TRY(knn_filter_debug(idx->filter, m, queries_dev, idx->refs, scores_dev, nullptr, qnorm_dev, consts,
+                             nullptr));
     return KNN_OK;
 }
 
@@ -283,6 +315,13 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
 {
     if (!idx || !stats)
         return fail(KNN_EINVAL, "knn_index_last_stats: bad arguments");
+    if (idx->stats[0] == 2 && idx->filter.ctl) {
+        DeviceGuard guard(idx->device);
+        unsigned ctl[KNN_CTL_WORDS];
+        HIP_TRY(hipMemcpy(ctl, idx->filter.ctl, sizeof ctl, hipMemcpyDeviceToHost));
+        idx->stats[1] = ctl[KNN_CTL_RECORDS];
+        idx->stats[2] = ctl[KNN_CTL_FALLBACK];
+    }
     memcpy(stats, idx->stats, sizeof idx->stats);
     return KNN_OK;
 }

@@ -15,16 +15,65 @@ static inline int knn_divup(long long a, long long b) { return (int)((a + b - 1)
 // ---- exact VALU kernels (knn_exact.hip) -----------------------------------
 // Folds the nearest reference of refs[0..n_local) (global index base + i) for each of the m
 // queries into keys[] with a 64-bit unsigned atomic min.  Every distance is computed with the
-// v0 arithmetic (reference core.cu:44-49).  Returns hipSuccess or the launch error.
+// v0 arithmetic (reference core.cu:44-49).  If `gate` is non-null the kernels return at once
+// unless *gate != 0 (device-side fallback switch, so the query path never syncs with the host).
 hipError_t knn_exact_launch(int k, int m, long long n_local, long long base, const float *q_dev,
-                            const float *r_dev, u64 *keys_dev, int num_cu, hipStream_t stream);
+                            const float *r_dev, u64 *keys_dev, int num_cu, const unsigned *gate,
+                            hipStream_t stream);
 
-// Exact re-rank of an explicit candidate list: cand[c] = (query << 32) | local_ref_index.
-hipError_t knn_rerank_launch(int k, const float *q_dev, const float *r_dev, long long base,
-                             const u64 *cand_dev, const unsigned *count_dev, unsigned capacity,
-                             u64 *keys_dev, hipStream_t stream);
+// Exact re-rank of the filter's candidate records (see knn_rerank_kernel).
+hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev,
+                             long long base, const u64 *rec_dev, const unsigned *ctl_dev,
+                             unsigned capacity, u64 *keys_dev, hipStream_t stream);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
 hipError_t knn_synth_fill_launch(float *dst, long long count, u64 seed, long long first,
                                  hipStream_t stream);
+
+// ---- MFMA filter + exact re-rank (knn_filter.hip) ---------------------------
+// Device-side control words of one filter query (FilterState::ctl).
+enum {
+    KNN_CTL_FALLBACK = 0,  // != 0: the exact kernels must scan the whole shard (filter unusable)
+    KNN_CTL_RECORDS = 1,   // number of candidate records appended (may exceed the capacity)
+    // words 2..4 are the out[0..2] window of knn_frag_kernel for the query batch
+    KNN_CTL_AMAX = 2,      // float bits: max |scaled query coordinate| in fp16
+    KNN_CTL_QNMAX = 3,     // float bits: max fp32 squared norm of the fp16 query rows
+    KNN_CTL_QBAD = 4,      // != 0: a query coordinate is non-finite or out of fp16 range
+    KNN_CTL_WORDS = 8
+};
+
+struct FilterState {
+    bool usable = false;       // references finite and in a sane range: filter layouts exist
+    int k = 0, kt = 0;         // real dimension; 16-wide K steps (padded k = 16 * kt)
+    long long n = 0;           // references in the shard
+    long long ntiles = 0;      // ceil(n / 32)
+    float sigma = 1.0f;        // power-of-two scale
+    float bmax = 0.0f;         // max |scaled fp16 reference coordinate|
+    float nmax = 0.0f;         // max fp32 squared norm of the fp16 reference rows
+    float *center = nullptr;   // device [16*kt]
+    void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
+    float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
+    // per-query workspace (one query in flight per index)
+    int m_cap = 0;
+    void *qry_frags = nullptr; // device [qtiles][kt][64] x 16 B: B operands (-2 * scaled query)
+    float *qry_norms = nullptr;// device [qtiles*32]
+    float *thr = nullptr;      // device [qtiles*32]
+    unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
+    u64 *records = nullptr;    // device [rec_cap]
+    unsigned rec_cap = 0;
+};
+
+// Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
+// (and returns hipSuccess) when the data rules the filter out.
+hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
+void knn_filter_free(FilterState &st);
+// Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.
+hipError_t knn_filter_query(FilterState &st, int m, const float *q_dev, const float *r_dev,
+                            long long base, u64 *keys_dev, int num_cu, hipStream_t stream,
+                            hipEvent_t ev_begin, hipEvent_t ev_end);
+// Test hook: raw filter scores S[m][n] (row-major) and the per-query thresholds for a query
+// batch, plus {sigma, eta, rho, amax, bmax}.  Synchronous.
+hipError_t knn_filter_debug(FilterState &st, int m, const float *q_dev, const float *r_dev,
+                            float *scores_dev, float *thr_out_dev, float *qnorm_out_dev,
+                            double consts_host[8], hipStream_t stream);

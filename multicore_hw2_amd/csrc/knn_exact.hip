@@ -49,9 +49,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restr
                                                             const float *__restrict__ R, int m,
                                                             long long n, long long base,
                                                             u64 *__restrict__ keys,
-                                                            long long refs_per_block)
+                                                            long long refs_per_block,
+                                                            const unsigned *__restrict__ gate)
 {
 #pragma clang fp contract(off)
+    if (gate && *gate == 0u)
+        return;
     const int lane = threadIdx.x & (KNN_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int q0 = (blockIdx.y * KNN_WAVES + wave) * (2 * QP * KNN_WAVE);
@@ -126,9 +129,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__rest
                                                              const float *__restrict__ R, int m,
                                                              long long n, long long base,
                                                              u64 *__restrict__ keys,
-                                                             long long refs_per_block)
+                                                             long long refs_per_block,
+                                                             const unsigned *__restrict__ gate)
 {
 #pragma clang fp contract(off)
+    if (gate && *gate == 0u)
+        return;
     const int lane = threadIdx.x & (KNN_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int q0 = (blockIdx.y * KNN_WAVES + wave) * KNN_WAVE;
@@ -185,9 +191,12 @@ template <int K, int QT>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__restrict__ Q,
                                                              const float *__restrict__ R, int krt,
                                                              int m, long long n, long long base,
-                                                             u64 *__restrict__ keys)
+                                                             u64 *__restrict__ keys,
+                                                             const unsigned *__restrict__ gate)
 {
 #pragma clang fp contract(off)
+    if (gate && *gate == 0u)
+        return;
     const int k = K > 0 ? K : krt;
     const int q0 = blockIdx.y * QT;
     float best[QT];
@@ -255,22 +264,29 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Exact re-rank of a candidate list produced by the MFMA filter: one candidate per thread.
+// Exact re-rank of the MFMA filter's candidate records.  A record names one query and the 16
+// references one lane of a 32x32 MFMA tile covers: (query << 32) | (ref_tile << 1) | half, rows
+// 8g + 4*half + i (g, i in 0..3) of that tile.  One (record, row) pair per thread, v0 arithmetic.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__restrict__ Q,
                                                                const float *__restrict__ R, int k,
-                                                               long long base,
-                                                               const u64 *__restrict__ cand,
-                                                               const unsigned *__restrict__ count,
+                                                               long long n, long long base,
+                                                               const u64 *__restrict__ rec,
+                                                               const unsigned *__restrict__ ctl,
                                                                unsigned capacity,
                                                                u64 *__restrict__ keys)
 {
 #pragma clang fp contract(off)
-    const unsigned total = min(*count, capacity);
-    for (unsigned c = blockIdx.x * KNN_BLOCK + threadIdx.x; c < total; c += gridDim.x * KNN_BLOCK) {
-        const u64 e = cand[c];
+    const unsigned nrec = min(ctl[KNN_CTL_RECORDS], capacity);
+    const u64 total = (u64)nrec * 16ull;
+    for (u64 c = (u64)blockIdx.x * KNN_BLOCK + threadIdx.x; c < total; c += (u64)gridDim.x * KNN_BLOCK) {
+        const u64 e = rec[c >> 4];
+        const unsigned reg = (unsigned)(c & 15ull);
         const unsigned qi = (unsigned)(e >> 32);
-        const unsigned ri = (unsigned)(e & 0xFFFFFFFFu);
+        const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
+        const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+        if (ri >= n)
+            continue;
         const float *__restrict__ q = Q + (size_t)qi * k;
         const float *__restrict__ r = R + (size_t)ri * k;
         float acc = 0.0f;
@@ -342,31 +358,31 @@ SliceGeom slice_refs(long long n, unsigned qgroups, int num_cu, long long min_re
 
 template <int K>
 hipError_t launch_qreg_k(int m, long long n, long long base, const float *q, const float *r,
-                         u64 *keys, int num_cu, hipStream_t s)
+                         u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
 {
     // queries per block: 1024 (QP=2) when m fills most of it, else 512 (QP=1), else 256 (unpacked)
     if (m > 3 * KNN_WAVE * KNN_WAVES) {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 4 * KNN_WAVE);
         const SliceGeom g = slice_refs(n, qg, num_cu, 512);
         hipLaunchKernelGGL((knn_exact_qreg<K, 2>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
-                           m, n, base, keys, g.refs_per_block);
+                           m, n, base, keys, g.refs_per_block, gate);
     } else if (m > KNN_WAVE * KNN_WAVES) {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 2 * KNN_WAVE);
         const SliceGeom g = slice_refs(n, qg, num_cu, 512);
         hipLaunchKernelGGL((knn_exact_qreg<K, 1>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
-                           m, n, base, keys, g.refs_per_block);
+                           m, n, base, keys, g.refs_per_block, gate);
     } else {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * KNN_WAVE);
         const SliceGeom g = slice_refs(n, qg, num_cu, 512);
         hipLaunchKernelGGL((knn_exact_qreg1<K>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r, m,
-                           n, base, keys, g.refs_per_block);
+                           n, base, keys, g.refs_per_block, gate);
     }
     return hipGetLastError();
 }
 
 template <int K>
 hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float *q, const float *r,
-                          u64 *keys, int num_cu, hipStream_t s)
+                          u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
 {
     constexpr int QT = 4;
     const unsigned qt = (unsigned)knn_divup(m, QT);
@@ -377,14 +393,14 @@ hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float
     if (blocks < 1)
         blocks = 1;
     hipLaunchKernelGGL((knn_exact_rlane<K, QT>), dim3((unsigned)blocks, qt), dim3(KNN_BLOCK), 0, s, q,
-                       r, k, m, n, base, keys);
+                       r, k, m, n, base, keys, gate);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t knn_exact_launch(int k, int m, long long n, long long base, const float *q,
-                            const float *r, u64 *keys, int num_cu, hipStream_t s)
+                            const float *r, u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
 {
     if (n <= 0 || m <= 0)
         return hipSuccess;
@@ -392,30 +408,31 @@ hipError_t knn_exact_launch(int k, int m, long long n, long long base, const flo
     const bool many = m >= 48;
     if (many) {
         switch (k) {
-        case 1: return launch_qreg_k<1>(m, n, base, q, r, keys, num_cu, s);
-        case 2: return launch_qreg_k<2>(m, n, base, q, r, keys, num_cu, s);
-        case 3: return launch_qreg_k<3>(m, n, base, q, r, keys, num_cu, s);
-        case 4: return launch_qreg_k<4>(m, n, base, q, r, keys, num_cu, s);
-        case 8: return launch_qreg_k<8>(m, n, base, q, r, keys, num_cu, s);
-        case 16: return launch_qreg_k<16>(m, n, base, q, r, keys, num_cu, s);
+        case 1: return launch_qreg_k<1>(m, n, base, q, r, keys, num_cu, gate, s);
+        case 2: return launch_qreg_k<2>(m, n, base, q, r, keys, num_cu, gate, s);
+        case 3: return launch_qreg_k<3>(m, n, base, q, r, keys, num_cu, gate, s);
+        case 4: return launch_qreg_k<4>(m, n, base, q, r, keys, num_cu, gate, s);
+        case 8: return launch_qreg_k<8>(m, n, base, q, r, keys, num_cu, gate, s);
+        case 16: return launch_qreg_k<16>(m, n, base, q, r, keys, num_cu, gate, s);
         default: break;
         }
     }
     switch (k) {
-    case 1: return launch_rlane_k<1>(k, m, n, base, q, r, keys, num_cu, s);
-    case 2: return launch_rlane_k<2>(k, m, n, base, q, r, keys, num_cu, s);
-    case 3: return launch_rlane_k<3>(k, m, n, base, q, r, keys, num_cu, s);
-    case 4: return launch_rlane_k<4>(k, m, n, base, q, r, keys, num_cu, s);
-    case 8: return launch_rlane_k<8>(k, m, n, base, q, r, keys, num_cu, s);
-    case 16: return launch_rlane_k<16>(k, m, n, base, q, r, keys, num_cu, s);
-    default: return launch_rlane_k<0>(k, m, n, base, q, r, keys, num_cu, s);
+    case 1: return launch_rlane_k<1>(k, m, n, base, q, r, keys, num_cu, gate, s);
+    case 2: return launch_rlane_k<2>(k, m, n, base, q, r, keys, num_cu, gate, s);
+    case 3: return launch_rlane_k<3>(k, m, n, base, q, r, keys, num_cu, gate, s);
+    case 4: return launch_rlane_k<4>(k, m, n, base, q, r, keys, num_cu, gate, s);
+    case 8: return launch_rlane_k<8>(k, m, n, base, q, r, keys, num_cu, gate, s);
+    case 16: return launch_rlane_k<16>(k, m, n, base, q, r, keys, num_cu, gate, s);
+    default: return launch_rlane_k<0>(k, m, n, base, q, r, keys, num_cu, gate, s);
     }
 }
 
-hipError_t knn_rerank_launch(int k, const float *q, const float *r, long long base, const u64 *cand,
-                             const unsigned *count, unsigned capacity, u64 *keys, hipStream_t s)
+hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
+                             const u64 *rec, const unsigned *ctl, unsigned capacity, u64 *keys,
+                             hipStream_t s)
 {
-    hipLaunchKernelGGL(knn_rerank_kernel, dim3(256), dim3(KNN_BLOCK), 0, s, q, r, k, base, cand, count,
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3(512), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, ctl,
                        capacity, keys);
     return hipGetLastError();
 }

@@ -1,2 +1,631 @@
-// knn_filter.hip — MFMA low-precision filter (placeholder until the filter path lands).
+// knn_filter.hip — low-precision MFMA filter with a rigorous error bound, in front of the exact
+// re-rank (gfx950 / MI355X).
+//
+// Why: at m = 1024 the exact scan needs (3k+3)·m·n fp32 VALU lane-ops — ~80x more time than
+// reading the references from HBM.  The distance matrix is a dense
+// contraction, |q-r|^2 = |q|^2 + |r|^2 - 2 q·r, and k = 16 is exactly one K-step of
+// v_mfma_f32_32x32x16_f16.  The filter evaluates, for every (query, reference) pair,
+//      S = N_r + sum_d (-2 a_d) * b_d          (fp16 operands, fp32 accumulate, C operand = N_r)
+// where a, b are the centred, power-of-two scaled coordinates rounded to fp16 and N_r = |b|^2,
+// and keeps only pairs with S <= thr_q.  thr_q is derived so that the true nearest reference
+// (under the reference's v0 fp32 arithmetic, core.cu:44-54) can never be discarded:
+//
+//   * an exact v0 distance E0 to some reference is known for the query (sample pre-pass with
+//     the exact kernel), so the winner j* has E_j* <= E0 and real distance
+//     D* <= sigma^2 (E0 (1+g2) + tau)                       [v0's own rounding: g2 = (k+3) 2^-24]
+//   * fp16 rounding of centred coordinates moves each coordinate difference by at most
+//     e = theta'(Amax + Bmax) + 2 nu0, so |D~ - D| <= 2 eta sqrt(D) + eta^2, eta = sqrt(k) e
+//   * norm sums and the MFMA's internal fp32 accumulation add at most rho (assumed <= 2^-18
+//     relative to the sum of magnitudes — 16x the single-rounding bound; tests/ check the
+//     scores against a float64 evaluation).
+//   => S_j* <= Dup + 2 eta sqrt(Dup) + eta^2 + rho - M_q(1-g) =: thr_q.
+//
+// Survivors are written as records (query, reference tile, lane half) and re-evaluated with the
+// exact arithmetic by knn_rerank_kernel, which folds them into the packed keys.  If anything
+// rules the filter out (non-finite data, fp16 range, record overflow) a device-side flag makes
+// the gated exact kernels scan everything instead: results are bit-exact either way.
 #include "knn_common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+#define FILTER_BLOCK 256
+
+// order-preserving map float -> uint (for atomic min/max over signed floats)
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float ord2f_host(unsigned o)
+{
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmaxf(v, __shfl_xor(v, off, KNN_WAVE));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-dimension min / max of the reference coordinates (+ count of non-finite values).
+//   stats[0..k) = ordered min, stats[k..2k) = ordered max, stats[2k] = #non-finite
+// Each thread keeps one fixed dimension: the element stride is a multiple of k.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_ref_stats_kernel(const float *__restrict__ R, long long count,
+                                                            int k, unsigned *__restrict__ stats)
+{
+    const long long threads = (long long)gridDim.x * blockDim.x;
+    const long long stride = threads / k * k;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid >= stride)
+        return;
+    const int d = (int)(gtid % k);
+    float lo = INFINITY, hi = -INFINITY;
+    unsigned bad = 0;
+    for (long long e = gtid; e < count; e += stride) {
+        const float v = R[e];
+        if (!(fabsf(v) < INFINITY))
+            ++bad;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    if (lo <= hi) {
+        atomicMin(&stats[d], f2ord(lo));
+        atomicMax(&stats[k + d], f2ord(hi));
+    }
+    if (bad)
+        atomicAdd(&stats[2 * k], bad);
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 AoS rows -> centred, scaled fp16 MFMA operand fragments + fp32 squared norms.
+// Fragment order: frag[(tile*KT + kt)*64 + half*32 + r] holds coordinates 16kt + 8half .. +7 of
+// row 32*tile + r — exactly what lane (half, r) of v_mfma_f32_32x32x16_f16 wants for A (rows =
+// references) or B (columns = queries), so the hot loop's operand loads are linear 1 KiB bursts.
+//   scale_out = 1 for references, -2 for queries (folds the -2 of -2 q·r into the operand).
+//   out[0] = max |fp16 coordinate| (float bits), out[1] = max norm, out[2] = #non-finite fp16
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__ X, long long rows,
+                                                       long long rows_padded, int k, int kt,
+                                                       const float *__restrict__ center, float sigma,
+                                                       float scale_out, float pad_norm,
+                                                       h8 *__restrict__ frag, float *__restrict__ norms,
+                                                       unsigned *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float vmax = 0.0f, nrm = 0.0f;
+    unsigned bad = 0;
+    if (i < rows_padded) {
+        const long long tile = i >> 5;
+        const int r = (int)(i & 31);
+        const bool real = i < rows;
+        const float *__restrict__ x = X + (size_t)(real ? i : 0) * k;
+        for (int kk = 0; kk < kt; ++kk) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                h8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int d = kk * 16 + half * 8 + j;
+                    float s = 0.0f;
+                    if (real && d < k)
+                        s = (x[d] - center[d]) * sigma;  // fp32 subtract, exact power-of-two scale
+                    const _Float16 hval = (_Float16)s;   // round to nearest even
+                    const float back = (float)hval;
+                    if (!(fabsf(back) < INFINITY))
+                        ++bad;
+                    vmax = fmaxf(vmax, fabsf(back));
+                    nrm = nrm + back * back;             // exact products, fp32 sum
+                    v[j] = (_Float16)(back * scale_out);  // *1 or *-2: exact in fp16 below overflow
+                    if (!(fabsf((float)v[j]) < INFINITY))
+                        ++bad;
+                }
+                frag[((size_t)tile * kt + kk) * 64 + half * 32 + r] = v;
+            }
+        }
+        norms[i] = real ? nrm : pad_norm;
+        if (!real)
+            nrm = 0.0f;
+    }
+    vmax = wave_max_f(vmax);
+    nrm = wave_max_f(nrm);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out[0], __float_as_uint(vmax));  // non-negative floats order like uints
+        atomicMax(&out[1], __float_as_uint(nrm));
+    }
+    if (bad)
+        atomicAdd(&out[2], bad);
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-query pruning threshold (double arithmetic; see the header comment for the derivation).
+// ------------------------------------------------------------------------------------------
+struct BoundConsts {
+    double eta, eta2, rho, g2, tau, gam, sigma2;
+};
+
+__host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double sigma, double amax,
+                                                        double bmax, double nmax)
+{
+    const double u = 0x1p-24;
+    const double theta = 0x1p-11 + 0x1p-23;          // fp32 centring + fp16 rounding, relative
+    const double thp = theta / (1.0 - theta);
+    const double nu0 = 0x1p-14 * 1.001;               // fp16 subnormal rounding or flush-to-zero
+    const double kp = 16.0 * kt;
+    const double emax = thp * (amax + bmax) + 2.0 * nu0;
+    BoundConsts c;
+    c.eta2 = k * emax * emax;
+    c.eta = sqrt(c.eta2);
+    const double omega = 0x1p-18;                     // MFMA internal accumulation (assumed bound)
+    c.gam = (kp + 2.0) * u;
+    const double mmax = kp * amax * amax;
+    c.rho = (omega + 2.0 * c.gam) * 2.0 * (nmax + mmax) + kp * 0x1p-27;
+    c.g2 = (k + 3.0) * u * 1.0001;
+    c.tau = k * 0x1p-125;
+    c.sigma2 = sigma * sigma;
+    return c;
+}
+
+__host__ __device__ inline float knn_threshold(const BoundConsts &c, double e0, double mq)
+{
+    const double dup = c.sigma2 * (e0 * (1.0 + c.g2) + c.tau);
+    double thr = dup + 2.0 * c.eta * sqrt(dup) + c.eta2 + c.rho - mq * (1.0 - c.gam);
+    thr += fabs(thr) * 1e-6 + 1e-30;                  // slack for the double arithmetic above
+    float tf = (float)thr;
+    if ((double)tf < thr)
+        tf = nextafterf(tf, INFINITY);
+    return nextafterf(tf, INFINITY);                  // the kernel tests S < thr (strict)
+}
+
+__global__ __launch_bounds__(256) void knn_thr_kernel(const u64 *__restrict__ keys,
+                                                      const float *__restrict__ qnorm, int m,
+                                                      int m_padded, int k, int kt, float sigma,
+                                                      float bmax, float nmax, float amax_limit,
+                                                      float *__restrict__ thr,
+                                                      unsigned *__restrict__ ctl)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m_padded)
+        return;
+    const float amax = __uint_as_float(ctl[KNN_CTL_AMAX]);
+    bool bad = ctl[KNN_CTL_QBAD] != 0u || !(amax <= amax_limit);
+    float t = -INFINITY;  // padding queries never pass
+    if (i < m) {
+        const float e0 = __uint_as_float((unsigned)(keys[i] >> 32));
+        if (!(e0 < INFINITY))
+            bad = true;  // no finite exact distance known: cannot bound
+        if (!bad) {
+            const BoundConsts c = knn_bound_consts(k, kt, sigma, amax, bmax, nmax);
+            t = knn_threshold(c, e0, qnorm[i]);
+            if (!(t < INFINITY))
+                bad = true;
+        }
+    }
+    thr[i] = t;
+    if (bad)
+        ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
+}
+
+// ------------------------------------------------------------------------------------------
+// The filter.  One wave owns a contiguous range of 32-reference tiles; it keeps the B operands
+// (queries) of QT query tiles and their thresholds in VGPRs, streams A operands (references) and
+// the C tile (reference norms broadcast along the query axis) once from HBM with the next tile
+// prefetched, and per (reference tile, query tile) issues KT MFMAs + an 8-op min3 tree + one
+// compare.  Rows (registers) = references, columns (lanes) = queries: the reduction over
+// references is in-lane, no cross-lane traffic, no LDS.
+//   grid.x * 4 waves split the reference tiles; grid.y = groups of QT query tiles.
+// ------------------------------------------------------------------------------------------
+template <int KT>
+__device__ __forceinline__ void load_ref_tile(const h8 *__restrict__ rf, const float *__restrict__ rn,
+                                              long long tile, int lane, h8 (&a)[KT], f16v &c)
+{
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+        a[kk] = rf[((size_t)tile * KT + kk) * 64 + lane];
+    // C[row][col] = N_row: rows of register i are 8*(i>>2) + 4*half + (i&3)
+    const f4v *__restrict__ rn4 = (const f4v *)(rn + (size_t)tile * 32 + 4 * (lane >> 5));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f4v v = rn4[2 * g];
+        c[4 * g + 0] = v[0];
+        c[4 * g + 1] = v[1];
+        c[4 * g + 2] = v[2];
+        c[4 * g + 3] = v[3];
+    }
+}
+
+__device__ __forceinline__ float min3f(float a, float b, float c)
+{
+    return __builtin_fminf(__builtin_fminf(a, b), c);
+}
+
+// One (reference tile, query tile) step, software-pipelined by one tile: the MFMA of the NEXT
+// query tile is issued first (into the other accumulator buffer), then the min3 tree of the
+// current one runs in its shadow.  Query tiles past the end of the batch hold a copy of the last
+// real tile with threshold -INF: wasted MFMAs, never a record (the host picks QT to fit m).
+template <int KT, int QT>
+__device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c, const h8 (&qf)[QT][KT],
+                                                const float *__restrict__ s_thr, int lane, int qt0,
+                                                long long tile, u64 *__restrict__ rec,
+                                                unsigned *__restrict__ ctl, unsigned cap)
+{
+    f16v d[2];
+    d[0] = c;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qf[0][kk], d[0], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float th = s_thr[t * 32 + (lane & 31)];
+        if (t + 1 < QT) {
+            f16v &dn = d[(t + 1) & 1];
+            dn = c;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qf[t + 1][kk], dn, 0, 0, 0);
+        }
+        const f16v &x = d[t & 1];
+        const float m0 = min3f(x[0], x[1], x[2]);
+        const float m1 = min3f(x[3], x[4], x[5]);
+        const float m2 = min3f(x[6], x[7], x[8]);
+        const float m3 = min3f(x[9], x[10], x[11]);
+        const float m4 = min3f(x[12], x[13], x[14]);
+        const float m5 = min3f(m0, m1, m2);
+        const float m6 = min3f(m3, m4, x[15]);
+        const float mn = min3f(m5, m6, th);
+        if (__builtin_expect(mn < th, 0)) {  // rare: one of this lane's 16 rows may beat the bound
+            const unsigned pos = atomicAdd(&ctl[KNN_CTL_RECORDS], 1u);
+            if (pos < cap)
+                rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
+                           (u64)(lane >> 5);
+        }
+    }
+}
+
+template <int KT, int QT>
+__global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
+    const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
+    unsigned *__restrict__ ctl, unsigned cap)
+{
+    __shared__ float s_thr[QT * 32];
+    if (ctl[KNN_CTL_FALLBACK] != 0u)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int qt0 = blockIdx.y * QT;
+    const int nq = min(QT, qtiles - qt0);  // wave-uniform
+    for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
+        s_thr[i] = i < nq * 32 ? thrg[(size_t)qt0 * 32 + i] : -INFINITY;
+    __syncthreads();
+
+    const long long wave = (long long)blockIdx.x * (FILTER_BLOCK / 64) +
+                           __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long nwaves = (long long)gridDim.x * (FILTER_BLOCK / 64);
+    const long long t0 = ntiles * wave / nwaves;
+    const long long t1 = ntiles * (wave + 1) / nwaves;
+    if (t0 >= t1)
+        return;
+
+    h8 qf[QT][KT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int tt = min(t, nq - 1);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+            qf[t][kk] = qfg[((size_t)(qt0 + tt) * KT + kk) * 64 + lane];
+    }
+
+    h8 a[KT];
+    f16v c;
+    load_ref_tile<KT>(rf, rn, t0, lane, a, c);
+    for (long long tile = t0; tile < t1; ++tile) {
+        h8 an[KT];
+        f16v cn;
+        load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);  // prefetch
+        filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, rec, ctl, cap);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+            a[kk] = an[kk];
+        c = cn;
+    }
+}
+
+// After the re-rank: a record overflow means candidates were dropped -> full exact scan.
+__global__ void knn_filter_finish_kernel(unsigned *__restrict__ ctl, unsigned cap)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && ctl[KNN_CTL_RECORDS] > cap)
+        ctl[KNN_CTL_FALLBACK] = 1u;
+}
+
+// Test hook: all scores of one (reference tile, query tile) pair per wave.
+template <int KT>
+__global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restrict__ rf,
+                                                               const float *__restrict__ rn,
+                                                               const h8 *__restrict__ qfg, int m,
+                                                               long long n, float *__restrict__ scores)
+{
+    const int lane = threadIdx.x & 63;
+    h8 a[KT];
+    f16v c;
+    load_ref_tile<KT>(rf, rn, blockIdx.x, lane, a, c);
+    f16v d = c;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qfg[((size_t)blockIdx.y * KT + kk) * 64 + lane], d,
+                                                   0, 0, 0);
+    const long long q = (long long)blockIdx.y * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long long r = (long long)blockIdx.x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (q < m && r < n)
+            scores[(size_t)q * n + r] = d[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side.
+// ------------------------------------------------------------------------------------------
+#define FTRY(call)                       \
+    do {                                 \
+        hipError_t e_ = (call);          \
+        if (e_ != hipSuccess)            \
+            return e_;                   \
+    } while (0)
+
+static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB
+static const float kAmaxLimit = 1024.0f;           // queries far outside the references' box
+
+void knn_filter_free(FilterState &st)
+{
+    (void)hipFree(st.center);
+    (void)hipFree(st.ref_frags);
+    (void)hipFree(st.ref_norms);
+    (void)hipFree(st.qry_frags);
+    (void)hipFree(st.qry_norms);
+    (void)hipFree(st.thr);
+    (void)hipFree(st.ctl);
+    (void)hipFree(st.records);
+    st = FilterState();
+}
+
+hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s)
+{
+    st = FilterState();
+    if (n <= 0 || k < 1 || k > 128)
+        return hipSuccess;
+    const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+    const int kp = 16 * kt;
+    const long long ntiles = (n + 31) / 32;
+
+    // 1. per-dimension range
+    std::vector<unsigned> hstats((size_t)2 * k + 1);
+    for (int d = 0; d < k; ++d) {
+        hstats[(size_t)d] = 0xFFFFFFFFu;
+        hstats[(size_t)k + d] = 0u;
+    }
+    hstats[(size_t)2 * k] = 0u;
+    unsigned *dstats = nullptr;
+    FTRY(hipMalloc((void **)&dstats, hstats.size() * sizeof(unsigned)));
+    hipError_t e = hipMemcpyAsync(dstats, hstats.data(), hstats.size() * sizeof(unsigned),
+                                  hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(knn_ref_stats_kernel, dim3(2048), dim3(256), 0, s, r, n * (long long)k, k, dstats);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hstats.data(), dstats, hstats.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(dstats);
+    FTRY(e);
+    if (hstats[(size_t)2 * k] != 0u)
+        return hipSuccess;  // NaN / Inf among the references: exact path only
+
+    std::vector<float> center((size_t)kp, 0.0f);
+    double h = 0.0;
+    for (int d = 0; d < k; ++d) {
+        const float lo = ord2f_host(hstats[(size_t)d]), hi = ord2f_host(hstats[(size_t)k + d]);
+        const float c = 0.5f * lo + 0.5f * hi;
+        center[(size_t)d] = c;
+        h = fmax(h, fmax((double)hi - (double)c, (double)c - (double)lo));
+    }
+    if (!(h <= 1e15) || (h != 0.0 && h < 1e-15))
+        return hipSuccess;
+    float sigma = 1.0f;
+    if (h > 0.0) {
+        int ex;
+        (void)frexp(h, &ex);  // h = f * 2^ex, f in [0.5, 1)  ->  h * 2^-ex < 1
+        sigma = (float)ldexp(1.0, -ex);
+    }
+
+    // 2. fragments + norms
+    st.k = k;
+    st.kt = kt;
+    st.n = n;
+    st.ntiles = ntiles;
+    st.sigma = sigma;
+    unsigned *dout = nullptr;
+    e = hipMalloc((void **)&st.center, (size_t)kp * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMalloc(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&dout, 4 * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(st.center, center.data(), (size_t)kp * sizeof(float), hipMemcpyHostToDevice, s);
+    unsigned hout[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) {
+        const long long rows_padded = ntiles * 32;
+        hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
+                           n, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
+                           st.ref_norms, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);  // also keeps `center` alive until the copy is done
+    (void)hipFree(dout);
+    if (e != hipSuccess) {
+        knn_filter_free(st);
+        return e;
+    }
+    if (hout[2] != 0u) {  // a scaled coordinate fell out of fp16 range (cannot happen with |b| <= 1)
+        knn_filter_free(st);
+        return hipSuccess;
+    }
+    memcpy(&st.bmax, &hout[0], 4);
+    memcpy(&st.nmax, &hout[1], 4);
+    st.usable = true;
+    return hipSuccess;
+}
+
+static hipError_t ensure_workspace(FilterState &st, int m)
+{
+    if (!st.ctl)
+        FTRY(hipMalloc((void **)&st.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
+    if (!st.records) {
+        FTRY(hipMalloc((void **)&st.records, (size_t)kRecordCapacity * sizeof(u64)));
+        st.rec_cap = kRecordCapacity;
+    }
+    if (m > st.m_cap) {
+        (void)hipFree(st.qry_frags);
+        (void)hipFree(st.qry_norms);
+        (void)hipFree(st.thr);
+        st.qry_frags = nullptr;
+        st.qry_norms = nullptr;
+        st.thr = nullptr;
+        st.m_cap = 0;
+        const size_t qtiles = (size_t)(m + 31) / 32;
+        FTRY(hipMalloc(&st.qry_frags, qtiles * st.kt * 64 * 16));
+        FTRY(hipMalloc((void **)&st.qry_norms, qtiles * 32 * sizeof(float)));
+        FTRY(hipMalloc((void **)&st.thr, qtiles * 32 * sizeof(float)));
+        st.m_cap = (int)(qtiles * 32);
+    }
+    return hipSuccess;
+}
+
+static hipError_t prep_queries(FilterState &st, int m, const float *q, hipStream_t s)
+{
+    const long long rows_padded = ((long long)m + 31) / 32 * 32;
+    FTRY(hipMemsetAsync(st.ctl, 0, KNN_CTL_WORDS * sizeof(unsigned), s));
+    static_assert(KNN_CTL_QNMAX == KNN_CTL_AMAX + 1 && KNN_CTL_QBAD == KNN_CTL_AMAX + 2, "ctl layout");
+    hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, q,
+                       (long long)m, rows_padded, st.k, st.kt, st.center, st.sigma, -2.0f, 0.0f,
+                       (h8 *)st.qry_frags, st.qry_norms, st.ctl + KNN_CTL_AMAX);
+    return hipGetLastError();
+}
+
+template <int KT, int QT>
+static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t s)
+{
+    const int qtiles = (m + 31) / 32;
+    const unsigned gy = (unsigned)((qtiles + QT - 1) / QT);
+    long long waves = (long long)num_cu * 8;  // 2 waves per SIMD
+    if (waves > st.ntiles)
+        waves = st.ntiles;
+    const unsigned gx = (unsigned)((waves + 3) / 4);
+    hipLaunchKernelGGL((knn_filter_kernel<KT, QT>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, st.thr, qtiles,
+                       st.ntiles, st.records, st.ctl, st.rec_cap);
+    return hipGetLastError();
+}
+
+hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float *r, long long base,
+                            u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end)
+{
+    FTRY(ensure_workspace(st, m));
+    FTRY(prep_queries(st, m, q, s));
+    // sample pre-pass: exact distances to a prefix of the shard give every query a finite E0
+    long long sample = st.n / 64;
+    if (sample < 1024)
+        sample = 1024;
+    if (sample > 65536)
+        sample = 65536;
+    if (sample > st.n)
+        sample = st.n;
+    FTRY(knn_exact_launch(st.k, m, sample, base, q, r, keys, num_cu, nullptr, s));
+    const int m_padded = (m + 31) / 32 * 32;
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)((m_padded + 255) / 256)), dim3(256), 0, s, keys,
+                       st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, st.thr,
+                       st.ctl);
+    FTRY(hipGetLastError());
+    if (ev_begin)
+        FTRY(hipEventRecord(ev_begin, s));
+    const int qtiles = (m + 31) / 32;
+    switch (st.kt) {
+    case 1:
+        if (qtiles <= 8)
+            FTRY((launch_filter<1, 8>(st, m, num_cu, s)));
+        else if (qtiles <= 16)
+            FTRY((launch_filter<1, 16>(st, m, num_cu, s)));
+        else
+            FTRY((launch_filter<1, 32>(st, m, num_cu, s)));
+        break;
+    case 2:
+        if (qtiles <= 8)
+            FTRY((launch_filter<2, 8>(st, m, num_cu, s)));
+        else
+            FTRY((launch_filter<2, 16>(st, m, num_cu, s)));
+        break;
+    case 4: FTRY((launch_filter<4, 4>(st, m, num_cu, s))); break;
+    default: FTRY((launch_filter<8, 2>(st, m, num_cu, s))); break;
+    }
+    if (ev_end)
+        FTRY(hipEventRecord(ev_end, s));
+    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, st.records, st.ctl, st.rec_cap, keys, s));
+    hipLaunchKernelGGL(knn_filter_finish_kernel, dim3(1), dim3(64), 0, s, st.ctl, st.rec_cap);
+    FTRY(hipGetLastError());
+    // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
+    return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, st.ctl + KNN_CTL_FALLBACK, s);
+}
+
+hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float *r, float *scores,
+                            float *thr_out, float *qnorm_out, double consts[8], hipStream_t s)
+{
+    FTRY(ensure_workspace(st, m));
+    FTRY(prep_queries(st, m, q, s));
+    const int qtiles = (m + 31) / 32;
+    const dim3 grid((unsigned)st.ntiles, (unsigned)qtiles);
+    switch (st.kt) {
+    case 1: hipLaunchKernelGGL(knn_filter_scores_kernel<1>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
+    case 2: hipLaunchKernelGGL(knn_filter_scores_kernel<2>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
+    case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
+    default: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
+    }
+    FTRY(hipGetLastError());
+    FTRY(hipMemcpyAsync(qnorm_out, st.qry_norms, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));
+    unsigned hctl[KNN_CTL_WORDS];
+    FTRY(hipMemcpyAsync(hctl, st.ctl, sizeof hctl, hipMemcpyDeviceToHost, s));
+    FTRY(hipStreamSynchronize(s));
+    float amax;
+    memcpy(&amax, &hctl[KNN_CTL_AMAX], 4);
+    const BoundConsts c = knn_bound_consts(st.k, st.kt, st.sigma, amax, st.bmax, st.nmax);
+    consts[0] = st.sigma;
+    consts[1] = c.eta;
+    consts[2] = c.rho;
+    consts[3] = amax;
+    consts[4] = st.bmax;
+    consts[5] = c.g2;
+    consts[6] = c.gam;
+    consts[7] = (double)hctl[KNN_CTL_QBAD];  // #non-finite fp16 query coordinates
+    (void)thr_out;
+    (void)r;
+    return hipSuccess;
+}

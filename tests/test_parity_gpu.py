@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # imported BEFORE libknn_mi355x.so is dlopen'ed: one HIP runtime (torch's) per process
 
 import multicore_hw2_amd as pkg
 from tests.oracle_lib import TA_SAMPLES
@@ -131,7 +132,6 @@ def test_sharded_callback_equals_single_shard(oracle, path):
 
 def test_index_api_keys_fold_across_shards_on_device(oracle, path):
     """knn_index_*: device-resident shards folding into one key array (the bench.py data path)."""
-    import torch
     k, m, n = 16, 512, 50000
     Q, R = oracle.synth(m * k, 31), oracle.synth(n * k, 32)
     dev = torch.device("cuda:0")
@@ -159,8 +159,115 @@ def test_index_api_keys_fold_across_shards_on_device(oracle, path):
         ix.close()
 
 
+def _filter_case(rng, name, m, n, k):
+    if name == "uniform":
+        return rng.random((m, k), dtype=np.float32), rng.random((n, k), dtype=np.float32)
+    if name == "offset":      # far from the origin: centring must absorb it
+        return ((rng.random((m, k)) * 3 + 1000).astype(np.float32),
+                (rng.random((n, k)) * 3 + 1000).astype(np.float32))
+    if name == "clustered":
+        c = rng.random((5, k))
+        return ((c[rng.integers(0, 5, m)] + rng.normal(0, 1e-3, (m, k))).astype(np.float32),
+                (c[rng.integers(0, 5, n)] + rng.normal(0, 1e-3, (n, k))).astype(np.float32))
+    if name == "mixed_scales":  # per-dimension scales differ by 1e4: small dims fall into fp16 subnormals
+        sc = np.logspace(-4, 0, k)
+        return ((rng.normal(0, 1, (m, k)) * sc).astype(np.float32), (rng.normal(0, 1, (n, k)) * sc).astype(np.float32))
+    if name == "queries_outside":  # queries well outside the references' bounding box
+        return ((rng.random((m, k)) * 40 - 20).astype(np.float32), rng.random((n, k)).astype(np.float32))
+    raise ValueError(name)
+
+
+@pytest.mark.parametrize("k", [3, 16, 24, 100])
+@pytest.mark.parametrize("dist", ["uniform", "offset", "clustered", "mixed_scales", "queries_outside"])
+def test_filter_scores_stay_inside_the_proven_error_bound(k, dist):
+    """The MFMA filter is only sound if |S + M - sigma^2 d^2| <= 2 eta sigma d + eta^2 + rho for
+    EVERY pair (knn_filter.hip header).  Checked against a float64 evaluation of the true distance;
+    also checks the fragment layout (a swapped row/column map breaks it at once)."""
+    rng = np.random.default_rng(k * 7 + len(dist))
+    m, n = 70, 1500
+    Q, R = _filter_case(rng, dist, m, n, k)
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    pkg.set_option("path", 2)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    finally:
+        pkg.set_option("path", 0)
+    scores = torch.full((m, n), float("nan"), dtype=torch.float32, device=dev)
+    qn = torch.empty(m, dtype=torch.float32, device=dev)
+    sigma, eta, rho, amax, bmax, g2, gam, qbad = ix.debug_filter_scores(m, q_d.data_ptr(), scores.data_ptr(),
+                                                                          qn.data_ptr())
+    torch.cuda.synchronize()
+    ix.close()
+    assert qbad == 0 and bmax <= 1.0
+    S = scores.cpu().numpy().astype(np.float64)
+    M = qn.cpu().numpy().astype(np.float64)
+    assert np.isfinite(S).all()
+    d2 = ((Q.astype(np.float64)[:, None, :] - R.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    D = sigma * sigma * d2
+    err = np.abs(S + M[:, None] - D)
+    bound = 2 * eta * np.sqrt(D) + eta * eta + rho + gam * M[:, None]
+    worst = float((err / bound).max())
+    assert worst <= 1.0, (dist, k, worst)
+    # the bound must not be vacuous either: on uniform data it stays a small fraction of D
+    if dist == "uniform" and k == 16:
+        assert float(np.median(bound / D)) < 0.05
+
+
+def test_filter_path_is_taken_and_reports_candidates(oracle):
+    k, m, n = 16, 1024, 1 << 20
+    Q, R = oracle.synth(m * k, 1000), oracle.synth(n * k, 1001)
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)   # auto path
+    pkg.keys_init(keys.data_ptr(), m)
+    ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+    pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+    torch.cuda.synchronize()
+    path_taken, records, fallback, _ = ix.last_stats()
+    assert path_taken == 2 and fallback == 0
+    assert 0 < records < 400 * m          # ~n/sample survivors per query, far below m*n/32
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R))
+    ix.close()
+
+
+def test_filter_falls_back_on_the_device_when_queries_rule_it_out(oracle):
+    """NaN / Inf / far-away queries are detected on the GPU; the gated exact kernels then scan
+    everything — no host round trip, same bit-exact answer."""
+    k, m, n = 16, 256, 100000
+    Q, R = oracle.synth(m * k, 5).reshape(m, k).copy(), oracle.synth(n * k, 6)
+    dev = torch.device("cuda:0")
+    r_d = torch.from_numpy(R).to(dev)
+    pkg.set_option("path", 2)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    try:
+        for what in ("nan", "inf", "far", "clean"):
+            Qc = Q.copy()
+            if what == "nan":
+                Qc[7, 3] = np.nan
+            elif what == "inf":
+                Qc[9, 0] = np.inf
+            elif what == "far":
+                Qc[11] = 1e6
+            q_d = torch.from_numpy(Qc).to(dev)
+            pkg.keys_init(keys.data_ptr(), m)
+            ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+            pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+            torch.cuda.synchronize()
+            path_taken, records, fallback, _ = ix.last_stats()
+            assert path_taken == 2
+            assert (fallback != 0) == (what != "clean"), (what, fallback)
+            np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Qc, R), err_msg=what)
+    finally:
+        pkg.set_option("path", 0)
+        ix.close()
+
+
 def test_device_synth_fill_matches_oracle_generator(oracle):
-    import torch
     x = torch.empty(100003, dtype=torch.float32, device="cuda:0")
     pkg.synth_fill_device(x.data_ptr(), x.numel(), 1001, first=12345,
                           stream=torch.cuda.current_stream().cuda_stream)
@@ -173,7 +280,6 @@ def test_headline_shape_properties(oracle, path):
     not need a full CPU scan — (1) a seeded subset of queries against the full reference set with
     the oracle, (2) planting an exact copy of each query makes that copy's index the answer,
     (3) splitting the set into shards and min-merging keys gives the same indices."""
-    import torch
     k, m, n = 16, 1024, 1 << 24
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
