@@ -181,11 +181,13 @@ def cpu_baseline(k, m, n, cpu_queries, gpu_idx):
     from tests.oracle_lib import Oracle
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
-    if cpu_queries < 0:
-        triples_per_s = 0.9e9    # one host core, order of magnitude
-        cpu_queries = int(max(1, min(m, 15.0 * triples_per_s / (float(n) * k))))
     Q = o.synth(m * k, 1000)
     R = o.synth(n * k, 1001)
+    if cpu_queries < 0:          # size the sample for ~15 s from a 2-query probe
+        t0 = time.perf_counter()
+        o.v0_serial(k, Q[:2 * k], R)
+        per_query = (time.perf_counter() - t0) / 2
+        cpu_queries = int(max(1, min(m, 15.0 / max(per_query, 1e-9))))
     t0 = time.perf_counter()
     want = o.v0_serial(k, Q[:cpu_queries * k], R)
     dt = time.perf_counter() - t0

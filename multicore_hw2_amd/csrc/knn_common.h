@@ -23,8 +23,9 @@ hipError_t knn_exact_launch(int k, int m, long long n_local, long long base, con
 
 // Exact re-rank of the filter's candidate records (see knn_rerank_kernel).
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev,
-                             long long base, const u64 *rec_dev, const unsigned *ctl_dev,
-                             unsigned capacity, u64 *keys_dev, hipStream_t stream);
+                             long long base, const u64 *rec_dev, const unsigned *counts_dev,
+                             unsigned nlists, unsigned slice, unsigned *ctl_dev, u64 *keys_dev,
+                             hipStream_t stream);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
@@ -35,7 +36,7 @@ hipError_t knn_synth_fill_launch(float *dst, long long count, u64 seed, long lon
 // Device-side control words of one filter query (FilterState::ctl).
 enum {
     KNN_CTL_FALLBACK = 0,  // != 0: the exact kernels must scan the whole shard (filter unusable)
-    KNN_CTL_RECORDS = 1,   // number of candidate records appended (may exceed the capacity)
+    KNN_CTL_RECORDS = 1,   // total candidate records re-ranked (summed by the re-rank kernel)
     // words 2..4 are the out[0..2] window of knn_frag_kernel for the query batch
     KNN_CTL_AMAX = 2,      // float bits: max |scaled query coordinate| in fp16
     KNN_CTL_QNMAX = 3,     // float bits: max fp32 squared norm of the fp16 query rows
@@ -60,8 +61,12 @@ struct FilterState {
     float *qry_norms = nullptr;// device [qtiles*32]
     float *thr = nullptr;      // device [qtiles*32]
     unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
-    u64 *records = nullptr;    // device [rec_cap]
+    u64 *records = nullptr;    // device [rec_cap]: nlists slices of `slice` records, one per wave
     unsigned rec_cap = 0;
+    unsigned *counts = nullptr;// device [nlists]: records each wave produced (may exceed slice)
+    unsigned nlists = 0, slice = 0;
+    float *umin = nullptr;     // device [sample blocks][m_padded]: per-block minima of the sample pass
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // optional: bracket the filter kernel
 };
 
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false

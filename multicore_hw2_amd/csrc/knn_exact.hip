@@ -116,10 +116,17 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restr
         const int qa = q0 + (2 * p) * KNN_WAVE + lane;
         const int qb = q0 + (2 * p + 1) * KNN_WAVE + lane;
         // best == +INF means no reference beat +INF: leave the key alone (v0 keeps index 0).
-        if (qa < m && best[p].x < INFINITY)
-            key_atomic_min(&keys[qa], pack_key(best[p].x, bidx[2 * p]));
-        if (qb < m && best[p].y < INFINITY)
-            key_atomic_min(&keys[qb], pack_key(best[p].y, bidx[2 * p + 1]));
+        // (keys[] only decreases: a stale plain read can only cause a spare atomic, never skip one)
+        if (qa < m && best[p].x < INFINITY) {
+            const u64 key = pack_key(best[p].x, bidx[2 * p]);
+            if (key < keys[qa])
+                key_atomic_min(&keys[qa], key);
+        }
+        if (qb < m && best[p].y < INFINITY) {
+            const u64 key = pack_key(best[p].y, bidx[2 * p + 1]);
+            if (key < keys[qb])
+                key_atomic_min(&keys[qb], key);
+        }
     }
 }
 
@@ -167,8 +174,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__rest
             bidx = gidx;
         }
     }
-    if (qi < m && best < INFINITY)
-        key_atomic_min(&keys[qi], pack_key(best, bidx));
+    if (qi < m && best < INFINITY) {
+        const u64 key = pack_key(best, bidx);
+        if (key < keys[qi])
+            key_atomic_min(&keys[qi], key);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
     for (int t = 0; t < QT; ++t) {
         // A lane that never updated carries (+INF, 0) == kKeyInit, neutral under min.
         const u64 key = wave_min_u64(pack_key(best[t], bidx[t]));
-        if (lane == 0 && q0 + t < m && key < kKeyInit)
+        if (lane == 0 && q0 + t < m && key < kKeyInit && key < keys[q0 + t])
             key_atomic_min(&keys[q0 + t], key);
     }
 }
@@ -272,31 +282,54 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                                                                const float *__restrict__ R, int k,
                                                                long long n, long long base,
                                                                const u64 *__restrict__ rec,
-                                                               const unsigned *__restrict__ ctl,
-                                                               unsigned capacity,
+                                                               const unsigned *__restrict__ counts,
+                                                               unsigned slice, unsigned *__restrict__ ctl,
                                                                u64 *__restrict__ keys)
 {
 #pragma clang fp contract(off)
-    const unsigned nrec = min(ctl[KNN_CTL_RECORDS], capacity);
-    const u64 total = (u64)nrec * 16ull;
-    for (u64 c = (u64)blockIdx.x * KNN_BLOCK + threadIdx.x; c < total; c += (u64)gridDim.x * KNN_BLOCK) {
-        const u64 e = rec[c >> 4];
-        const unsigned reg = (unsigned)(c & 15ull);
-        const unsigned qi = (unsigned)(e >> 32);
-        const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
-        const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
-        if (ri >= n)
-            continue;
-        const float *__restrict__ q = Q + (size_t)qi * k;
-        const float *__restrict__ r = R + (size_t)ri * k;
-        float acc = 0.0f;
-        for (int d = 0; d < k; ++d) {
-            const float diff = q[d] - r[d];
-            const float sq = diff * diff;
-            acc = acc + sq;
+    // one block per record list (= per filter wave)
+    const unsigned want = counts[blockIdx.x];
+    const unsigned nrec = min(want, slice);
+    if (threadIdx.x == 0 && want != 0u) {
+        atomicAdd(&ctl[KNN_CTL_RECORDS], nrec);
+        if (want > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;  // candidates were dropped: the gated exact scan takes over
+    }
+    const u64 *__restrict__ list = rec + (size_t)blockIdx.x * slice;
+    // 16 consecutive lanes share one record (one query): their keys are min-folded with shuffles
+    // and ONE guarded atomic is issued per record (the keys sit on a handful of cache lines; the
+    // unguarded 16-per-record form spent ~1 ms in atomic contention at 270k records).
+    const unsigned total = (nrec * 16u + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
+    for (unsigned c = threadIdx.x; c < total; c += KNN_BLOCK) {
+        u64 key = ~0ull;
+        unsigned qi = 0u;
+        if (c < nrec * 16u) {
+            const u64 e = list[c >> 4];
+            const unsigned reg = c & 15u;
+            qi = (unsigned)(e >> 32);
+            const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
+            const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+            if (ri < n) {
+                const float *__restrict__ q = Q + (size_t)qi * k;
+                const float *__restrict__ r = R + (size_t)ri * k;
+                float acc = 0.0f;
+                for (int d = 0; d < k; ++d) {
+                    const float diff = q[d] - r[d];
+                    const float sq = diff * diff;
+                    acc = acc + sq;
+                }
+                if (acc < INFINITY)  // false for NaN too: v0 never selects those
+                    key = pack_key(acc, (unsigned)(base + ri));
+            }
         }
-        if (acc < INFINITY)  // false for NaN too: v0 never selects those
-            key_atomic_min(&keys[qi], pack_key(acc, (unsigned)(base + ri)));
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const u64 o = __shfl_xor(key, off, KNN_WAVE);
+            key = o < key ? o : key;
+        }
+        // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
+        if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+            key_atomic_min(&keys[qi], key);
     }
 }
 
@@ -429,11 +462,13 @@ hipError_t knn_exact_launch(int k, int m, long long n, long long base, const flo
 }
 
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
-                             const u64 *rec, const unsigned *ctl, unsigned capacity, u64 *keys,
-                             hipStream_t s)
+                             const u64 *rec, const unsigned *counts, unsigned nlists, unsigned slice,
+                             unsigned *ctl, u64 *keys, hipStream_t s)
 {
-    hipLaunchKernelGGL(knn_rerank_kernel, dim3(512), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, ctl,
-                       capacity, keys);
+    if (nlists == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, counts,
+                       slice, ctl, keys);
     return hipGetLastError();
 }
 

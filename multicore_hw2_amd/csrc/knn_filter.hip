@@ -179,9 +179,19 @@ __host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double si
     return c;
 }
 
-__host__ __device__ inline float knn_threshold(const BoundConsts &c, double e0, double mq)
+// Threshold implied by a filter score `u` = S of SOME real reference j0 of the shard (the minimum
+// over the sample pass), for a query whose fp16 row has computed squared norm mq:
+//   D~_j0 <= u + mq(1+g) + rho;  (sqrt(D_j0) - eta)^2 <= D~_j0 + 2 eta^2  =>  D_j0 <= D0up
+//   the winner j* has E_j* <= E_j0 (v0 values), hence D_j* <= D0up (1+g2)^2 + sigma^2 tau =: Dup
+//   and its own score obeys S_j* <= Dup + 2 eta sqrt(Dup) + eta^2 + rho - mq(1-g).
+// Monotone in u, so any upper bound of the true sample minimum is safe too.
+__host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, double mq)
 {
-    const double dup = c.sigma2 * (e0 * (1.0 + c.g2) + c.tau);
+    double dt = u + mq * (1.0 + 1.01 * c.gam) + c.rho;
+    if (dt < 0.0)
+        dt = 0.0;
+    const double sq0 = c.eta + sqrt(dt + 2.0 * c.eta2);
+    const double dup = sq0 * sq0 * (1.0 + c.g2) * (1.0 + c.g2) + c.sigma2 * c.tau;
     double thr = dup + 2.0 * c.eta * sqrt(dup) + c.eta2 + c.rho - mq * (1.0 - c.gam);
     thr += fabs(thr) * 1e-6 + 1e-30;                  // slack for the double arithmetic above
     float tf = (float)thr;
@@ -190,7 +200,8 @@ __host__ __device__ inline float knn_threshold(const BoundConsts &c, double e0, 
     return nextafterf(tf, INFINITY);                  // the kernel tests S < thr (strict)
 }
 
-__global__ __launch_bounds__(256) void knn_thr_kernel(const u64 *__restrict__ keys,
+// umin: per-block minima of the sample pass, [nblocks][m_padded]
+__global__ __launch_bounds__(256) void knn_thr_kernel(const float *__restrict__ umin, int nblocks,
                                                       const float *__restrict__ qnorm, int m,
                                                       int m_padded, int k, int kt, float sigma,
                                                       float bmax, float nmax, float amax_limit,
@@ -204,12 +215,14 @@ __global__ __launch_bounds__(256) void knn_thr_kernel(const u64 *__restrict__ ke
     bool bad = ctl[KNN_CTL_QBAD] != 0u || !(amax <= amax_limit);
     float t = -INFINITY;  // padding queries never pass
     if (i < m) {
-        const float e0 = __uint_as_float((unsigned)(keys[i] >> 32));
-        if (!(e0 < INFINITY))
-            bad = true;  // no finite exact distance known: cannot bound
+        float u = INFINITY;
+        for (int b = 0; b < nblocks; ++b)
+            u = fminf(u, umin[(size_t)b * m_padded + i]);
+        if (!(u < INFINITY))
+            bad = true;  // no finite sample score: cannot bound
         if (!bad) {
             const BoundConsts c = knn_bound_consts(k, kt, sigma, amax, bmax, nmax);
-            t = knn_threshold(c, e0, qnorm[i]);
+            t = knn_threshold(c, u, qnorm[i]);
             if (!(t < INFINITY))
                 bad = true;
         }
@@ -259,8 +272,8 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 template <int KT, int QT>
 __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c, const h8 (&qf)[QT][KT],
                                                 const float *__restrict__ s_thr, int lane, int qt0,
-                                                long long tile, u64 *__restrict__ rec,
-                                                unsigned *__restrict__ ctl, unsigned cap)
+                                                long long tile, u64 *__restrict__ my_rec,
+                                                unsigned &cnt, unsigned slice)
 {
     f16v d[2];
     d[0] = c;
@@ -286,11 +299,17 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
         const float m5 = min3f(m0, m1, m2);
         const float m6 = min3f(m3, m4, x[15]);
         const float mn = min3f(m5, m6, th);
-        if (__builtin_expect(mn < th, 0)) {  // rare: one of this lane's 16 rows may beat the bound
-            const unsigned pos = atomicAdd(&ctl[KNN_CTL_RECORDS], 1u);
-            if (pos < cap)
-                rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
-                           (u64)(lane >> 5);
+        const bool hit = mn < th;  // rare: one of this lane's 16 rows may beat the bound
+        const u64 mask = __ballot(hit);
+        if (__builtin_expect(mask != 0ull, 0)) {  // wave-uniform branch
+            if (hit) {
+                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (pos < slice)
+                    my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
+                                  (u64)(lane >> 5);
+            }
+            cnt += (unsigned)__popcll(mask);
         }
     }
 }
@@ -299,8 +318,10 @@ template <int KT, int QT>
 __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
-    unsigned *__restrict__ ctl, unsigned cap)
+    unsigned *__restrict__ counts, const unsigned *__restrict__ ctl, unsigned slice)
 {
+    // Records go to a slice of `rec` private to this wave (no shared counter: a single atomic
+    // word serialises at ~88 returns/us); counts[wave] = records the wave wanted to write.
     __shared__ float s_thr[QT * 32];
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;
@@ -316,8 +337,9 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
     const long long nwaves = (long long)gridDim.x * (FILTER_BLOCK / 64);
     const long long t0 = ntiles * wave / nwaves;
     const long long t1 = ntiles * (wave + 1) / nwaves;
-    if (t0 >= t1)
-        return;
+    const size_t list = (size_t)blockIdx.y * (size_t)nwaves + (size_t)wave;
+    u64 *__restrict__ my_rec = rec + list * slice;
+    unsigned cnt = 0u;
 
     h8 qf[QT][KT];
 #pragma unroll
@@ -328,26 +350,109 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
             qf[t][kk] = qfg[((size_t)(qt0 + tt) * KT + kk) * 64 + lane];
     }
 
-    h8 a[KT];
-    f16v c;
-    load_ref_tile<KT>(rf, rn, t0, lane, a, c);
-    for (long long tile = t0; tile < t1; ++tile) {
-        h8 an[KT];
-        f16v cn;
-        load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);  // prefetch
-        filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, rec, ctl, cap);
+    if (t0 < t1) {
+        h8 a[KT];
+        f16v c;
+        load_ref_tile<KT>(rf, rn, t0, lane, a, c);
+        for (long long tile = t0; tile < t1; ++tile) {
+            h8 an[KT];
+            f16v cn;
+            load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);  // prefetch
+            filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice);
 #pragma unroll
-        for (int kk = 0; kk < KT; ++kk)
-            a[kk] = an[kk];
-        c = cn;
+            for (int kk = 0; kk < KT; ++kk)
+                a[kk] = an[kk];
+            c = cn;
+        }
     }
+    if (lane == 0)
+        counts[list] = cnt;
 }
 
-// After the re-rank: a record overflow means candidates were dropped -> full exact scan.
-__global__ void knn_filter_finish_kernel(unsigned *__restrict__ ctl, unsigned cap)
+// Sample pass: the same MFMA stream over every `stride`-th reference tile, keeping only the
+// running minimum score per query (no thresholds, no branches).  It replaces an exact pre-pass:
+// the minimum is a score of a real reference, which is all knn_threshold needs.  Per-block
+// minima go to umin[blockIdx.x][query]; the threshold kernel folds the blocks.
+template <int KT, int QT>
+__global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_sample_kernel(
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg, int qtiles,
+    long long ntiles, long long stride, float *__restrict__ umin, int m_padded,
+    const unsigned *__restrict__ ctl)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && ctl[KNN_CTL_RECORDS] > cap)
-        ctl[KNN_CTL_FALLBACK] = 1u;
+    __shared__ float s_min[FILTER_BLOCK / 64][QT * 32];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int qt0 = blockIdx.y * QT;
+    const int nq = min(QT, qtiles - qt0);
+    const long long wave = (long long)blockIdx.x * (FILTER_BLOCK / 64) + wib;
+    const long long nwaves = (long long)gridDim.x * (FILTER_BLOCK / 64);
+    const long long ns = (ntiles + stride - 1) / stride;  // sampled tiles: 0, stride, 2 stride, ...
+    const long long i0 = ns * wave / nwaves;
+    const long long i1 = ns * (wave + 1) / nwaves;
+
+    h8 qf[QT][KT];
+    float um[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int tt = min(t, nq - 1);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+            qf[t][kk] = qfg[((size_t)(qt0 + tt) * KT + kk) * 64 + lane];
+        um[t] = INFINITY;
+    }
+    if (i0 < i1) {
+        h8 a[KT];
+        f16v c;
+        load_ref_tile<KT>(rf, rn, i0 * stride, lane, a, c);
+        for (long long i = i0; i < i1; ++i) {
+            h8 an[KT];
+            f16v cn;
+            load_ref_tile<KT>(rf, rn, min(i + 1, i1 - 1) * stride, lane, an, cn);
+            f16v d[2];
+            d[0] = c;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qf[0][kk], d[0], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                if (t + 1 < QT) {
+                    f16v &dn = d[(t + 1) & 1];
+                    dn = c;
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk)
+                        dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qf[t + 1][kk], dn, 0, 0, 0);
+                }
+                const f16v &x = d[t & 1];
+                const float m0 = min3f(x[0], x[1], x[2]);
+                const float m1 = min3f(x[3], x[4], x[5]);
+                const float m2 = min3f(x[6], x[7], x[8]);
+                const float m3 = min3f(x[9], x[10], x[11]);
+                const float m4 = min3f(x[12], x[13], x[14]);
+                const float m5 = min3f(m0, m1, m2);
+                const float m6 = min3f(m3, m4, x[15]);
+                um[t] = min3f(m5, m6, um[t]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                a[kk] = an[kk];
+            c = cn;
+        }
+    }
+    // lanes l and l+32 hold the same query column: fold, then fold the block's waves through LDS
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float v = fminf(um[t], __shfl_xor(um[t], 32, KNN_WAVE));
+        if (lane < 32)
+            s_min[wib][t * 32 + lane] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq * 32; i += FILTER_BLOCK) {
+        float v = s_min[0][i];
+#pragma unroll
+        for (int w = 1; w < FILTER_BLOCK / 64; ++w)
+            v = fminf(v, s_min[w][i]);
+        umin[(size_t)blockIdx.x * m_padded + (size_t)qt0 * 32 + i] = v;
+    }
 }
 
 // Test hook: all scores of one (reference tile, query tile) pair per wave.
@@ -385,7 +490,9 @@ __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restr
             return e_;                   \
     } while (0)
 
-static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB
+static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB, split evenly over the waves
+static const unsigned kMaxLists = 1u << 16;
+static const unsigned kSampleBlocks = 128;           // blocks of the sample pass (x 4 waves)
 static const float kAmaxLimit = 1024.0f;           // queries far outside the references' box
 
 void knn_filter_free(FilterState &st)
@@ -398,6 +505,8 @@ void knn_filter_free(FilterState &st)
     (void)hipFree(st.thr);
     (void)hipFree(st.ctl);
     (void)hipFree(st.records);
+    (void)hipFree(st.counts);
+    (void)hipFree(st.umin);
     st = FilterState();
 }
 
@@ -504,6 +613,13 @@ static hipError_t ensure_workspace(FilterState &st, int m)
         FTRY(hipMalloc((void **)&st.records, (size_t)kRecordCapacity * sizeof(u64)));
         st.rec_cap = kRecordCapacity;
     }
+    if (!st.counts)
+        FTRY(hipMalloc((void **)&st.counts, (size_t)kMaxLists * sizeof(unsigned)));
+    if (m > st.m_cap) {
+        (void)hipFree(st.umin);
+        st.umin = nullptr;
+        FTRY(hipMalloc((void **)&st.umin, (size_t)kSampleBlocks * ((size_t)(m + 31) / 32 * 32) * sizeof(float)));
+    }
     if (m > st.m_cap) {
         (void)hipFree(st.qry_frags);
         (void)hipFree(st.qry_norms);
@@ -536,15 +652,51 @@ template <int KT, int QT>
 static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t s)
 {
     const int qtiles = (m + 31) / 32;
+    const int m_padded = qtiles * 32;
     const unsigned gy = (unsigned)((qtiles + QT - 1) / QT);
+
+    // 1. sample pass over every stride-th tile (about 1/16 of the shard) -> per-query minima
+    long long stride = st.ntiles / 2048;
+    if (stride < 1)
+        stride = 1;
+    if (stride > 16)
+        stride = 16;
+    const long long ns = (st.ntiles + stride - 1) / stride;
+    unsigned sb = kSampleBlocks;
+    if ((long long)sb * 4 > ns)
+        sb = (unsigned)((ns + 3) / 4);
+    hipLaunchKernelGGL((knn_filter_sample_kernel<KT, QT>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, qtiles, st.ntiles,
+                       stride, st.umin, m_padded, st.ctl);
+    FTRY(hipGetLastError());
+
+    // 2. thresholds
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)((m_padded + 255) / 256)), dim3(256), 0, s, st.umin,
+                       (int)sb, st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
+                       st.thr, st.ctl);
+    FTRY(hipGetLastError());
+
+    // 3. the filter proper (timed: the dominant kernel)
     long long waves = (long long)num_cu * 8;  // 2 waves per SIMD
     if (waves > st.ntiles)
         waves = st.ntiles;
-    const unsigned gx = (unsigned)((waves + 3) / 4);
+    unsigned gx = (unsigned)((waves + 3) / 4);
+    while ((size_t)gx * 4 * gy > kMaxLists && gx > 1)
+        gx = (gx + 1) / 2;
+    if ((size_t)gx * 4 * gy > kMaxLists)
+        return hipErrorInvalidValue;
+    st.nlists = gx * 4 * gy;
+    st.slice = st.rec_cap / st.nlists;
+    FTRY(hipMemsetAsync(st.counts, 0, (size_t)st.nlists * sizeof(unsigned), s));
+    if (st.ev_begin)
+        FTRY(hipEventRecord(st.ev_begin, s));
     hipLaunchKernelGGL((knn_filter_kernel<KT, QT>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                        (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, st.thr, qtiles,
-                       st.ntiles, st.records, st.ctl, st.rec_cap);
-    return hipGetLastError();
+                       st.ntiles, st.records, st.counts, st.ctl, st.slice);
+    FTRY(hipGetLastError());
+    if (st.ev_end)
+        FTRY(hipEventRecord(st.ev_end, s));
+    return hipSuccess;
 }
 
 hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float *r, long long base,
@@ -552,22 +704,8 @@ hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float 
 {
     FTRY(ensure_workspace(st, m));
     FTRY(prep_queries(st, m, q, s));
-    // sample pre-pass: exact distances to a prefix of the shard give every query a finite E0
-    long long sample = st.n / 64;
-    if (sample < 1024)
-        sample = 1024;
-    if (sample > 65536)
-        sample = 65536;
-    if (sample > st.n)
-        sample = st.n;
-    FTRY(knn_exact_launch(st.k, m, sample, base, q, r, keys, num_cu, nullptr, s));
-    const int m_padded = (m + 31) / 32 * 32;
-    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)((m_padded + 255) / 256)), dim3(256), 0, s, keys,
-                       st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, st.thr,
-                       st.ctl);
-    FTRY(hipGetLastError());
-    if (ev_begin)
-        FTRY(hipEventRecord(ev_begin, s));
+    st.ev_begin = ev_begin;
+    st.ev_end = ev_end;
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {
     case 1:
@@ -587,11 +725,8 @@ hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float 
     case 4: FTRY((launch_filter<4, 4>(st, m, num_cu, s))); break;
     default: FTRY((launch_filter<8, 2>(st, m, num_cu, s))); break;
     }
-    if (ev_end)
-        FTRY(hipEventRecord(ev_end, s));
-    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, st.records, st.ctl, st.rec_cap, keys, s));
-    hipLaunchKernelGGL(knn_filter_finish_kernel, dim3(1), dim3(64), 0, s, st.ctl, st.rec_cap);
-    FTRY(hipGetLastError());
+    // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
+    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, st.records, st.counts, st.nlists, st.slice, st.ctl, keys, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
     return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, st.ctl + KNN_CTL_FALLBACK, s);
 }
