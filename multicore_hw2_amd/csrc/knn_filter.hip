@@ -200,7 +200,8 @@ __host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, d
     return nextafterf(tf, INFINITY);                  // the kernel tests S < thr (strict)
 }
 
-// umin: per-block minima of the sample pass, [nblocks][m_padded]
+// umin: per-block minima of the sample pass, [nblocks][m_padded].  Block = 32 queries x 8
+// parts: each part folds every 8th sample block (coalesced over the 32 queries), LDS folds parts.
 __global__ __launch_bounds__(256) void knn_thr_kernel(const float *__restrict__ umin, int nblocks,
                                                       const float *__restrict__ qnorm, int m,
                                                       int m_padded, int k, int kt, float sigma,
@@ -208,16 +209,23 @@ __global__ __launch_bounds__(256) void knn_thr_kernel(const float *__restrict__ 
                                                       float *__restrict__ thr,
                                                       unsigned *__restrict__ ctl)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m_padded)
+    __shared__ float s_part[8][32];
+    const int ql = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ql;  // m_padded is a multiple of 32
+    float u = INFINITY;
+    for (int b = part; b < nblocks; b += 8)
+        u = fminf(u, umin[(size_t)b * m_padded + i]);
+    s_part[part][ql] = u;
+    __syncthreads();
+    if (part != 0)
         return;
+#pragma unroll
+    for (int p = 1; p < 8; ++p)
+        u = fminf(u, s_part[p][ql]);
     const float amax = __uint_as_float(ctl[KNN_CTL_AMAX]);
     bool bad = ctl[KNN_CTL_QBAD] != 0u || !(amax <= amax_limit);
     float t = -INFINITY;  // padding queries never pass
     if (i < m) {
-        float u = INFINITY;
-        for (int b = 0; b < nblocks; ++b)
-            u = fminf(u, umin[(size_t)b * m_padded + i]);
         if (!(u < INFINITY))
             bad = true;  // no finite sample score: cannot bound
         if (!bad) {
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restr
 
 static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB, split evenly over the waves
 static const unsigned kMaxLists = 1u << 16;
-static const unsigned kSampleBlocks = 128;           // blocks of the sample pass (x 4 waves)
+static const unsigned kSampleBlocks = 512;           // most blocks the sample pass uses (x 4 waves)
 static const float kAmaxLimit = 1024.0f;           // queries far outside the references' box
 
 void knn_filter_free(FilterState &st)
@@ -662,7 +670,9 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     if (stride > 16)
         stride = 16;
     const long long ns = (st.ntiles + stride - 1) / stride;
-    unsigned sb = kSampleBlocks;
+    unsigned sb = (unsigned)num_cu * 2;  // 2 waves per SIMD, like the main pass
+    if (sb > kSampleBlocks)
+        sb = kSampleBlocks;
     if ((long long)sb * 4 > ns)
         sb = (unsigned)((ns + 3) / 4);
     hipLaunchKernelGGL((knn_filter_sample_kernel<KT, QT>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
@@ -671,7 +681,7 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     FTRY(hipGetLastError());
 
     // 2. thresholds
-    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)((m_padded + 255) / 256)), dim3(256), 0, s, st.umin,
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(256), 0, s, st.umin,
                        (int)sb, st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
                        st.thr, st.ctl);
     FTRY(hipGetLastError());
