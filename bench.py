@@ -145,6 +145,19 @@ def main():
                     "kernel": "knn_exact (VALU-bound at this m: see valu_frac)",
                     "valu_lane_ops_per_s": lane_ops / (kern_avg_ms * 1e-3),
                     "valu_frac": lane_ops / (kern_avg_ms * 1e-3) / VALU_LANE_OPS_PEAK}
+        # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
+        # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json); only quoted for the
+        # workload/kernel it was measured on.
+        pmc_path = os.path.join(ROOT, "profiles", "r01_c3_pmc_traffic.json")
+        if wname == "C3" and world == 1 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)["kernels"]
+            kname = "_Z17knn_filter_kernelILi1ELi32EE" if path_taken == 2 else "void knn_exact_qreg<16, 2>"
+            for name, ent in pmc.items():
+                if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
+                    roof["traffic"] = ent["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r01_c3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
+                                             "separate passes; read bytes = 2 x FETCH_SIZE KiB, gfx950)"
         roof["kernel_avg_ms"] = kern_avg_ms
         roof["kernel_launches_timed"] = launches
         roof["algorithmic_bytes_per_launch"] = alg_bytes
