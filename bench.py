@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact VALU only, 2 force MFMA filter")
+    ap.add_argument("--filter-qt", type=int, default=0, help="tuning: query tiles per filter wave (0 auto)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
     return ap.parse_args()
@@ -75,6 +76,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg.set_option("path", args.path)
+    pkg.set_option("filter_qt", args.filter_qt)
 
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)

@@ -109,6 +109,8 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             shards (0 = one per visible GPU).  Shards beyond the GPU count
  *             wrap around the devices — exercises the partition + merge logic
  *             on a single GPU.
+ *   "filter_qt" tuning: query tiles (of 32) each filter wave keeps in registers: 8, 16 or 32
+ *             (0 = chosen from m)
  * Returns KNN_EINVAL for an unknown name or value. */
 int knn_set_option(const char *name, long long value);
 long long knn_get_option(const char *name);

@@ -29,7 +29,8 @@ EXPORTED_SYMBOLS = [
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "libknn_mi355x.so")
+# KNN_MI355X_LIB: A/B hook — load another build of the same C-ABI (e.g. a previous commit's .so)
+lib_path = os.environ.get("KNN_MI355X_LIB") or os.path.join(_HERE, "libknn_mi355x.so")
 _lib = None
 
 

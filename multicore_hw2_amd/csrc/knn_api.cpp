@@ -61,6 +61,7 @@ int fail(int code, const char *what, const char *detail = nullptr)
 
 std::atomic<long long> g_opt_path{0};
 std::atomic<long long> g_opt_shards{0};
+std::atomic<long long> g_opt_filter_qt{0};
 
 struct DeviceGuard {
     int prev = -1;
@@ -125,6 +126,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_shards = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "filter_qt")) {
+        if (value != 0 && value != 8 && value != 16 && value != 32)
+            return fail(KNN_EINVAL, "knn_set_option: filter_qt must be 0, 8, 16 or 32");
+        g_opt_filter_qt = value;
+        return KNN_OK;
+    }
     return fail(KNN_EINVAL, "knn_set_option: unknown option", name);
 }
 
@@ -134,6 +141,8 @@ long long knn_get_option(const char *name)
         return g_opt_path;
     if (name && !strcmp(name, "shards"))
         return g_opt_shards;
+    if (name && !strcmp(name, "filter_qt"))
+        return g_opt_filter_qt;
     return -1;
 }
 
@@ -258,6 +267,7 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
     if (use_filter) {
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;
+        idx->filter.force_qt = (int)g_opt_filter_qt;
         HIP_TRY(knn_filter_query(idx->filter, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));
         return KNN_OK;

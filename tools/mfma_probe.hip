@@ -11,7 +11,9 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
-// MODE 0: MFMA only; 1: MFMA + min3 tree + compare; 2: min3 tree only (on a rotating register set)
+// MODE 0: MFMA only; 1: MFMA + min3 tree + compare/branch per tile; 2: min3 tree only;
+// 3: MFMA + min3 tree folded into a running minimum (no compare, no branch);
+// 4: MFMA + min3 tree + (acc |= mn ^ thr), one compare/branch per 4 tiles
 template <int MODE, int WPS>
 __global__ __launch_bounds__(256, WPS) void probe(const h8 *__restrict__ in, float *__restrict__ out, int iters, float thr)
 {
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(256, WPS) void probe(const h8 *__restrict__ in, flo
     f16v c;
     for (int i = 0; i < 16; ++i) c[i] = (float)i * 0.01f;
     float um = 1e30f;
-    unsigned hits = 0;
+    unsigned hits = 0, acc = 0;
     f16v d[2];
     d[0] = c; d[1] = c;
     for (int it = 0; it < iters; ++it) {
@@ -44,8 +46,19 @@ __global__ __launch_bounds__(256, WPS) void probe(const h8 *__restrict__ in, flo
                 const float m4 = min3f(x[12], x[13], x[14]);
                 const float m5 = min3f(m0, m1, m2);
                 const float m6 = min3f(m3, m4, x[15]);
-                const float mn = min3f(m5, m6, thr);
-                if (__builtin_expect(mn < thr, 0)) { ++hits; um = mn; }
+                if (MODE == 3) {
+                    um = min3f(m5, m6, um);
+                } else if (MODE == 4) {
+                    const float mn = min3f(m5, m6, thr);
+                    acc |= __float_as_uint(mn) ^ __float_as_uint(thr);
+                    if ((t & 3) == 3) {
+                        if (__builtin_expect(acc != 0u, 0)) { ++hits; um = mn; }
+                        acc = 0u;
+                    }
+                } else {
+                    const float mn = min3f(m5, m6, thr);
+                    if (__builtin_expect(mn < thr, 0)) { ++hits; um = mn; }
+                }
             } else {
                 asm volatile("" :: "v"(d[t & 1]));
             }
@@ -96,5 +109,9 @@ int main()
     if (run<1, 2>("mfma + min3 tree + cmp", in, out, cus, a, b)) return 1;
     if (run<2, 1>("min3 tree + cmp only", in, out, cus, a, b)) return 1;
     if (run<2, 2>("min3 tree + cmp only", in, out, cus, a, b)) return 1;
+    if (run<3, 1>("mfma + min3 running min", in, out, cus, a, b)) return 1;
+    if (run<3, 2>("mfma + min3 running min", in, out, cus, a, b)) return 1;
+    if (run<4, 1>("mfma + min3 + xor/or, cmp/4", in, out, cus, a, b)) return 1;
+    if (run<4, 2>("mfma + min3 + xor/or, cmp/4", in, out, cus, a, b)) return 1;
     return 0;
 }
