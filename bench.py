@@ -72,11 +72,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("KNN_BENCH_FORCE_DIST") == "1":   # the env hook rehearses the N>1 code on 1 GPU
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg.set_option("path", args.path)
-    pkg.set_option("filter_qt", args.filter_qt)
+    if args.filter_qt:
+        pkg.set_option("filter_qt", args.filter_qt)
 
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)

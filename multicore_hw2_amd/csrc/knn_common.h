@@ -21,6 +21,12 @@ hipError_t knn_exact_launch(int k, int m, long long n_local, long long base, con
                             const float *r_dev, u64 *keys_dev, int num_cu, const unsigned *gate,
                             hipStream_t stream);
 
+// Exact re-rank of the filter's candidate records (see knn_rerank_kernel).
+hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev,
+                             long long base, const u64 *rec_dev, const unsigned *counts_dev,
+                             unsigned nlists, unsigned slice, unsigned *ctl_dev, u64 *keys_dev,
+                             hipStream_t stream);
+
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
 hipError_t knn_synth_fill_launch(float *dst, long long count, u64 seed, long long first,
@@ -30,7 +36,7 @@ hipError_t knn_synth_fill_launch(float *dst, long long count, u64 seed, long lon
 // Device-side control words of one filter query (FilterState::ctl).
 enum {
     KNN_CTL_FALLBACK = 0,  // != 0: the exact kernels must scan the whole shard (filter unusable)
-    KNN_CTL_RECORDS = 1,   // total candidate records re-ranked exactly (summed over the filter's waves)
+    KNN_CTL_RECORDS = 1,   // total candidate records re-ranked (summed by the re-rank kernel)
     // words 2..4 are the out[0..2] window of knn_frag_kernel for the query batch
     KNN_CTL_AMAX = 2,      // float bits: max |scaled query coordinate| in fp16
     KNN_CTL_QNMAX = 3,     // float bits: max fp32 squared norm of the fp16 query rows
@@ -55,12 +61,13 @@ struct FilterState {
     float *qry_norms = nullptr;// device [qtiles*32]
     float *thr = nullptr;      // device [qtiles*32]
     unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
+    u64 *records = nullptr;    // device [rec_cap]: nlists slices of `slice` records, one per wave
+    unsigned rec_cap = 0;
+    unsigned *counts = nullptr;// device [nlists]: records each wave produced (may exceed slice)
+    unsigned nlists = 0, slice = 0;
     float *umin = nullptr;     // device [sample blocks][m_padded]: per-block minima of the sample pass
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // optional: bracket the filter kernel
     unsigned *qpart = nullptr; // device [3 * query blocks]: {max |coord|, max norm, #bad} per block
-    const float *q_src = nullptr, *r_src = nullptr;  // this call's fp32 rows (for the in-kernel re-rank)
-    long long base = 0;
-    u64 *keys = nullptr;
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
 };
 

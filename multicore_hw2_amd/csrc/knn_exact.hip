@@ -274,6 +274,83 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Exact re-rank of the MFMA filter's candidate records.  A record names one query and the 16
+// references one lane of a 32x32 MFMA tile covers: (query << 32) | (ref_tile << 1) | half, rows
+// 8g + 4*half + i (g, i in 0..3) of that tile.  One (record, row) pair per thread, v0 arithmetic.
+// ------------------------------------------------------------------------------------------
+template <int K>  // K > 0: compile-time dimension (all row loads issue before the first use)
+__global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__restrict__ Q,
+                                                               const float *__restrict__ R, int krt,
+                                                               long long n, long long base,
+                                                               const u64 *__restrict__ rec,
+                                                               const unsigned *__restrict__ counts,
+                                                               unsigned slice, unsigned *__restrict__ ctl,
+                                                               u64 *__restrict__ keys)
+{
+#pragma clang fp contract(off)
+    // one block per record list (= per filter wave)
+    const int k = K > 0 ? K : krt;
+    const unsigned want = counts[blockIdx.x];
+    const unsigned nrec = min(want, slice);
+    if (threadIdx.x == 0 && want != 0u) {
+        atomicAdd(&ctl[KNN_CTL_RECORDS], nrec);
+        if (want > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;  // candidates were dropped: the gated exact scan takes over
+    }
+    const u64 *__restrict__ list = rec + (size_t)blockIdx.x * slice;
+    // 16 consecutive lanes share one record (one query): their keys are min-folded with shuffles
+    // and ONE guarded atomic is issued per record (the keys sit on a handful of cache lines; the
+    // unguarded 16-per-record form spent ~1 ms in atomic contention at 270k records).
+    const unsigned total = (nrec * 16u + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
+    for (unsigned c = threadIdx.x; c < total; c += KNN_BLOCK) {
+        u64 key = ~0ull;
+        unsigned qi = 0u;
+        if (c < nrec * 16u) {
+            const u64 e = list[c >> 4];
+            const unsigned reg = c & 15u;
+            qi = (unsigned)(e >> 32);
+            const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
+            const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+            if (ri < n) {
+                const float *__restrict__ q = Q + (size_t)qi * k;
+                const float *__restrict__ r = R + (size_t)ri * k;
+                float acc = 0.0f;
+                if (K > 0) {
+                    float qv[K > 0 ? K : 1], rv[K > 0 ? K : 1];
+#pragma unroll
+                    for (int d = 0; d < K; ++d) {
+                        qv[d] = q[d];
+                        rv[d] = r[d];
+                    }
+#pragma unroll
+                    for (int d = 0; d < K; ++d) {
+                        const float diff = qv[d] - rv[d];
+                        const float sq = diff * diff;
+                        acc = acc + sq;
+                    }
+                } else {
+                    for (int d = 0; d < k; ++d) {
+                        const float diff = q[d] - r[d];
+                        const float sq = diff * diff;
+                        acc = acc + sq;
+                    }
+                }
+                if (acc < INFINITY)  // false for NaN too: v0 never selects those
+                    key = pack_key(acc, (unsigned)(base + ri));
+            }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const u64 o = __shfl_xor(key, off, KNN_WAVE);
+            key = o < key ? o : key;
+        }
+        // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
+        if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+            key_atomic_min(&keys[qi], key);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small utility kernels.
 // ------------------------------------------------------------------------------------------
 __global__ void knn_keys_fill_kernel(u64 *keys, int m)
@@ -399,6 +476,26 @@ hipError_t knn_exact_launch(int k, int m, long long n, long long base, const flo
     case 16: return launch_rlane_k<16>(k, m, n, base, q, r, keys, num_cu, gate, s);
     default: return launch_rlane_k<0>(k, m, n, base, q, r, keys, num_cu, gate, s);
     }
+}
+
+hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
+                             const u64 *rec, const unsigned *counts, unsigned nlists, unsigned slice,
+                             unsigned *ctl, u64 *keys, hipStream_t s)
+{
+    if (nlists == 0)
+        return hipSuccess;
+#define KNN_RERANK(KK)                                                                                     \
+    hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, counts, \
+                       slice, ctl, keys)
+    switch (k) {
+    case 3: KNN_RERANK(3); break;
+    case 4: KNN_RERANK(4); break;
+    case 8: KNN_RERANK(8); break;
+    case 16: KNN_RERANK(16); break;
+    default: KNN_RERANK(0); break;
+    }
+#undef KNN_RERANK
+    return hipGetLastError();
 }
 
 hipError_t knn_keys_fill_launch(u64 *keys, int m, hipStream_t s)

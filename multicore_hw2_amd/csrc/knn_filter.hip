@@ -237,9 +237,13 @@ __global__ __launch_bounds__(256) void knn_thr_kernel(const float *__restrict__ 
                                                       float bmax, float nmax, float amax_limit,
                                                       float *__restrict__ thr,
                                                       unsigned *__restrict__ ctl,
-                                                      const unsigned *__restrict__ qpart, int qblocks)
+                                                      const unsigned *__restrict__ qpart, int qblocks,
+                                                      unsigned *__restrict__ counts, unsigned nlists)
 {
     __shared__ float s_part[8][32];
+    // housekeeping folded in here to save launches: zero the record counters of the filter pass
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nlists; i += gridDim.x * blockDim.x)
+        counts[i] = 0u;
     const int ql = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + ql;  // m_padded is a multiple of 32
     float u = INFINITY;
@@ -316,15 +320,11 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 // query tile is issued first (into the other accumulator buffer), then the min3 tree of the
 // current one runs in its shadow.  Query tiles past the end of the batch hold a copy of the last
 // real tile with threshold -INF: wasted MFMAs, never a record (the host picks QT to fit m).
-// A lane whose 16-row minimum beats its query's threshold appends a record
-// (query << 32) | (ref tile << 1) | lane half to the wave's LDS ring.
-#define FILTER_RING 128  // records a wave can hold between flushes
-
 template <int KT, int QT>
 __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c, const h8 (&qf)[QT][KT],
                                                 const float *__restrict__ s_thr, int lane, int qt0,
-                                                long long tile, u64 *__restrict__ ring, unsigned &pending,
-                                                unsigned &dropped)
+                                                long long tile, u64 *__restrict__ my_rec,
+                                                unsigned &cnt, unsigned slice)
 {
     f16v d[2];
     d[0] = c;
@@ -354,103 +354,43 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
         const u64 mask = __ballot(hit);
         if (__builtin_expect(mask != 0ull, 0)) {  // wave-uniform branch
             if (hit) {
-                const unsigned pos = pending + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (pos < FILTER_RING)
-                    ring[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
-                                (u64)(lane >> 5);
+                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (pos < slice)
+                    my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
+                                  (u64)(lane >> 5);
             }
-            const unsigned add = (unsigned)__popcll(mask);
-            if (pending + add > FILTER_RING)
-                dropped += pending + add - FILTER_RING;
-            pending = min(pending + add, (unsigned)FILTER_RING);
+            cnt += (unsigned)__popcll(mask);
         }
-    }
-}
-
-// Exact re-rank of the wave's pending records, inside the filter kernel: 4 records per pass (16
-// lanes each = the 16 reference rows a record names), v0 arithmetic on the original fp32 rows,
-// shuffle-min over the 16 lanes, one guarded 64-bit atomic per record.  The memory latency of a
-// flush is covered by the SIMD's other wave.
-__device__ __forceinline__ void filter_flush(const u64 *__restrict__ ring, unsigned pending, int lane,
-                                             const float *__restrict__ Q, const float *__restrict__ R,
-                                             int k, long long n, long long base, u64 *__restrict__ keys)
-{
-#pragma clang fp contract(off)
-    for (unsigned b = 0; b < pending; b += 4) {
-        const unsigned ri_ = b + ((unsigned)lane >> 4);
-        u64 key = ~0ull;
-        unsigned qi = 0u;
-        if (ri_ < pending) {
-            const u64 e = ring[ri_];
-            const unsigned reg = (unsigned)lane & 15u;
-            qi = (unsigned)(e >> 32);
-            const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
-            const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
-            if (ri < n) {
-                const float *__restrict__ q = Q + (size_t)qi * k;
-                const float *__restrict__ r = R + (size_t)ri * k;
-                float acc = 0.0f;
-                if (k == 16) {
-                    float qv[16], rv[16];
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) {
-                        qv[d] = q[d];
-                        rv[d] = r[d];
-                    }
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) {
-                        const float diff = qv[d] - rv[d];
-                        const float sq = diff * diff;
-                        acc = acc + sq;
-                    }
-                } else {
-                    for (int d = 0; d < k; ++d) {
-                        const float diff = q[d] - r[d];
-                        const float sq = diff * diff;
-                        acc = acc + sq;
-                    }
-                }
-                if (acc < INFINITY)  // false for NaN too: v0 never selects those
-                    key = ((u64)__float_as_uint(acc) << 32) | (u64)(unsigned)(base + ri);
-            }
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const u64 o = __shfl_xor(key, off, KNN_WAVE);
-            key = o < key ? o : key;
-        }
-        // keys[] only ever decreases: a stale (larger) read can only cause a spare atomic
-        if ((lane & 15) == 0 && key != ~0ull && key < keys[qi])
-            __hip_atomic_fetch_min(&keys[qi], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 template <int KT, int QT>
 __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
-    const float *__restrict__ thrg, int qtiles, long long ntiles, const float *__restrict__ Q,
-    const float *__restrict__ R, int k, long long n, long long base, u64 *__restrict__ keys,
-    unsigned *__restrict__ ctl)
+    const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
+    unsigned *__restrict__ counts, const unsigned *__restrict__ ctl, unsigned slice)
 {
+    // Records go to a slice of `rec` private to this wave (no shared counter: a single atomic
+    // word serialises at ~88 returns/us); counts[wave] = records the wave wanted to write.
     __shared__ float s_thr[QT * 32];
-    __shared__ u64 s_ring[FILTER_BLOCK / 64][FILTER_RING];
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;
     const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int qt0 = blockIdx.y * QT;
     const int nq = min(QT, qtiles - qt0);  // wave-uniform
     for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
         s_thr[i] = i < nq * 32 ? thrg[(size_t)qt0 * 32 + i] : -INFINITY;
     __syncthreads();
 
-    const long long wave = (long long)blockIdx.x * (FILTER_BLOCK / 64) + wib;
+    const long long wave = (long long)blockIdx.x * (FILTER_BLOCK / 64) +
+                           __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long nwaves = (long long)gridDim.x * (FILTER_BLOCK / 64);
     const long long t0 = ntiles * wave / nwaves;
     const long long t1 = ntiles * (wave + 1) / nwaves;
-    u64 *__restrict__ ring = s_ring[wib];
-    unsigned pending = 0u, dropped = 0u, total = 0u;
+    const size_t list = (size_t)blockIdx.y * (size_t)nwaves + (size_t)wave;
+    u64 *__restrict__ my_rec = rec + list * slice;
+    unsigned cnt = 0u;
 
     h8 qf[QT][KT];
 #pragma unroll
@@ -469,35 +409,15 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
             h8 an[KT];
             f16v cn;
             load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);  // prefetch
-            filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, ring, pending, dropped);
-            if (__builtin_expect(pending >= 4u, 0)) {  // wave-uniform
-                // the records were written by other lanes of this wave: LDS ops of one wave
-                // complete in order; the fence only stops the compiler from reordering them
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                filter_flush(ring, pending, lane, Q, R, k, n, base, keys);
-                total += pending;
-                pending = 0u;
-                __builtin_amdgcn_wave_barrier();
-                if (dropped != 0u || total > 16384u)
-                    break;  // the bound is not selective on this data: hand over to the exact scan
-            }
+            filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice);
 #pragma unroll
             for (int kk = 0; kk < KT; ++kk)
                 a[kk] = an[kk];
             c = cn;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        filter_flush(ring, pending, lane, Q, R, k, n, base, keys);
-        total += pending;
     }
-    if (lane == 0 && total != 0u)
-        atomicAdd(&ctl[KNN_CTL_RECORDS], total);
-    if (lane == 0 && (dropped != 0u || total > 16384u))
-        ctl[KNN_CTL_FALLBACK] = 1u;  // records were lost or the filter is useless here
+    if (lane == 0)
+        counts[list] = cnt;
 }
 
 // Sample pass: the same MFMA stream over every `stride`-th reference tile, keeping only the
@@ -621,6 +541,8 @@ __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restr
             return e_;                   \
     } while (0)
 
+static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB, split evenly over the waves
+static const unsigned kMaxLists = 1u << 16;
 static const unsigned kSampleBlocks = 512;           // most blocks the sample pass uses (x 4 waves)
 static const float kAmaxLimit = 1024.0f;           // queries far outside the references' box
 
@@ -633,6 +555,8 @@ void knn_filter_free(FilterState &st)
     (void)hipFree(st.qry_norms);
     (void)hipFree(st.thr);
     (void)hipFree(st.ctl);
+    (void)hipFree(st.records);
+    (void)hipFree(st.counts);
     (void)hipFree(st.umin);
     (void)hipFree(st.qpart);
     st = FilterState();
@@ -737,6 +661,12 @@ static hipError_t ensure_workspace(FilterState &st, int m)
 {
     if (!st.ctl)
         FTRY(hipMalloc((void **)&st.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
+    if (!st.records) {
+        FTRY(hipMalloc((void **)&st.records, (size_t)kRecordCapacity * sizeof(u64)));
+        st.rec_cap = kRecordCapacity;
+    }
+    if (!st.counts)
+        FTRY(hipMalloc((void **)&st.counts, (size_t)kMaxLists * sizeof(unsigned)));
     if (m > st.m_cap) {
         (void)hipFree(st.umin);
         st.umin = nullptr;
@@ -783,6 +713,12 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     if (waves > st.ntiles)
         waves = st.ntiles;
     unsigned gx = (unsigned)((waves + 3) / 4);
+    while ((size_t)gx * 4 * gy > kMaxLists && gx > 1)
+        gx = (gx + 1) / 2;
+    if ((size_t)gx * 4 * gy > kMaxLists)
+        return hipErrorInvalidValue;
+    st.nlists = gx * 4 * gy;
+    st.slice = st.rec_cap / st.nlists;
 
     // 1. sample pass over every stride-th tile (about 1/16 of the shard) -> per-query minima
     long long stride = st.ntiles / 2048;
@@ -804,7 +740,7 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     // 2. thresholds
     hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(256), 0, s, st.umin,
                        (int)sb, st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
-                       st.thr, st.ctl, st.qpart, (m_padded + 255) / 256);
+                       st.thr, st.ctl, st.qpart, (m_padded + 255) / 256, st.counts, st.nlists);
     FTRY(hipGetLastError());
 
     // 3. the filter proper (timed: the dominant kernel)
@@ -812,7 +748,7 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
         FTRY(hipEventRecord(st.ev_begin, s));
     hipLaunchKernelGGL((knn_filter_kernel<KT, QT>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                        (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, st.thr, qtiles,
-                       st.ntiles, st.q_src, st.r_src, st.k, st.n, st.base, st.keys, st.ctl);
+                       st.ntiles, st.records, st.counts, st.ctl, st.slice);
     FTRY(hipGetLastError());
     if (st.ev_end)
         FTRY(hipEventRecord(st.ev_end, s));
@@ -826,10 +762,6 @@ hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float 
     FTRY(prep_queries(st, m, q, s));
     st.ev_begin = ev_begin;
     st.ev_end = ev_end;
-    st.q_src = q;
-    st.r_src = r;
-    st.base = base;
-    st.keys = keys;
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {
     case 1:
@@ -849,6 +781,8 @@ hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float 
     case 4: FTRY((launch_filter<4, 4>(st, m, num_cu, s))); break;
     default: FTRY((launch_filter<8, 2>(st, m, num_cu, s))); break;
     }
+    // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
+    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, st.records, st.counts, st.nlists, st.slice, st.ctl, keys, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
     return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, st.ctl + KNN_CTL_FALLBACK, s);
 }
