@@ -90,34 +90,56 @@ def main():
     q_d = torch.empty(m * k, dtype=torch.float32, device=dev)
     pkg.synth_fill_device(r_d.data_ptr(), n_local * k, 1001, first=lo * k, device=local_rank, stream=stream)
     pkg.synth_fill_device(q_d.data_ptr(), m * k, 1000, device=local_rank, stream=stream)
-    keys = torch.empty(m, dtype=torch.int64, device=dev)
-    out = torch.empty(m, dtype=torch.int32, device=dev)
+    # two key/result buffers: with N > 1 the all-reduce of step i overlaps the scan of step i+1
+    keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(2)]
+    outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
     t0 = time.perf_counter()
     index = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo,
                          refs_on_device=True, stream=stream)
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) * 1e3
+    pending = [None, None]   # in-flight all-reduce of each buffer
 
-    def step():
-        pkg.keys_init(keys.data_ptr(), m, device=local_rank, stream=stream)
-        index.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=stream)
+    def finish(b):
+        """Complete the step that used buffer b: wait for its all-reduce (stream-side), unpack."""
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+            pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank, stream=stream)
+
+    def step(i):
+        """One pass of the hot path: m queries against the resident shard -> int32 indices.  Every
+        step is complete (init, scan, reduce, unpack); with N > 1 its reduce + unpack are issued
+        one step late so the collective's latency hides behind the next scan."""
+        b = i & 1
+        finish(b)                      # buffer b was last used by step i-2
+        pkg.keys_init(keys[b].data_ptr(), m, device=local_rank, stream=stream)
+        index.query_keys(m, q_d.data_ptr(), keys[b].data_ptr(), stream=stream)
         if dist is not None:
             # keys < 2^63 (distance bits of a non-negative float): int64 MIN == unsigned MIN
-            dist.all_reduce(keys, op=dist.ReduceOp.MIN)
-        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), device=local_rank, stream=stream)
+            pending[b] = dist.all_reduce(keys[b], op=dist.ReduceOp.MIN, async_op=True)
+            finish(b ^ 1)              # step i-1: its all-reduce ran beside this step's scan
+        else:
+            pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank, stream=stream)
+
+    def drain():
+        finish(0)
+        finish(1)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    drain()
     fence()
     index.timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     launches, kern_ms = index.timing_read()
@@ -129,7 +151,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     qps = m * args.steps / elapsed
     stats = index.last_stats()
-    result_idx = out.cpu().numpy()
+    result_idx = outs[(args.steps - 1) & 1].cpu().numpy()
 
     if rank == 0:
         kern_avg_ms = kern_ms / max(launches, 1)

@@ -127,8 +127,8 @@ int knn_set_option(const char *name, long long value)
         return KNN_OK;
     }
     if (!strcmp(name, "filter_qt")) {
-        if (value != 0 && value != 8 && value != 16 && value != 32)
-            return fail(KNN_EINVAL, "knn_set_option: filter_qt must be 0, 8, 16 or 32");
+        if (value != 0 && value != 2 && value != 8 && value != 16 && value != 32)
+            return fail(KNN_EINVAL, "knn_set_option: filter_qt must be 0, 2, 8, 16 or 32");
         g_opt_filter_qt = value;
         return KNN_OK;
     }
@@ -263,7 +263,7 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
         ev = &idx->events[idx->events_used++];
     }
     const long long path = g_opt_path;
-    const bool use_filter = idx->filter.usable && (path == 2 || (path == 0 && m >= 128 && idx->n >= 65536));
+    const bool use_filter = idx->filter.usable && (path == 2 || (path == 0 && m >= 5 && idx->n >= 65536));
     if (use_filter) {
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;

@@ -709,7 +709,9 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     const int m_padded = qtiles * 32;
     const unsigned gy = (unsigned)((qtiles + QT - 1) / QT);
 
-    long long waves = (long long)num_cu * 8;  // filter grid: 2 waves per SIMD
+    // filter grid: 2 waves per SIMD when the wave's registers are full of query fragments,
+    // more when they are not (small batches are HBM-latency-bound)
+    long long waves = (long long)num_cu * (QT * KT >= 16 ? 8 : 16);
     if (waves > st.ntiles)
         waves = st.ntiles;
     unsigned gx = (unsigned)((waves + 3) / 4);
@@ -765,7 +767,9 @@ hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float 
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {
     case 1:
-        if (qtiles <= 8 || st.force_qt == 8)
+        if ((qtiles <= 2 && st.force_qt == 0) || st.force_qt == 2)
+            FTRY((launch_filter<1, 2>(st, m, num_cu, s)));
+        else if (qtiles <= 8 || st.force_qt == 8)
             FTRY((launch_filter<1, 8>(st, m, num_cu, s)));
         else if (qtiles <= 16 || st.force_qt == 16)
             FTRY((launch_filter<1, 16>(st, m, num_cu, s)));
