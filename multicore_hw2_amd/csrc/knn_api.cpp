@@ -146,8 +146,27 @@ long long knn_get_option(const char *name)
     return -1;
 }
 
+}  // extern "C"
+
+namespace {
+// build_filter: 1 build the MFMA filter layouts, 0 do not, -1 library policy
+int index_create_impl(knn_index **out, int device, int k, long long n_local, const float *refs,
+                      int refs_on_device, long long base_index, void *stream, int build_filter);
+}
+
+extern "C" {
+
 int knn_index_create(knn_index **out, int device, int k, long long n_local, const float *refs,
                      int refs_on_device, long long base_index, void *stream)
+{
+    return index_create_impl(out, device, k, n_local, refs, refs_on_device, base_index, stream, -1);
+}
+
+}  // extern "C"
+
+namespace {
+int index_create_impl(knn_index **out, int device, int k, long long n_local, const float *refs,
+                      int refs_on_device, long long base_index, void *stream, int build_filter)
 {
     if (!out)
         return fail(KNN_EINVAL, "knn_index_create: null out");
@@ -199,7 +218,9 @@ int knn_index_create(knn_index **out, int device, int k, long long n_local, cons
         }
     }
     // MFMA filter layouts (skipped for small shards and when the exact path is forced)
-    if (n_local > 0 && g_opt_path != 1 && (g_opt_path == 2 || n_local >= 65536)) {
+    if (build_filter < 0)
+        build_filter = g_opt_path == 2 || n_local >= 65536;
+    if (n_local > 0 && g_opt_path != 1 && build_filter) {
         hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s);
         if (e != hipSuccess) {
             knn_index_destroy(idx);
@@ -209,6 +230,9 @@ int knn_index_create(knn_index **out, int device, int k, long long n_local, cons
     *out = idx;
     return KNN_OK;
 }
+}  // namespace
+
+extern "C" {
 
 void knn_index_destroy(knn_index *idx)
 {
@@ -451,8 +475,15 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         if (hi <= lo)
             return;
         knn_index *idx = nullptr;
-        int rc = knn_index_create(&idx, (int)(g % ndev), k, hi - lo,
-                                  referencePoints + (size_t)lo * (size_t)k, 0, lo, nullptr);
+        // One-shot call: the filter layouts cost two extra passes over the shard plus a few
+        // allocations, so build them only where that is cheaper than the exact VALU scan
+        // (rates measured on MI355X: 58e12 exact lane-ops/s, ~3.4e-14 s per filtered pair).
+        const double pairs = (double)m * (double)(hi - lo);
+        const double t_exact = (3.0 * k + 3.0) * pairs / 58e12;
+        const double t_filter = 3e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * pairs + 1e-4;
+        const int want_filter = g_opt_path == 2 || (g_opt_path == 0 && m >= 5 && t_filter < t_exact);
+        int rc = index_create_impl(&idx, (int)(g % ndev), k, hi - lo,
+                                   referencePoints + (size_t)lo * (size_t)k, 0, lo, nullptr, want_filter);
         if (rc == KNN_OK)
             rc = query_keys_host(idx, m, searchPoints, keys.data());
         knn_index_destroy(idx);

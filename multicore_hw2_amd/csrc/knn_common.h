@@ -66,6 +66,7 @@ struct FilterState {
     unsigned *counts = nullptr;// device [nlists]: records each wave produced (may exceed slice)
     unsigned nlists = 0, slice = 0;
     float *umin = nullptr;     // device [sample blocks][m_padded]: per-block minima of the sample pass
+    size_t umin_cap = 0;       // floats allocated in umin
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // optional: bracket the filter kernel
     unsigned *qpart = nullptr; // device [3 * query blocks]: {max |coord|, max norm, #bad} per block
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)

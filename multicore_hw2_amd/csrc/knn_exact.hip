@@ -208,7 +208,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
     if (gate && *gate == 0u)
         return;
     const int k = K > 0 ? K : krt;
-    const int q0 = blockIdx.y * QT;
+    const int nqt = (m + QT - 1) / QT;
+    // grid.y may be smaller than the number of query tiles (the launch caps the grid so that a
+    // gated no-op launch stays cheap): stride over them
+    for (int qt = blockIdx.y; qt < nqt; qt += gridDim.y) {
+    const int q0 = qt * QT;
     float best[QT];
     unsigned bidx[QT];
 #pragma unroll
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
         if (lane == 0 && q0 + t < m && key < kKeyInit && key < keys[q0 + t])
             key_atomic_min(&keys[q0 + t], key);
     }
+    }  // query tiles
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,7 +334,25 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                         acc = acc + sq;
                     }
                 } else {
-                    for (int d = 0; d < k; ++d) {
+                    // run-time k: chunks of 16 with all 32 loads of a chunk in flight together
+                    // (a plain scalar loop is one dependent round trip per dimension); the
+                    // accumulation order stays d = 0..k-1
+                    int d = 0;
+                    for (; d + 16 <= k; d += 16) {
+                        float qv[16], rv[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            qv[j] = q[d + j];
+                            rv[j] = r[d + j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float diff = qv[j] - rv[j];
+                            const float sq = diff * diff;
+                            acc = acc + sq;
+                        }
+                    }
+                    for (; d < k; ++d) {
                         const float diff = q[d] - r[d];
                         const float sq = diff * diff;
                         acc = acc + sq;
@@ -435,9 +458,13 @@ hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float
                           u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
 {
     constexpr int QT = 4;
-    const unsigned qt = (unsigned)knn_divup(m, QT);
+    unsigned qt = (unsigned)knn_divup(m, QT);
+    if (qt > 64u)
+        qt = 64u;  // the kernel strides over the remaining query tiles
     long long blocks = (n + KNN_BLOCK - 1) / KNN_BLOCK;
-    const long long cap = (long long)num_cu * 8;
+    long long cap = (long long)num_cu * 8 / qt;
+    if (cap < 4)
+        cap = 4;
     if (blocks > cap)
         blocks = cap;
     if (blocks < 1)

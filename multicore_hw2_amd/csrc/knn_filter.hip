@@ -51,6 +51,20 @@ static inline float ord2f_host(unsigned o)
     return f;
 }
 
+// Monotone accumulators on a few hot words: a plain (possibly stale) read first.  The target only
+// moves one way, so a stale value can cost a spare atomic, never lose an update; without the
+// guard half a million atomics on one word serialise at ~88/us (6 ms on a 2^24-row shard).
+__device__ __forceinline__ void guarded_atomic_max(unsigned *p, unsigned v)
+{
+    if (v > __builtin_nontemporal_load(p))
+        atomicMax(p, v);
+}
+__device__ __forceinline__ void guarded_atomic_min(unsigned *p, unsigned v)
+{
+    if (v < __builtin_nontemporal_load(p))
+        atomicMin(p, v);
+}
+
 __device__ __forceinline__ float wave_max_f(float v)
 {
 #pragma unroll
@@ -83,9 +97,44 @@ __global__ __launch_bounds__(256) void knn_ref_stats_kernel(const float *__restr
         hi = fmaxf(hi, v);
     }
     if (lo <= hi) {
-        atomicMin(&stats[d], f2ord(lo));
-        atomicMax(&stats[k + d], f2ord(hi));
+        guarded_atomic_min(&stats[d], f2ord(lo));
+        guarded_atomic_max(&stats[k + d], f2ord(hi));
     }
+    if (bad)
+        atomicAdd(&stats[2 * k], bad);
+}
+
+// Same, 16 bytes per lane per step (k % 4 == 0, 16-byte aligned rows): every lane keeps four fixed
+// dimensions, four independent loads in flight.
+__global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restrict__ R4, long long count4,
+                                                             int k, unsigned *__restrict__ stats)
+{
+    const int k4 = k >> 2;
+    const long long threads = (long long)gridDim.x * blockDim.x;
+    const long long stride = threads / k4 * k4;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid >= stride)
+        return;
+    const int d0 = (int)(gtid % k4) * 4;
+    f4v lo = {INFINITY, INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned bad = 0;
+#pragma unroll 4
+    for (long long e = gtid; e < count4; e += stride) {
+        const f4v v = __builtin_nontemporal_load(&R4[e]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!(fabsf(v[c]) < INFINITY))
+                ++bad;
+            lo[c] = fminf(lo[c], v[c]);
+            hi[c] = fmaxf(hi[c], v[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (lo[c] <= hi[c]) {
+            guarded_atomic_min(&stats[d0 + c], f2ord(lo[c]));
+            guarded_atomic_max(&stats[k + d0 + c], f2ord(hi[c]));
+        }
     if (bad)
         atomicAdd(&stats[2 * k], bad);
 }
@@ -172,8 +221,73 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
         return;
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&out[0], __float_as_uint(vmax));  // non-negative floats order like uints
-        atomicMax(&out[1], __float_as_uint(nrm));
+        guarded_atomic_max(&out[0], __float_as_uint(vmax));  // non-negative floats order like uints
+        guarded_atomic_max(&out[1], __float_as_uint(nrm));
+    }
+    if (bad)
+        atomicAdd(&out[2], bad);
+}
+
+// k = 16 references, 16-byte aligned: the block reads its 256 rows (16 KiB) as fully coalesced
+// 16-byte chunks into LDS (XOR-swizzled so the row reads below are bank-conflict free), then
+// every thread converts its own row.  Same outputs as knn_frag_kernel(scale_out = 1).
+__global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__ X4, long long rows,
+                                                         long long rows_padded,
+                                                         const float *__restrict__ center, float sigma,
+                                                         h8 *__restrict__ frag, float *__restrict__ norms,
+                                                         unsigned *__restrict__ out)
+{
+    __shared__ f4v s_x[256 * 4];
+    const long long row0 = (long long)blockIdx.x * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = threadIdx.x + j * 256;       // chunk index inside the block's 1024 chunks
+        const int rr = c >> 2, cc = c & 3;
+        f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row0 + rr < rows)
+            v = __builtin_nontemporal_load(&X4[(size_t)row0 * 4 + c]);
+        s_x[rr * 4 + (cc ^ ((rr >> 2) & 3))] = v;
+    }
+    __syncthreads();
+    const long long i = row0 + threadIdx.x;
+    float vmax = 0.0f, nrm = 0.0f;
+    unsigned bad = 0;
+    if (i < rows_padded) {
+        const long long tile = i >> 5;
+        const int r = (int)(i & 31);
+        const bool real = i < rows;
+        const int sw = ((int)threadIdx.x >> 2) & 3;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            h8 v;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int cc = half * 2 + g;
+                const f4v x = s_x[threadIdx.x * 4 + (cc ^ sw)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = cc * 4 + j;
+                    const float sc = real ? (x[j] - center[d]) * sigma : 0.0f;
+                    const _Float16 hval = (_Float16)sc;
+                    const float back = (float)hval;
+                    if (!(fabsf(back) < INFINITY))
+                        ++bad;
+                    vmax = fmaxf(vmax, fabsf(back));
+                    nrm = nrm + back * back;
+                    v[g * 4 + j] = hval;
+                }
+            }
+            frag[(size_t)tile * 64 + half * 32 + r] = v;
+        }
+        norms[i] = real ? nrm : INFINITY;
+        if (!real)
+            nrm = 0.0f;
+    }
+    vmax = wave_max_f(vmax);
+    nrm = wave_max_f(nrm);
+    if ((threadIdx.x & 63) == 0) {
+        guarded_atomic_max(&out[0], __float_as_uint(vmax));
+        guarded_atomic_max(&out[1], __float_as_uint(nrm));
     }
     if (bad)
         atomicAdd(&out[2], bad);
@@ -583,7 +697,11 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     hipError_t e = hipMemcpyAsync(dstats, hstats.data(), hstats.size() * sizeof(unsigned),
                                   hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(knn_ref_stats_kernel, dim3(2048), dim3(256), 0, s, r, n * (long long)k, k, dstats);
+        if (k % 4 == 0 && ((uintptr_t)r & 15u) == 0)
+            hipLaunchKernelGGL(knn_ref_stats4_kernel, dim3(2048), dim3(256), 0, s, (const f4v *)r,
+                               n * (long long)k / 4, k, dstats);
+        else
+            hipLaunchKernelGGL(knn_ref_stats_kernel, dim3(2048), dim3(256), 0, s, r, n * (long long)k, k, dstats);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -633,9 +751,14 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     unsigned hout[4] = {0, 0, 0, 0};
     if (e == hipSuccess) {
         const long long rows_padded = ntiles * 32;
-        hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
-                           n, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
-                           st.ref_norms, dout, 0, nullptr);
+        if (k == 16 && ((uintptr_t)r & 15u) == 0)
+            hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s,
+                               (const f4v *)r, n, rows_padded, st.center, sigma, (h8 *)st.ref_frags,
+                               st.ref_norms, dout);
+        else
+            hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
+                               n, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
+                               st.ref_norms, dout, 0, nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -667,11 +790,6 @@ static hipError_t ensure_workspace(FilterState &st, int m)
     }
     if (!st.counts)
         FTRY(hipMalloc((void **)&st.counts, (size_t)kMaxLists * sizeof(unsigned)));
-    if (m > st.m_cap) {
-        (void)hipFree(st.umin);
-        st.umin = nullptr;
-        FTRY(hipMalloc((void **)&st.umin, (size_t)kSampleBlocks * ((size_t)(m + 31) / 32 * 32) * sizeof(float)));
-    }
     if (m > st.m_cap) {
         (void)hipFree(st.qry_frags);
         (void)hipFree(st.qry_norms);
@@ -715,6 +833,13 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     if (waves > st.ntiles)
         waves = st.ntiles;
     unsigned gx = (unsigned)((waves + 3) / 4);
+    // many query groups (large m): split the references over fewer waves so every wave still
+    // streams a long run of tiles per load of its query fragments
+    const unsigned target_blocks = (unsigned)num_cu * 8;
+    if (gy > 1 && (size_t)gx * gy > target_blocks)
+        gx = (target_blocks + gy - 1) / gy;
+    if (gx < 1)
+        gx = 1;
     while ((size_t)gx * 4 * gy > kMaxLists && gx > 1)
         gx = (gx + 1) / 2;
     if ((size_t)gx * 4 * gy > kMaxLists)
@@ -723,7 +848,7 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     st.slice = st.rec_cap / st.nlists;
 
     // 1. sample pass over every stride-th tile (about 1/16 of the shard) -> per-query minima
-    long long stride = st.ntiles / 2048;
+    long long stride = st.ntiles / 256;
     if (stride < 1)
         stride = 1;
     if (stride > 16)
@@ -732,8 +857,22 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     unsigned sb = (unsigned)num_cu * 2;  // 2 waves per SIMD, like the main pass
     if (sb > kSampleBlocks)
         sb = kSampleBlocks;
+    if (gy > 1 && (size_t)sb * gy > target_blocks)
+        sb = (target_blocks + gy - 1) / gy;
     if ((long long)sb * 4 > ns)
         sb = (unsigned)((ns + 3) / 4);
+    if (sb < 1)
+        sb = 1;
+    {   // per-block minima buffer, grown on demand
+        const size_t need = (size_t)sb * (size_t)m_padded;
+        if (need > st.umin_cap) {
+            (void)hipFree(st.umin);
+            st.umin = nullptr;
+            st.umin_cap = 0;
+            FTRY(hipMalloc((void **)&st.umin, need * sizeof(float)));
+            st.umin_cap = need;
+        }
+    }
     hipLaunchKernelGGL((knn_filter_sample_kernel<KT, QT>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
                        (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, qtiles, st.ntiles,
                        stride, st.umin, m_padded, st.ctl);

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Run and parity-check the BASELINE.json configs that are not the default bench line
+(C1, C2, C4 on one GPU, C5): timing of the device-resident step + oracle check on a query subset."""
+import subprocess
+import sys
+import time
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import multicore_hw2_amd as pkg          # noqa: E402
+from tests.oracle_lib import Oracle      # noqa: E402
+
+
+def run(o, name, k, m, n, check_q, steps=5):
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
+    q_d = torch.empty(m * k, dtype=torch.float32, device=dev)
+    pkg.synth_fill_device(r_d.data_ptr(), n * k, 1001, stream=stream)
+    pkg.synth_fill_device(q_d.data_ptr(), m * k, 1000, stream=stream)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    t0 = time.perf_counter()
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True, stream=stream)
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - t0
+
+    def step():
+        pkg.keys_init(keys.data_ptr(), m, stream=stream)
+        ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=stream)
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), stream=stream)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ix.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nl, kms = ix.timing_read()
+    st = ix.last_stats()
+    R, Q = r_d.cpu().numpy(), q_d.cpu().numpy()
+    sel = np.random.default_rng(0).choice(m, check_q, replace=False)
+    want = o.v0(k, Q.reshape(m, k)[sel], R)
+    ok = bool((out.cpu().numpy()[sel] == want).all())
+    line = (f"{name}: k={k} m={m} n={n}: {dt * 1e3:.3f} ms/step, {m / dt:.0f} queries/s, dominant kernel "
+            f"{kms / nl:.3f} ms, path={'filter' if st[0] == 2 else 'exact'}, records={st[1]}, fallback={st[2]}, "
+            f"index build {tb * 1e3:.1f} ms, bit-exact on {check_q} sampled queries: {ok}")
+    if st[0] == 2:
+        tf = 2.0 * k * m * n / (kms / nl * 1e-3) / 1e12
+        line += f", filter MFMA {tf:.0f} TFLOP/s = {tf / 2500 * 100:.1f}% of 2.5 PF dense f16"
+    print(line, flush=True)
+    ix.close()
+    assert ok
+
+
+if __name__ == "__main__":
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
+    which = sys.argv[1:] or ["C1", "C2", "C5", "C4"]
+    if "C1" in which:
+        run(o, "C1", 3, 1, 1024, 1)
+    if "C2" in which:
+        run(o, "C2", 3, 1024, 1 << 20, 1024)
+    if "C5" in which:
+        run(o, "C5", 128, 65536, 65536, 2048)
+    if "C4" in which:
+        run(o, "C4 (one GPU)", 16, 1024, 1 << 27, 16)
