@@ -318,3 +318,23 @@ def test_headline_shape_properties(oracle, path):
     r2[torch.from_numpy(pos).to(dev)] = q_d.view(m, k)
     planted = run(1)
     np.testing.assert_array_equal(planted, pos.astype(np.int32))
+
+
+def test_ta_style_harness_through_the_cpp_function_pointer_boundary(tmp_path, oracle):
+    """a TA-style C++ harness (tests/harness/ta_harness.cpp, own code) selects the
+    operator through CALLBACKn macros / a function pointer exactly like the reference's main.cu
+    and must report 0 errors against its v0 baseline on all 8 samples; the indices it writes are
+    the reference's results.csv index lines."""
+    import subprocess
+    hdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness")
+    subprocess.check_call(["make", "-C", hdir], stdout=subprocess.DEVNULL)
+    csv = tmp_path / "results_indices.csv"
+    r = subprocess.run([os.path.join(hdir, "ta_harness"), str(csv)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("errors/total w.r.t. baseline: 0/") == 16
+    assert "Callback10, 16, 1024, 65536," in r.stdout
+    gold = read_golden_indices()
+    lines = csv.read_text().splitlines()
+    assert len(lines) == len(gold)
+    for line, g in zip(lines, gold):
+        assert [int(t) for t in line.split(",") if t] == g.tolist()
