@@ -1,0 +1,185 @@
+// filter_probe.hip — experiment bench for the filter's hot loop: variants of the per-tile
+// epilogue on the production data path (same fragment layout, loads and pipelining as
+// knn_filter_kernel), timed on synthetic data.  Results are NOT checked: this tool only prices
+// instruction mixes.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o filter_probe filter_probe.hip
+#include "../multicore_hw2_amd/csrc/knn_filter.hip"
+#include "../multicore_hw2_amd/csrc/knn_exact.hip"
+
+// VAR 0: production epilogue (8 min3 incl. thr, cmp, branch)
+// VAR 1: running minimum only (8 min3, no cmp/branch)
+// VAR 2: half tree (4 min3 + cmp + branch)                      [slope check, wrong results]
+// VAR 3: production + s_setprio(1) around the MFMA issue
+// VAR 4: xor/or accumulate, one cmp + branch per 4 tiles
+// VAR 5: no epilogue at all (MFMA stream only, result kept alive per tile)
+// VAR 6: MFMA accumulate chains (4 rotating accumulators, srcC = vdst), nothing else per tile
+// VAR 7: VAR 6 + an 8-op min3 tree per tile on registers the MFMAs do not write (pure issue contention)
+// VAR 8: VAR 6 with C taken from the fixed c tile (srcC != vdst), results folded once per ref tile
+template <int VAR>
+__global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__restrict__ rf, const float *__restrict__ rn,
+                                                                 const h8 *__restrict__ qfg, const float *__restrict__ thrg,
+                                                                 long long ntiles, float *__restrict__ sink)
+{
+    constexpr int KT = 1, QT = 32;
+    __shared__ float s_thr[QT * 32];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
+        s_thr[i] = thrg[i];
+    __syncthreads();
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long t0 = ntiles * wave / nwaves, t1 = ntiles * (wave + 1) / nwaves;
+    h8 qf[QT][KT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+        qf[t][0] = qfg[(size_t)t * 64 + lane];
+    float um = 3e38f;
+    unsigned hits = 0, acc = 0;
+    h8 a[KT];
+    f16v c;
+    load_ref_tile<KT>(rf, rn, t0, lane, a, c);
+    for (long long tile = t0; tile < t1; ++tile) {
+        h8 an[KT];
+        f16v cn;
+        load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);
+        if (VAR >= 6) {
+            f16v e[4];
+            e[0] = c; e[1] = c; e[2] = c; e[3] = c;
+            f16v y = cn;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                if (VAR == 8)
+                    e[t & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t][0], c, 0, 0, 0);
+                else
+                    e[t & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t][0], e[t & 3], 0, 0, 0);
+                if (VAR == 7) {
+                    asm volatile("" : "+v"(y));
+                    const float m0 = min3f(y[0], y[1], y[2]);
+                    const float m1 = min3f(y[3], y[4], y[5]);
+                    const float m2 = min3f(y[6], y[7], y[8]);
+                    const float m3 = min3f(y[9], y[10], y[11]);
+                    const float m4 = min3f(y[12], y[13], y[14]);
+                    const float m5 = min3f(m0, m1, m2);
+                    const float m6 = min3f(m3, m4, y[15]);
+                    um = min3f(m5, m6, um);
+                }
+                if (VAR == 8 && (t & 3) == 3) {
+                    asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+                }
+            }
+            um = fminf(um, e[0][0] + e[1][1] + e[2][2] + e[3][3]);
+            a[0] = an[0];
+            c = cn;
+            continue;
+        }
+        f16v d[2];
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0][0], c, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float th = s_thr[t * 32 + (lane & 31)];
+            if (t + 1 < QT) {
+                if (VAR == 3) __builtin_amdgcn_s_setprio(1);
+                d[(t + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 1][0], c, 0, 0, 0);
+                if (VAR == 3) __builtin_amdgcn_s_setprio(0);
+            }
+            const f16v &x = d[t & 1];
+            if (VAR == 5) {
+                asm volatile("" ::"v"(x));
+                continue;
+            }
+            const float m0 = min3f(x[0], x[1], x[2]);
+            const float m1 = min3f(x[3], x[4], x[5]);
+            if (VAR == 2) {
+                const float m2 = min3f(x[6], x[7], x[8]);
+                const float mn = min3f(min3f(m0, m1, m2), x[15], th);
+                if (__builtin_expect(mn < th, 0)) { ++hits; um = mn; }
+                continue;
+            }
+            const float m2 = min3f(x[6], x[7], x[8]);
+            const float m3 = min3f(x[9], x[10], x[11]);
+            const float m4 = min3f(x[12], x[13], x[14]);
+            const float m5 = min3f(m0, m1, m2);
+            const float m6 = min3f(m3, m4, x[15]);
+            if (VAR == 1) {
+                um = min3f(m5, m6, um);
+            } else if (VAR == 4) {
+                const float mn = min3f(m5, m6, th);
+                acc |= __float_as_uint(mn) ^ __float_as_uint(th);
+                if ((t & 3) == 3) {
+                    if (__builtin_expect(__ballot(acc != 0u) != 0ull, 0)) { ++hits; um = mn; }
+                    acc = 0u;
+                }
+            } else {
+                const float mn = min3f(m5, m6, th);
+                const bool hit = mn < th;
+                if (__builtin_expect(__ballot(hit) != 0ull, 0)) { ++hits; um = mn; }
+            }
+        }
+        a[0] = an[0];
+        c = cn;
+    }
+    if (um == 1.2345f || hits == 0xFFFFFFFFu)
+        sink[threadIdx.x] = um + hits;
+}
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int VAR>
+static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, const float *thr, long long ntiles, float *sink)
+{
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHK(hipEventRecord(a));
+        hipLaunchKernelGGL(probe_kernel<VAR>, dim3(512), dim3(FILTER_BLOCK), 0, 0, rf, rn, qf, thr, ntiles, sink);
+        CHK(hipEventRecord(b));
+        CHK(hipEventSynchronize(b));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    const double tiles = (double)ntiles * 32;
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s  %6.1f ns per tile per SIMD\n", name, best, tiles * 32768 / (best * 1e-3) / 1e12,
+           best * 1e6 / (tiles / 1024.0));
+    return 0;
+}
+
+int main()
+{
+    const long long n = 1ll << 24, ntiles = n / 32;
+    float *refs, *rn, *thr, *sink, *q;
+    h8 *rf, *qf;
+    CHK(hipMalloc(&refs, n * 16 * 4));
+    CHK(hipMalloc(&q, 1024 * 16 * 4));
+    CHK(hipMalloc(&rf, ntiles * 1024));
+    CHK(hipMalloc(&qf, 32 * 1024));
+    CHK(hipMalloc(&rn, n * 4));
+    CHK(hipMalloc(&thr, 1024 * 4));
+    CHK(hipMalloc(&sink, 4096));
+    CHK(knn_synth_fill_launch(refs, n * 16, 1001, 0, 0));
+    CHK(knn_synth_fill_launch(q, 1024 * 16, 1000, 0, 0));
+    float *center;
+    unsigned *out;
+    CHK(hipMalloc(&center, 64));
+    CHK(hipMalloc(&out, 64));
+    CHK(hipMemset(out, 0, 64));
+    std::vector<float> hc(16, 0.5f), hthr(1024, -5.0f);   // thresholds no score can reach: no hits
+    CHK(hipMemcpy(center, hc.data(), 64, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(thr, hthr.data(), 4096, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (const f4v *)refs, n, n, center, 2.0f, rf, rn, out);
+    hipLaunchKernelGGL(knn_frag_kernel, dim3(4), dim3(256), 0, 0, q, 1024ll, 1024ll, 16, 1, center, 2.0f, -2.0f, 0.0f, qf, sink + 0, out, 0, (unsigned *)nullptr);
+    CHK(hipDeviceSynchronize());
+    for (int round = 0; round < 2; ++round) {
+        if (run<0>("0 production (8 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<1>("1 running min (8 min3)", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<2>("2 half tree (4 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<3>("3 production + setprio around MFMA", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<4>("4 xor/or accumulate, branch per 4 tiles", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<5>("5 MFMA stream only", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<6>("6 MFMA accumulate chains only", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<7>("7 MFMA chains + independent 8 min3", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<8>("8 MFMA srcC=c, folded per 4 tiles", rf, rn, qf, thr, ntiles, sink)) return 1;
+    }
+    return 0;
+}
