@@ -353,7 +353,14 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
         DeviceGuard guard(idx->device);
         unsigned ctl[KNN_CTL_WORDS];
         HIP_TRY(hipMemcpy(ctl, idx->filter.ctl, sizeof ctl, hipMemcpyDeviceToHost));
-        idx->stats[1] = ctl[KNN_CTL_RECORDS];
+        std::vector<unsigned> counts(idx->filter.nlists);
+        if (!counts.empty())
+            HIP_TRY(hipMemcpy(counts.data(), idx->filter.counts, counts.size() * sizeof(unsigned),
+                              hipMemcpyDeviceToHost));
+        long long records = 0;
+        for (unsigned c : counts)
+            records += c < idx->filter.slice ? c : idx->filter.slice;
+        idx->stats[1] = records;
         idx->stats[2] = ctl[KNN_CTL_FALLBACK];
     }
     memcpy(stats, idx->stats, sizeof idx->stats);

@@ -297,11 +297,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
     const int k = K > 0 ? K : krt;
     const unsigned want = counts[blockIdx.x];
     const unsigned nrec = min(want, slice);
-    if (threadIdx.x == 0 && want != 0u) {
-        atomicAdd(&ctl[KNN_CTL_RECORDS], nrec);
-        if (want > slice)
-            ctl[KNN_CTL_FALLBACK] = 1u;  // candidates were dropped: the gated exact scan takes over
-    }
+    // (no shared record counter here: 2048 blocks adding to one word cost ~23 us; the host sums
+    // counts[] when statistics are asked for)
+    if (threadIdx.x == 0 && want > slice)
+        ctl[KNN_CTL_FALLBACK] = 1u;  // candidates were dropped: the gated exact scan takes over
     const u64 *__restrict__ list = rec + (size_t)blockIdx.x * slice;
     // 16 consecutive lanes share one record (one query): their keys are min-folded with shuffles
     // and ONE guarded atomic is issued per record (the keys sit on a handful of cache lines; the

@@ -343,9 +343,11 @@ __host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, d
     return nextafterf(tf, INFINITY);                  // the kernel tests S < thr (strict)
 }
 
-// umin: per-block minima of the sample pass, [nblocks][m_padded].  Block = 32 queries x 8
-// parts: each part folds every 8th sample block (coalesced over the 32 queries), LDS folds parts.
-__global__ __launch_bounds__(256) void knn_thr_kernel(const float *__restrict__ umin, int nblocks,
+// umin: per-block minima of the sample pass, [nblocks][m_padded].  Block = 32 queries x 32
+// parts: each part folds every 32nd sample block (coalesced over the 32 queries, all its loads
+// in flight at once), LDS folds the parts.
+#define THR_PARTS 32
+__global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__restrict__ umin, int nblocks,
                                                       const float *__restrict__ qnorm, int m,
                                                       int m_padded, int k, int kt, float sigma,
                                                       float bmax, float nmax, float amax_limit,
@@ -354,21 +356,22 @@ __global__ __launch_bounds__(256) void knn_thr_kernel(const float *__restrict__ 
                                                       const unsigned *__restrict__ qpart, int qblocks,
                                                       unsigned *__restrict__ counts, unsigned nlists)
 {
-    __shared__ float s_part[8][32];
+    __shared__ float s_part[THR_PARTS][32];
     // housekeeping folded in here to save launches: zero the record counters of the filter pass
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nlists; i += gridDim.x * blockDim.x)
         counts[i] = 0u;
     const int ql = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + ql;  // m_padded is a multiple of 32
     float u = INFINITY;
-    for (int b = part; b < nblocks; b += 8)
+#pragma unroll 16
+    for (int b = part; b < nblocks; b += THR_PARTS)
         u = fminf(u, umin[(size_t)b * m_padded + i]);
     s_part[part][ql] = u;
     __syncthreads();
     if (part != 0)
         return;
 #pragma unroll
-    for (int p = 1; p < 8; ++p)
+    for (int p = 1; p < THR_PARTS; ++p)
         u = fminf(u, s_part[p][ql]);
     float amax = 0.0f;
     unsigned qbad = 0u;
@@ -480,7 +483,7 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
 }
 
 template <int KT, int QT>
-__global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_kernel(
+__global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_filter_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
     unsigned *__restrict__ counts, const unsigned *__restrict__ ctl, unsigned slice)
@@ -829,7 +832,7 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
 
     // filter grid: 2 waves per SIMD when the wave's registers are full of query fragments,
     // more when they are not (small batches are HBM-latency-bound)
-    long long waves = (long long)num_cu * (QT * KT >= 16 ? 8 : 16);
+    long long waves = (long long)num_cu * (QT * KT > 16 ? 8 : QT * KT == 16 ? 12 : 16);
     if (waves > st.ntiles)
         waves = st.ntiles;
     unsigned gx = (unsigned)((waves + 3) / 4);
@@ -879,7 +882,7 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
     FTRY(hipGetLastError());
 
     // 2. thresholds
-    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(256), 0, s, st.umin,
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, st.umin,
                        (int)sb, st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
                        st.thr, st.ctl, st.qpart, (m_padded + 255) / 256, st.counts, st.nlists);
     FTRY(hipGetLastError());

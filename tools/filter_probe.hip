@@ -4,6 +4,7 @@
 // instruction mixes.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o filter_probe filter_probe.hip
 #include "../multicore_hw2_amd/csrc/knn_filter.hip"
 #include "../multicore_hw2_amd/csrc/knn_exact.hip"
+#include <algorithm>
 
 // VAR 0: production epilogue (8 min3 incl. thr, cmp, branch)
 // VAR 1: running minimum only (8 min3, no cmp/branch)
@@ -17,9 +18,11 @@
 template <int VAR>
 __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__restrict__ rf, const float *__restrict__ rn,
                                                                  const h8 *__restrict__ qfg, const float *__restrict__ thrg,
-                                                                 long long ntiles, float *__restrict__ sink)
+                                                                 long long ntiles, float *__restrict__ sink,
+                                                                 unsigned long long *__restrict__ stamps)
 {
     constexpr int KT = 1, QT = 32;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     __shared__ float s_thr[QT * 32];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
@@ -37,6 +40,55 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
     h8 a[KT];
     f16v c;
     load_ref_tile<KT>(rf, rn, t0, lane, a, c);
+    if (VAR == 9 || VAR == 10) {   // two reference tiles in flight
+        h8 a1[KT], a2[KT];
+        f16v c1, c2;
+        load_ref_tile<KT>(rf, rn, min(t0 + 1, t1 - 1), lane, a1, c1);
+        for (long long tile = t0; tile < t1; ++tile) {
+            load_ref_tile<KT>(rf, rn, min(tile + 2, t1 - 1), lane, a2, c2);
+            if (VAR == 9) {
+                f16v e[4];
+                e[0] = c; e[1] = c; e[2] = c; e[3] = c;
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    e[t & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t][0], e[t & 3], 0, 0, 0);
+                um = fminf(um, e[0][0] + e[1][1] + e[2][2] + e[3][3]);
+            } else {
+                f16v d[2];
+                d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0][0], c, 0, 0, 0);
+                const float *vthr = s_thr + (lane & 31);
+                float th_next = vthr[0];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const float th = th_next;
+                    asm volatile("" ::: "memory");
+                    if (t + 1 < QT) {
+                        th_next = vthr[(t + 1) * 32];
+                        d[(t + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 1][0], c, 0, 0, 0);
+                    }
+                    const f16v &x = d[t & 1];
+                    const float m0 = min3f(x[0], x[1], x[2]);
+                    const float m1 = min3f(x[3], x[4], x[5]);
+                    const float m2 = min3f(x[6], x[7], x[8]);
+                    const float m3 = min3f(x[9], x[10], x[11]);
+                    const float m4 = min3f(x[12], x[13], x[14]);
+                    const float m5 = min3f(m0, m1, m2);
+                    const float m6 = min3f(m3, m4, x[15]);
+                    const float mn = min3f(m5, m6, th);
+                    if (__builtin_expect(__ballot(mn < th) != 0ull, 0)) { ++hits; um = mn; }
+                }
+            }
+            a[0] = a1[0]; c = c1;
+            a1[0] = a2[0]; c1 = c2;
+        }
+        if (um == 1.2345f || hits == 0xFFFFFFFFu)
+            sink[threadIdx.x] = um + hits;
+        if (lane == 0) {
+            stamps[2 * wave] = __builtin_amdgcn_s_memtime() - c0;
+            stamps[2 * wave + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+        return;
+    }
     for (long long tile = t0; tile < t1; ++tile) {
         h8 an[KT];
         f16v cn;
@@ -119,10 +171,15 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
     }
     if (um == 1.2345f || hits == 0xFFFFFFFFu)
         sink[threadIdx.x] = um + hits;
+    if (lane == 0) {   // diagnostic only: shader cycles and 100 MHz ticks this wave ran
+        stamps[2 * wave] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[2 * wave + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
+static unsigned long long *g_stamps;
 template <int VAR>
 static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, const float *thr, long long ntiles, float *sink)
 {
@@ -132,7 +189,7 @@ static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, co
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         CHK(hipEventRecord(a));
-        hipLaunchKernelGGL(probe_kernel<VAR>, dim3(512), dim3(FILTER_BLOCK), 0, 0, rf, rn, qf, thr, ntiles, sink);
+        hipLaunchKernelGGL(probe_kernel<VAR>, dim3(512), dim3(FILTER_BLOCK), 0, 0, rf, rn, qf, thr, ntiles, sink, g_stamps);
         CHK(hipEventRecord(b));
         CHK(hipEventSynchronize(b));
         float ms;
@@ -140,8 +197,16 @@ static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, co
         if (ms < best) best = ms;
     }
     const double tiles = (double)ntiles * 32;
-    printf("%-44s %8.3f ms  %7.1f TFLOP/s  %6.1f ns per tile per SIMD\n", name, best, tiles * 32768 / (best * 1e-3) / 1e12,
-           best * 1e6 / (tiles / 1024.0));
+    std::vector<unsigned long long> hs(4096);
+    CHK(hipMemcpy(hs.data(), g_stamps, 4096 * 8, hipMemcpyDeviceToHost));
+    std::vector<double> clk;
+    for (int w = 0; w < 2048; ++w)
+        if (hs[2 * w + 1])
+            clk.push_back((double)hs[2 * w] / (double)hs[2 * w + 1] * 0.1);   // GHz
+    std::sort(clk.begin(), clk.end());
+    const double ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s  %6.1f ns = %5.1f cycles per tile per SIMD at the in-kernel clock %.2f GHz\n", name, best,
+           tiles * 32768 / (best * 1e-3) / 1e12, best * 1e6 / (tiles / 1024.0), best * 1e6 / (tiles / 1024.0) * ghz, ghz);
     return 0;
 }
 
@@ -157,6 +222,8 @@ int main()
     CHK(hipMalloc(&rn, n * 4));
     CHK(hipMalloc(&thr, 1024 * 4));
     CHK(hipMalloc(&sink, 4096));
+    CHK(hipMalloc(&g_stamps, 4096 * 8));
+    CHK(hipMemset(g_stamps, 0, 4096 * 8));
     CHK(knn_synth_fill_launch(refs, n * 16, 1001, 0, 0));
     CHK(knn_synth_fill_launch(q, 1024 * 16, 1000, 0, 0));
     float *center;
@@ -180,6 +247,8 @@ int main()
         if (run<6>("6 MFMA accumulate chains only", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<7>("7 MFMA chains + independent 8 min3", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<8>("8 MFMA srcC=c, folded per 4 tiles", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<9>("9 MFMA chains, 2 ref tiles prefetched", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<10>("10 production epilogue, 2 ref tiles prefetched", rf, rn, qf, thr, ntiles, sink)) return 1;
     }
     return 0;
 }

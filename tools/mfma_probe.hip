@@ -27,6 +27,36 @@ __global__ __launch_bounds__(256, WPS) void probe(const h8 *__restrict__ in, flo
     unsigned hits = 0, acc = 0;
     f16v d[2];
     d[0] = c; d[1] = c;
+    if (MODE == 7 || MODE == 8) {   // vdst rotates over 4 tuples, srcC = a fixed VGPR tile (7) or literal zero (8)
+        f16v e[4];
+        e[0] = c; e[1] = c; e[2] = c; e[3] = c;
+        f16v z;
+        for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+        float s = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                e[t & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, q[t], MODE == 7 ? c : z, 0, 0, 0);
+                if ((t & 3) == 3)
+                    asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+            }
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = s + e[0][0] + e[1][1] + e[2][2] + e[3][3];
+        return;
+    }
+    if (MODE == 5 || MODE == 6) {   // pure accumulate chains: 4 (MODE 5) or 2 (MODE 6) rotating accumulators
+        f16v e[4];
+        e[0] = c; e[1] = c; e[2] = c; e[3] = c;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = MODE == 5 ? (t & 3) : (t & 1);
+                e[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, q[t], e[j], 0, 0, 0);
+            }
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = e[0][0] + e[1][1] + e[2][2] + e[3][3];
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         if (MODE != 2)
             d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, q[0], c, 0, 0, 0);
@@ -109,6 +139,14 @@ int main()
     if (run<1, 2>("mfma + min3 tree + cmp", in, out, cus, a, b)) return 1;
     if (run<2, 1>("min3 tree + cmp only", in, out, cus, a, b)) return 1;
     if (run<2, 2>("min3 tree + cmp only", in, out, cus, a, b)) return 1;
+    if (run<5, 1>("mfma chains x4 accumulators", in, out, cus, a, b)) return 1;
+    if (run<5, 2>("mfma chains x4 accumulators", in, out, cus, a, b)) return 1;
+    if (run<6, 1>("mfma chains x2 accumulators", in, out, cus, a, b)) return 1;
+    if (run<6, 2>("mfma chains x2 accumulators", in, out, cus, a, b)) return 1;
+    if (run<7, 1>("mfma srcC = fixed VGPR tile", in, out, cus, a, b)) return 1;
+    if (run<7, 2>("mfma srcC = fixed VGPR tile", in, out, cus, a, b)) return 1;
+    if (run<8, 1>("mfma srcC = 0", in, out, cus, a, b)) return 1;
+    if (run<8, 2>("mfma srcC = 0", in, out, cus, a, b)) return 1;
     if (run<3, 1>("mfma + min3 running min", in, out, cus, a, b)) return 1;
     if (run<3, 2>("mfma + min3 running min", in, out, cus, a, b)) return 1;
     if (run<4, 1>("mfma + min3 + xor/or, cmp/4", in, out, cus, a, b)) return 1;
