@@ -40,6 +40,50 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
     h8 a[KT];
     f16v c;
     load_ref_tile<KT>(rf, rn, t0, lane, a, c);
+    if (VAR == 11) {   // MFMAs issued in pairs: 2 in flight while the previous pair's trees run
+        for (long long tile = t0; tile < t1; ++tile) {
+            h8 an[KT];
+            f16v cn;
+            load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);
+            f16v d[4];
+            d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0][0], c, 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[1][0], c, 0, 0, 0);
+            const float *vthr = s_thr + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < QT; t += 2) {
+                asm volatile("" ::: "memory");
+                const float th0 = vthr[t * 32], th1 = vthr[(t + 1) * 32];
+                const int cur = t & 2, nxt = cur ^ 2;
+                if (t + 2 < QT) {
+                    d[nxt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 2][0], c, 0, 0, 0);
+                    d[nxt + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 3][0], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f16v &x = d[cur + u];
+                    const float th = u ? th1 : th0;
+                    const float m0 = min3f(x[0], x[1], x[2]);
+                    const float m1 = min3f(x[3], x[4], x[5]);
+                    const float m2 = min3f(x[6], x[7], x[8]);
+                    const float m3 = min3f(x[9], x[10], x[11]);
+                    const float m4 = min3f(x[12], x[13], x[14]);
+                    const float m5 = min3f(m0, m1, m2);
+                    const float m6 = min3f(m3, m4, x[15]);
+                    const float mn = min3f(m5, m6, th);
+                    if (__builtin_expect(__ballot(mn < th) != 0ull, 0)) { ++hits; um = mn; }
+                }
+            }
+            a[0] = an[0];
+            c = cn;
+        }
+        if (um == 1.2345f || hits == 0xFFFFFFFFu)
+            sink[threadIdx.x] = um + hits;
+        if (lane == 0) {
+            stamps[2 * wave] = __builtin_amdgcn_s_memtime() - c0;
+            stamps[2 * wave + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+        return;
+    }
     if (VAR == 9 || VAR == 10) {   // two reference tiles in flight
         h8 a1[KT], a2[KT];
         f16v c1, c2;
@@ -247,6 +291,7 @@ int main()
         if (run<6>("6 MFMA accumulate chains only", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<7>("7 MFMA chains + independent 8 min3", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<8>("8 MFMA srcC=c, folded per 4 tiles", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (run<11>("11 production epilogue, MFMAs issued in pairs", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<9>("9 MFMA chains, 2 ref tiles prefetched", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<10>("10 production epilogue, 2 ref tiles prefetched", rf, rn, qf, thr, ntiles, sink)) return 1;
     }
