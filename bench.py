@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact VALU only, 2 force MFMA filter")
     ap.add_argument("--filter-qt", type=int, default=0, help="tuning: query tiles per filter wave (0 auto)")
+    ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
     return ap.parse_args()
@@ -71,6 +72,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # Native libraries (RCCL prints a version banner at communicator creation) write to fd 1:
+    # keep stdout clean for the ONE JSON line by pointing fd 1 at stderr until it is printed.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1 or os.environ.get("KNN_BENCH_FORCE_DIST") == "1":   # the env hook rehearses the N>1 code on 1 GPU
         import torch.distributed as dist
@@ -90,7 +96,10 @@ def main():
     q_d = torch.empty(m * k, dtype=torch.float32, device=dev)
     pkg.synth_fill_device(r_d.data_ptr(), n_local * k, 1001, first=lo * k, device=local_rank, stream=stream)
     pkg.synth_fill_device(q_d.data_ptr(), m * k, 1000, device=local_rank, stream=stream)
-    # two key/result buffers: with N > 1 the all-reduce of step i overlaps the scan of step i+1
+    # Two batches in flight: step i runs on stream i&1 with the index's query workspace i&1 and its
+    # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
+    # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
+    # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
     keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(2)]
     outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
     t0 = time.perf_counter()
@@ -98,29 +107,35 @@ def main():
                          refs_on_device=True, stream=stream)
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) * 1e3
+    nstreams = 1 if args.serial else 2
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     pending = [None, None]   # in-flight all-reduce of each buffer
 
     def finish(b):
         """Complete the step that used buffer b: wait for its all-reduce (stream-side), unpack."""
         if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-            pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank, stream=stream)
+            st = streams[b % nstreams]
+            with torch.cuda.stream(st):
+                pending[b].wait()
+                pending[b] = None
+                pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank,
+                                    stream=st.cuda_stream)
 
     def step(i):
-        """One pass of the hot path: m queries against the resident shard -> int32 indices.  Every
-        step is complete (init, scan, reduce, unpack); with N > 1 its reduce + unpack are issued
-        one step late so the collective's latency hides behind the next scan."""
         b = i & 1
+        st = streams[b % nstreams]
         finish(b)                      # buffer b was last used by step i-2
-        pkg.keys_init(keys[b].data_ptr(), m, device=local_rank, stream=stream)
-        index.query_keys(m, q_d.data_ptr(), keys[b].data_ptr(), stream=stream)
+        with torch.cuda.stream(st):
+            pkg.keys_init(keys[b].data_ptr(), m, device=local_rank, stream=st.cuda_stream)
+            index.query_keys(m, q_d.data_ptr(), keys[b].data_ptr(), stream=st.cuda_stream, slot=b)
+            if dist is not None:
+                # keys < 2^63 (distance bits of a non-negative float): int64 MIN == unsigned MIN
+                pending[b] = dist.all_reduce(keys[b], op=dist.ReduceOp.MIN, async_op=True)
+            else:
+                pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank,
+                                    stream=st.cuda_stream)
         if dist is not None:
-            # keys < 2^63 (distance bits of a non-negative float): int64 MIN == unsigned MIN
-            pending[b] = dist.all_reduce(keys[b], op=dist.ReduceOp.MIN, async_op=True)
             finish(b ^ 1)              # step i-1: its all-reduce ran beside this step's scan
-        else:
-            pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank, stream=stream)
 
     def drain():
         finish(0)
@@ -202,10 +217,14 @@ def main():
                                    (wname, k, m, n),
                        "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
+                       "batches_in_flight": nstreams,
                        "collective": "rccl all_reduce(min) of %d packed keys" % m if world > 1 else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     index.close()
     if dist is not None:
         dist.barrier()

@@ -95,6 +95,13 @@ int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream)
 int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
                          unsigned long long *keys_dev, void *stream);
 
+/* Same, using query workspace `slot` (0 or 1) of the index.  The index owns two independent
+ * workspaces, so two batches may be in flight at once on two streams (e.g. batch i+1's small
+ * preparation kernels beside batch i's scan); calls that share a slot must be stream-ordered.
+ * knn_index_query_keys == slot 0. */
+int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
+                              unsigned long long *keys_dev, void *stream);
+
 /* out_dev[j] = (int)(keys_dev[j] & 0xFFFFFFFF) (async on stream). */
 int knn_keys_to_indices(int device, const unsigned long long *keys_dev, int m, int *out_dev,
                         void *stream);

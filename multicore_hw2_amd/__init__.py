@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_destroy", "knn_keys_init", "knn_index_query_keys", "knn_keys_to_indices",
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
-    "knn_debug_filter_scores",
+    "knn_debug_filter_scores", "knn_index_query_keys_slot",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -58,6 +58,7 @@ def lib():
     L.knn_index_destroy.restype = None
     L.knn_keys_init.argtypes = [c_int, c_vp, c_int, c_vp]
     L.knn_index_query_keys.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
+    L.knn_index_query_keys_slot.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp]
     L.knn_keys_to_indices.argtypes = [c_int, c_vp, c_int, c_vp, c_vp]
     L.knn_index_query_host.argtypes = [c_vp, c_int, c_vp, c_vp]
     L.knn_set_option.argtypes = [ctypes.c_char_p, c_ll]
@@ -145,10 +146,11 @@ class KnnIndex:
                                       1 if refs_on_device else 0, self.base, ctypes.c_void_p(stream)))
         self._keep = None
 
-    def query_keys(self, m, queries_dev, keys_dev, stream=0):
-        """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m]."""
-        _check(lib().knn_index_query_keys(self._h, int(m), ctypes.c_void_p(int(queries_dev)),
-                                          ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream)))
+    def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0):
+        """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m].
+        slot 0/1 picks one of the index's two independent query workspaces."""
+        _check(lib().knn_index_query_keys_slot(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
+                                               ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream)))
 
     def query(self, queries):
         """Synchronous host-in/host-out query of this shard alone."""

@@ -94,6 +94,7 @@ struct knn_index {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // one pair per timed launch
     size_t events_used = 0;
+    int last_slot = 0;
 };
 
 extern "C" {
@@ -265,7 +266,13 @@ int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream)
 int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
                          unsigned long long *keys_dev, void *stream)
 {
-    if (!idx || m < 0 || (m > 0 && (!queries_dev || !keys_dev)))
+    return knn_index_query_keys_slot(idx, 0, m, queries_dev, keys_dev, stream);
+}
+
+int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
+                              unsigned long long *keys_dev, void *stream)
+{
+    if (!idx || m < 0 || slot < 0 || slot >= KNN_SLOTS || (m > 0 && (!queries_dev || !keys_dev)))
         return fail(KNN_EINVAL, "knn_index_query_keys: bad arguments");
     if (m == 0 || idx->n == 0)
         return KNN_OK;
@@ -292,7 +299,8 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;
         idx->filter.force_qt = (int)g_opt_filter_qt;
-        HIP_TRY(knn_filter_query(idx->filter, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
+        idx->last_slot = slot;
+        HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));
         return KNN_OK;
     }
@@ -349,17 +357,18 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
 {
     if (!idx || !stats)
         return fail(KNN_EINVAL, "knn_index_last_stats: bad arguments");
-    if (idx->stats[0] == 2 && idx->filter.ctl) {
+    const FilterWorkspace &w = idx->filter.ws[idx->last_slot];
+    if (idx->stats[0] == 2 && w.ctl) {
         DeviceGuard guard(idx->device);
         unsigned ctl[KNN_CTL_WORDS];
-        HIP_TRY(hipMemcpy(ctl, idx->filter.ctl, sizeof ctl, hipMemcpyDeviceToHost));
-        std::vector<unsigned> counts(idx->filter.nlists);
+        HIP_TRY(hipMemcpy(ctl, w.ctl, sizeof ctl, hipMemcpyDeviceToHost));
+        std::vector<unsigned> counts(w.nlists);
         if (!counts.empty())
-            HIP_TRY(hipMemcpy(counts.data(), idx->filter.counts, counts.size() * sizeof(unsigned),
+            HIP_TRY(hipMemcpy(counts.data(), w.counts, counts.size() * sizeof(unsigned),
                               hipMemcpyDeviceToHost));
         long long records = 0;
         for (unsigned c : counts)
-            records += c < idx->filter.slice ? c : idx->filter.slice;
+            records += c < w.slice ? c : w.slice;
         idx->stats[1] = records;
         idx->stats[2] = ctl[KNN_CTL_FALLBACK];
     }

@@ -44,18 +44,10 @@ enum {
     KNN_CTL_WORDS = 8
 };
 
-struct FilterState {
-    bool usable = false;       // references finite and in a sane range: filter layouts exist
-    int k = 0, kt = 0;         // real dimension; 16-wide K steps (padded k = 16 * kt)
-    long long n = 0;           // references in the shard
-    long long ntiles = 0;      // ceil(n / 32)
-    float sigma = 1.0f;        // power-of-two scale
-    float bmax = 0.0f;         // max |scaled fp16 reference coordinate|
-    float nmax = 0.0f;         // max fp32 squared norm of the fp16 reference rows
-    float *center = nullptr;   // device [16*kt]
-    void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
-    float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
-    // per-query workspace (one query in flight per index)
+#define KNN_SLOTS 2  // independent query workspaces per index: two batches may be in flight
+
+// Per-batch scratch of the filter path (one per slot).
+struct FilterWorkspace {
     int m_cap = 0;
     void *qry_frags = nullptr; // device [qtiles][kt][64] x 16 B: B operands (-2 * scaled query)
     float *qry_norms = nullptr;// device [qtiles*32]
@@ -67,9 +59,27 @@ struct FilterState {
     unsigned nlists = 0, slice = 0;
     float *umin = nullptr;     // device [sample blocks][m_padded]: per-block minima of the sample pass
     size_t umin_cap = 0;       // floats allocated in umin
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // optional: bracket the filter kernel
     unsigned *qpart = nullptr; // device [3 * query blocks]: {max |coord|, max norm, #bad} per block
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // optional: bracket the filter kernel
+};
+
+struct FilterState {
+    bool usable = false;       // references finite and in a sane range: filter layouts exist
+    int k = 0, kt = 0;         // real dimension; 16-wide K steps (padded k = 16 * kt)
+    long long n = 0;           // references in the shard
+    long long ntiles = 0;      // ceil(n / 32)
+    float sigma = 1.0f;        // power-of-two scale
+    float bmax = 0.0f;         // max |scaled fp16 reference coordinate|
+    float nmax = 0.0f;         // max fp32 squared norm of the fp16 reference rows
+    float *center = nullptr;   // device [16*kt]
+    void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
+    float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
+    FilterWorkspace ws[KNN_SLOTS];
+    // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
+    // 15 % slower than back to back; only the small preparation kernels are meant to overlap.
+    hipEvent_t scan_done = nullptr;
+    bool scan_recorded = false;
 };
 
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
@@ -77,7 +87,7 @@ struct FilterState {
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.
-hipError_t knn_filter_query(FilterState &st, int m, const float *q_dev, const float *r_dev,
+hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q_dev, const float *r_dev,
                             long long base, u64 *keys_dev, int num_cu, hipStream_t stream,
                             hipEvent_t ev_begin, hipEvent_t ev_end);
 // Test hook: raw filter scores S[m][n] (row-major) and the per-query thresholds for a query

@@ -668,14 +668,18 @@ void knn_filter_free(FilterState &st)
     (void)hipFree(st.center);
     (void)hipFree(st.ref_frags);
     (void)hipFree(st.ref_norms);
-    (void)hipFree(st.qry_frags);
-    (void)hipFree(st.qry_norms);
-    (void)hipFree(st.thr);
-    (void)hipFree(st.ctl);
-    (void)hipFree(st.records);
-    (void)hipFree(st.counts);
-    (void)hipFree(st.umin);
-    (void)hipFree(st.qpart);
+    if (st.scan_done)
+        (void)hipEventDestroy(st.scan_done);
+    for (FilterWorkspace &w : st.ws) {
+        (void)hipFree(w.qry_frags);
+        (void)hipFree(w.qry_norms);
+        (void)hipFree(w.thr);
+        (void)hipFree(w.ctl);
+        (void)hipFree(w.records);
+        (void)hipFree(w.counts);
+        (void)hipFree(w.umin);
+        (void)hipFree(w.qpart);
+    }
     st = FilterState();
 }
 
@@ -783,48 +787,48 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     return hipSuccess;
 }
 
-static hipError_t ensure_workspace(FilterState &st, int m)
+static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
 {
-    if (!st.ctl)
-        FTRY(hipMalloc((void **)&st.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
-    if (!st.records) {
-        FTRY(hipMalloc((void **)&st.records, (size_t)kRecordCapacity * sizeof(u64)));
-        st.rec_cap = kRecordCapacity;
+    if (!w.ctl)
+        FTRY(hipMalloc((void **)&w.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
+    if (!w.records) {
+        FTRY(hipMalloc((void **)&w.records, (size_t)kRecordCapacity * sizeof(u64)));
+        w.rec_cap = kRecordCapacity;
     }
-    if (!st.counts)
-        FTRY(hipMalloc((void **)&st.counts, (size_t)kMaxLists * sizeof(unsigned)));
-    if (m > st.m_cap) {
-        (void)hipFree(st.qry_frags);
-        (void)hipFree(st.qry_norms);
-        (void)hipFree(st.thr);
-        st.qry_frags = nullptr;
-        st.qry_norms = nullptr;
-        st.thr = nullptr;
-        st.m_cap = 0;
+    if (!w.counts)
+        FTRY(hipMalloc((void **)&w.counts, (size_t)kMaxLists * sizeof(unsigned)));
+    if (m > w.m_cap) {
+        (void)hipFree(w.qry_frags);
+        (void)hipFree(w.qry_norms);
+        (void)hipFree(w.thr);
+        w.qry_frags = nullptr;
+        w.qry_norms = nullptr;
+        w.thr = nullptr;
+        w.m_cap = 0;
         const size_t qtiles = (size_t)(m + 31) / 32;
-        FTRY(hipMalloc(&st.qry_frags, qtiles * st.kt * 64 * 16));
-        FTRY(hipMalloc((void **)&st.qry_norms, qtiles * 32 * sizeof(float)));
-        FTRY(hipMalloc((void **)&st.thr, qtiles * 32 * sizeof(float)));
-        (void)hipFree(st.qpart);
-        st.qpart = nullptr;
-        FTRY(hipMalloc((void **)&st.qpart, 3 * ((qtiles * 32 + 255) / 256) * sizeof(unsigned)));
-        st.m_cap = (int)(qtiles * 32);
+        FTRY(hipMalloc(&w.qry_frags, qtiles * st.kt * 64 * 16));
+        FTRY(hipMalloc((void **)&w.qry_norms, qtiles * 32 * sizeof(float)));
+        FTRY(hipMalloc((void **)&w.thr, qtiles * 32 * sizeof(float)));
+        (void)hipFree(w.qpart);
+        w.qpart = nullptr;
+        FTRY(hipMalloc((void **)&w.qpart, 3 * ((qtiles * 32 + 255) / 256) * sizeof(unsigned)));
+        w.m_cap = (int)(qtiles * 32);
     }
     return hipSuccess;
 }
 
-static hipError_t prep_queries(FilterState &st, int m, const float *q, hipStream_t s)
+static hipError_t prep_queries(FilterState &st, FilterWorkspace &w, int m, const float *q, hipStream_t s)
 {
     // no memsets: the fragment kernel writes per-block partials and resets FALLBACK / RECORDS
     const long long rows_padded = ((long long)m + 31) / 32 * 32;
     const unsigned blocks = (unsigned)((rows_padded + 255) / 256);
     hipLaunchKernelGGL(knn_frag_kernel, dim3(blocks), dim3(256), 0, s, q, (long long)m, rows_padded, st.k, st.kt,
-                       st.center, st.sigma, -2.0f, 0.0f, (h8 *)st.qry_frags, st.qry_norms, st.qpart, 1, st.ctl);
+                       st.center, st.sigma, -2.0f, 0.0f, (h8 *)w.qry_frags, w.qry_norms, w.qpart, 1, w.ctl);
     return hipGetLastError();
 }
 
 template <int KT, int QT>
-static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t s)
+static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int num_cu, hipStream_t s)
 {
     const int qtiles = (m + 31) / 32;
     const int m_padded = qtiles * 32;
@@ -847,8 +851,8 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
         gx = (gx + 1) / 2;
     if ((size_t)gx * 4 * gy > kMaxLists)
         return hipErrorInvalidValue;
-    st.nlists = gx * 4 * gy;
-    st.slice = st.rec_cap / st.nlists;
+    w.nlists = gx * 4 * gy;
+    w.slice = w.rec_cap / w.nlists;
 
     // 1. sample pass over every stride-th tile (about 1/16 of the shard) -> per-query minima
     long long stride = st.ntiles / 256;
@@ -868,89 +872,97 @@ static hipError_t launch_filter(FilterState &st, int m, int num_cu, hipStream_t 
         sb = 1;
     {   // per-block minima buffer, grown on demand
         const size_t need = (size_t)sb * (size_t)m_padded;
-        if (need > st.umin_cap) {
-            (void)hipFree(st.umin);
-            st.umin = nullptr;
-            st.umin_cap = 0;
-            FTRY(hipMalloc((void **)&st.umin, need * sizeof(float)));
-            st.umin_cap = need;
+        if (need > w.umin_cap) {
+            (void)hipFree(w.umin);
+            w.umin = nullptr;
+            w.umin_cap = 0;
+            FTRY(hipMalloc((void **)&w.umin, need * sizeof(float)));
+            w.umin_cap = need;
         }
     }
     hipLaunchKernelGGL((knn_filter_sample_kernel<KT, QT>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
-                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, qtiles, st.ntiles,
-                       stride, st.umin, m_padded, st.ctl);
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, qtiles, st.ntiles,
+                       stride, w.umin, m_padded, w.ctl);
     FTRY(hipGetLastError());
 
     // 2. thresholds
-    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, st.umin,
-                       (int)sb, st.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
-                       st.thr, st.ctl, st.qpart, (m_padded + 255) / 256, st.counts, st.nlists);
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
+                       (int)sb, w.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
+                       w.thr, w.ctl, w.qpart, (m_padded + 255) / 256, w.counts, w.nlists);
     FTRY(hipGetLastError());
 
-    // 3. the filter proper (timed: the dominant kernel)
-    if (st.ev_begin)
-        FTRY(hipEventRecord(st.ev_begin, s));
+    // 3. the filter proper (timed: the dominant kernel).  Ordered after the other slot's scan.
+    if (!st.scan_done)
+        FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
+    if (st.scan_recorded)
+        FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
+    if (w.ev_begin)
+        FTRY(hipEventRecord(w.ev_begin, s));
     hipLaunchKernelGGL((knn_filter_kernel<KT, QT>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, st.thr, qtiles,
-                       st.ntiles, st.records, st.counts, st.ctl, st.slice);
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles,
+                       st.ntiles, w.records, w.counts, w.ctl, w.slice);
     FTRY(hipGetLastError());
-    if (st.ev_end)
-        FTRY(hipEventRecord(st.ev_end, s));
+    if (w.ev_end)
+        FTRY(hipEventRecord(w.ev_end, s));
+    FTRY(hipEventRecord(st.scan_done, s));
+    st.scan_recorded = true;
     return hipSuccess;
 }
 
-hipError_t knn_filter_query(FilterState &st, int m, const float *q, const float *r, long long base,
+hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
                             u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
-    FTRY(ensure_workspace(st, m));
-    FTRY(prep_queries(st, m, q, s));
-    st.ev_begin = ev_begin;
-    st.ev_end = ev_end;
+    FilterWorkspace &w = st.ws[slot];
+    FTRY(ensure_workspace(st, w, m));
+    FTRY(prep_queries(st, w, m, q, s));
+    w.ev_begin = ev_begin;
+    w.ev_end = ev_end;
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {
     case 1:
         if ((qtiles <= 2 && st.force_qt == 0) || st.force_qt == 2)
-            FTRY((launch_filter<1, 2>(st, m, num_cu, s)));
+            FTRY((launch_filter<1, 2>(st, w, m, num_cu, s)));
         else if (qtiles <= 8 || st.force_qt == 8)
-            FTRY((launch_filter<1, 8>(st, m, num_cu, s)));
+            FTRY((launch_filter<1, 8>(st, w, m, num_cu, s)));
         else if (qtiles <= 16 || st.force_qt == 16)
-            FTRY((launch_filter<1, 16>(st, m, num_cu, s)));
+            FTRY((launch_filter<1, 16>(st, w, m, num_cu, s)));
         else
-            FTRY((launch_filter<1, 32>(st, m, num_cu, s)));
+            FTRY((launch_filter<1, 32>(st, w, m, num_cu, s)));
         break;
     case 2:
         if (qtiles <= 8)
-            FTRY((launch_filter<2, 8>(st, m, num_cu, s)));
+            FTRY((launch_filter<2, 8>(st, w, m, num_cu, s)));
         else
-            FTRY((launch_filter<2, 16>(st, m, num_cu, s)));
+            FTRY((launch_filter<2, 16>(st, w, m, num_cu, s)));
         break;
-    case 4: FTRY((launch_filter<4, 4>(st, m, num_cu, s))); break;
-    default: FTRY((launch_filter<8, 2>(st, m, num_cu, s))); break;
+    case 4: FTRY((launch_filter<4, 4>(st, w, m, num_cu, s))); break;
+    default: FTRY((launch_filter<8, 2>(st, w, m, num_cu, s))); break;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
-    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, st.records, st.counts, st.nlists, st.slice, st.ctl, keys, s));
+    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records, w.counts, w.nlists, w.slice, w.ctl, keys, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
-    return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, st.ctl + KNN_CTL_FALLBACK, s);
+    return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl + KNN_CTL_FALLBACK, s);
 }
 
 hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float *r, float *scores,
                             float *thr_out, float *qnorm_out, double consts[8], hipStream_t s)
 {
-    FTRY(ensure_workspace(st, m));
-    FTRY(prep_queries(st, m, q, s));
+    FilterWorkspace &w = st.ws[0];
+    FTRY(ensure_workspace(st, w, m));
+    FTRY(prep_queries(st, w, m, q, s));
     const int qtiles = (m + 31) / 32;
     const dim3 grid((unsigned)st.ntiles, (unsigned)qtiles);
     switch (st.kt) {
-    case 1: hipLaunchKernelGGL(knn_filter_scores_kernel<1>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
-    case 2: hipLaunchKernelGGL(knn_filter_scores_kernel<2>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
-    case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
-    default: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)st.qry_frags, m, st.n, scores); break;
+    case 1: hipLaunchKernelGGL(knn_filter_scores_kernel<1>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 2: hipLaunchKernelGGL(knn_filter_scores_kernel<2>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    default: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     }
     FTRY(hipGetLastError());
-    FTRY(hipMemcpyAsync(qnorm_out, st.qry_norms, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));
+    FTRY(hipMemcpyAsync(qnorm_out, w.qry_norms, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));
     const int qblocks = ((m + 31) / 32 * 32 + 255) / 256;
     std::vector<unsigned> part((size_t)3 * qblocks);
-    FTRY(hipMemcpyAsync(part.data(), st.qpart, part.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    FTRY(hipMemcpyAsync(part.data(), w.qpart, part.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     FTRY(hipStreamSynchronize(s));
     float amax = 0.0f;
     unsigned qbad = 0u;
