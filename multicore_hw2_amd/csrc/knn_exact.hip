@@ -279,6 +279,110 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// rlane16: the k = 16, few-queries (HBM-bound) case with LDS-staged reference tiles.  A block
+// reads 256 rows = 16 KiB as fully coalesced 16-byte chunks (lane l of a wave takes chunk l: one
+// 1 KiB burst per wave-instruction instead of 64 partial lines), parks them in LDS with an XOR
+// swizzle of the chunk index, and every lane reads back its own row with four conflict-free
+// ds_read_b128.  The next tile's global loads are issued before the current tile is consumed.
+// Arithmetic, tie-break and reduction are those of knn_exact_rlane.
+// ------------------------------------------------------------------------------------------
+typedef float f4x __attribute__((ext_vector_type(4)));
+
+template <int QT>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane16(const float *__restrict__ Q,
+                                                               const f4x *__restrict__ R4, int m,
+                                                               long long n, long long base,
+                                                               u64 *__restrict__ keys,
+                                                               const unsigned *__restrict__ gate)
+{
+#pragma clang fp contract(off)
+    constexpr int K = 16;
+    __shared__ f4x s_x[KNN_BLOCK * 4];
+    if (gate && *gate == 0u)
+        return;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.y * QT;
+    float qv[QT][K];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int d = 0; d < K; ++d)
+            qv[t][d] = Q[(size_t)min(q0 + t, m - 1) * K + d];  // wave-uniform -> SGPRs
+    float best[QT];
+    unsigned bidx[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        best[t] = INFINITY;
+        bidx[t] = 0u;
+    }
+    const long long ntiles = (n + KNN_BLOCK - 1) / KNN_BLOCK;
+    const long long nchunks = n * 4;  // 16-byte chunks in the shard
+    const int sw = (tid >> 2) & 3;
+
+    f4x pre[4];
+    long long tile = blockIdx.x;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long c = tile * (KNN_BLOCK * 4) + tid + j * KNN_BLOCK;
+            pre[j] = c < nchunks ? __builtin_nontemporal_load(&R4[c]) : (f4x){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // the previous tile's rows have been consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = tid + j * KNN_BLOCK;
+            const int rr = c >> 2, cc = c & 3;
+            s_x[rr * 4 + (cc ^ ((rr >> 2) & 3))] = pre[j];
+        }
+        __syncthreads();
+        const long long nxt = tile + gridDim.x;
+        if (nxt < ntiles) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long c = nxt * (KNN_BLOCK * 4) + tid + j * KNN_BLOCK;
+                pre[j] = c < nchunks ? __builtin_nontemporal_load(&R4[c]) : (f4x){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const long long i = tile * KNN_BLOCK + tid;
+        float rv[K];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const f4x x = s_x[tid * 4 + (cc ^ sw)];
+            rv[4 * cc + 0] = x[0];
+            rv[4 * cc + 1] = x[1];
+            rv[4 * cc + 2] = x[2];
+            rv[4 * cc + 3] = x[3];
+        }
+        if (i < n) {
+            const unsigned gidx = (unsigned)(base + i);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                    const float diff = qv[t][d] - rv[d];
+                    const float sq = diff * diff;
+                    acc = acc + sq;
+                }
+                if (best[t] > acc) {
+                    best[t] = acc;
+                    bidx[t] = gidx;
+                }
+            }
+        }
+    }
+    const int lane = tid & (KNN_WAVE - 1);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const u64 key = wave_min_u64(pack_key(best[t], bidx[t]));
+        if (lane == 0 && q0 + t < m && key < kKeyInit && key < keys[q0 + t])
+            key_atomic_min(&keys[q0 + t], key);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact re-rank of the MFMA filter's candidate records.  A record names one query and the 16
 // references one lane of a 32x32 MFMA tile covers: (query << 32) | (ref_tile << 1) | half, rows
 // 8g + 4*half + i (g, i in 0..3) of that tile.  One (record, row) pair per thread, v0 arithmetic.
@@ -457,6 +561,17 @@ hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float
                           u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
 {
     constexpr int QT = 4;
+    if (K == 16 && m <= 2 * QT && n >= 4096 && ((uintptr_t)r & 15u) == 0) {
+        // HBM-bound shape: LDS-staged, fully coalesced reference tiles
+        const unsigned gy = (unsigned)knn_divup(m, QT);
+        long long gx = (n + KNN_BLOCK - 1) / KNN_BLOCK;
+        const long long capx = (long long)num_cu * 8 / gy;
+        if (gx > capx)
+            gx = capx;
+        hipLaunchKernelGGL((knn_exact_rlane16<QT>), dim3((unsigned)gx, gy), dim3(KNN_BLOCK), 0, s, q,
+                           (const f4x *)r, m, n, base, keys, gate);
+        return hipGetLastError();
+    }
     unsigned qt = (unsigned)knn_divup(m, QT);
     if (qt > 64u)
         qt = 64u;  // the kernel strides over the remaining query tiles
