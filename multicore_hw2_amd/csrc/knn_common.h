@@ -51,6 +51,7 @@ struct FilterWorkspace {
     int m_cap = 0;
     void *qry_frags = nullptr; // device [qtiles][kt][64] x 16 B: B operands (-2 * scaled query)
     float *qry_norms = nullptr;// device [qtiles*32]
+    float *qry_amax = nullptr; // device [qtiles*32]: max |scaled fp16 coordinate| of each query
     float *thr = nullptr;      // device [qtiles*32]
     unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
     u64 *records = nullptr;    // device [rec_cap]: nlists slices of `slice` records, one per wave

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
                                                        float scale_out, float pad_norm,
                                                        h8 *__restrict__ frag, float *__restrict__ norms,
                                                        unsigned *__restrict__ out, int out_is_partials,
-                                                       unsigned *__restrict__ ctl)
+                                                       unsigned *__restrict__ ctl, float *__restrict__ rowmax)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float vmax = 0.0f, nrm = 0.0f;
@@ -188,6 +188,8 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
             }
         }
         norms[i] = real ? nrm : pad_norm;
+        if (rowmax)
+            rowmax[i] = vmax;  // this row's max |coordinate|: per-query error bound
         if (!real)
             nrm = 0.0f;
     }
@@ -348,7 +350,8 @@ __host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, d
 // in flight at once), LDS folds the parts.
 #define THR_PARTS 32
 __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__restrict__ umin, int nblocks,
-                                                      const float *__restrict__ qnorm, int m,
+                                                      const float *__restrict__ qnorm,
+                                                      const float *__restrict__ qamax, int m,
                                                       int m_padded, int k, int kt, float sigma,
                                                       float bmax, float nmax, float amax_limit,
                                                       float *__restrict__ thr,
@@ -389,7 +392,9 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
         if (!(u < INFINITY))
             bad = true;  // no finite sample score: cannot bound
         if (!bad) {
-            const BoundConsts c = knn_bound_consts(k, kt, sigma, amax, bmax, nmax);
+            // the error bound of THIS query: its own coordinate magnitude, not the batch maximum
+            // (one far-away query must not loosen everybody's threshold)
+            const BoundConsts c = knn_bound_consts(k, kt, sigma, qamax[i], bmax, nmax);
             t = knn_threshold(c, u, qnorm[i]);
             if (!(t < INFINITY))
                 bad = true;
@@ -673,6 +678,7 @@ void knn_filter_free(FilterState &st)
     for (FilterWorkspace &w : st.ws) {
         (void)hipFree(w.qry_frags);
         (void)hipFree(w.qry_norms);
+        (void)hipFree(w.qry_amax);
         (void)hipFree(w.thr);
         (void)hipFree(w.ctl);
         (void)hipFree(w.records);
@@ -765,7 +771,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         else
             hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
                                n, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
-                               st.ref_norms, dout, 0, nullptr);
+                               st.ref_norms, dout, 0, nullptr, nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -808,6 +814,9 @@ static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
         const size_t qtiles = (size_t)(m + 31) / 32;
         FTRY(hipMalloc(&w.qry_frags, qtiles * st.kt * 64 * 16));
         FTRY(hipMalloc((void **)&w.qry_norms, qtiles * 32 * sizeof(float)));
+        (void)hipFree(w.qry_amax);
+        w.qry_amax = nullptr;
+        FTRY(hipMalloc((void **)&w.qry_amax, qtiles * 32 * sizeof(float)));
         FTRY(hipMalloc((void **)&w.thr, qtiles * 32 * sizeof(float)));
         (void)hipFree(w.qpart);
         w.qpart = nullptr;
@@ -823,7 +832,8 @@ static hipError_t prep_queries(FilterState &st, FilterWorkspace &w, int m, const
     const long long rows_padded = ((long long)m + 31) / 32 * 32;
     const unsigned blocks = (unsigned)((rows_padded + 255) / 256);
     hipLaunchKernelGGL(knn_frag_kernel, dim3(blocks), dim3(256), 0, s, q, (long long)m, rows_padded, st.k, st.kt,
-                       st.center, st.sigma, -2.0f, 0.0f, (h8 *)w.qry_frags, w.qry_norms, w.qpart, 1, w.ctl);
+                       st.center, st.sigma, -2.0f, 0.0f, (h8 *)w.qry_frags, w.qry_norms, w.qpart, 1, w.ctl,
+                       w.qry_amax);
     return hipGetLastError();
 }
 
@@ -887,7 +897,7 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
 
     // 2. thresholds
     hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
-                       (int)sb, w.qry_norms, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
+                       (int)sb, w.qry_norms, w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
                        w.thr, w.ctl, w.qpart, (m_padded + 255) / 256, w.counts, w.nlists);
     FTRY(hipGetLastError());
 

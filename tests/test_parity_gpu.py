@@ -371,3 +371,32 @@ def test_two_workspace_slots_run_concurrent_batches_on_two_streams(oracle):
             ix2.query_keys(8, q_d[0].data_ptr(), keys[0].data_ptr(), slot=2)
         finally:
             ix2.close()
+
+
+def test_one_far_away_query_does_not_loosen_the_whole_batch(oracle):
+    """Thresholds use each query's own coordinate magnitude: a single query 100 box-widths away
+    keeps the filter selective for the other 255 (and is itself answered exactly)."""
+    k, m, n = 16, 256, 1 << 18
+    Q, R = oracle.synth(m * k, 91).reshape(m, k).copy(), oracle.synth(n * k, 92)
+    dev = torch.device("cuda:0")
+    r_d = torch.from_numpy(R).to(dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    recs = {}
+    for name, val in (("clean", None), ("outlier", 50.0)):
+        Qc = Q.copy()
+        if val is not None:
+            Qc[5] = val
+        q_d = torch.from_numpy(Qc).to(dev)
+        pkg.keys_init(keys.data_ptr(), m)
+        ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+        torch.cuda.synchronize()
+        path_taken, records, fallback, _ = ix.last_stats()
+        assert path_taken == 2 and fallback == 0, (name, fallback)
+        np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Qc, R), err_msg=name)
+        recs[name] = records
+    # the outlier's own threshold is loose (it may keep thousands of survivors); the rest are unchanged
+    assert recs["outlier"] < recs["clean"] + 20000, recs
+    ix.close()

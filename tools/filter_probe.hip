@@ -279,7 +279,7 @@ int main()
     CHK(hipMemcpy(center, hc.data(), 64, hipMemcpyHostToDevice));
     CHK(hipMemcpy(thr, hthr.data(), 4096, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (const f4v *)refs, n, n, center, 2.0f, rf, rn, out);
-    hipLaunchKernelGGL(knn_frag_kernel, dim3(4), dim3(256), 0, 0, q, 1024ll, 1024ll, 16, 1, center, 2.0f, -2.0f, 0.0f, qf, sink + 0, out, 0, (unsigned *)nullptr);
+    hipLaunchKernelGGL(knn_frag_kernel, dim3(4), dim3(256), 0, 0, q, 1024ll, 1024ll, 16, 1, center, 2.0f, -2.0f, 0.0f, qf, sink + 0, out, 0, (unsigned *)nullptr, (float *)nullptr);
     CHK(hipDeviceSynchronize());
     for (int round = 0; round < 2; ++round) {
         if (run<0>("0 production (8 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;
