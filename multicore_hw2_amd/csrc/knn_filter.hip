@@ -542,6 +542,149 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_fil
         counts[list] = cnt;
 }
 
+// ------------------------------------------------------------------------------------------
+// Deep-K variant (k > 32, e.g. config C5 k = 128): with KT K-steps per tile the A fragments of a
+// reference tile are KT KiB, and the register-resident scheme above can only keep 2 query tiles per
+// wave, so every KiB of A was used for 2 MFMAs and the kernel sat on L2 bandwidth (1.0 PF at k = 128).
+// Here a block's 4 waves share each reference tile through LDS (double-buffered, one barrier per
+// tile) and each wave owns QT = 4 DIFFERENT query tiles with one accumulator per query tile that
+// runs down the K-steps: 4*QT*KT MFMAs per staged tile, 8x less A traffic.
+//   SAMPLE = true : every stride-th tile, running minima -> umin[blockIdx.x][query]
+//   SAMPLE = false: all tiles, threshold test -> per-wave record slices (as knn_filter_kernel)
+//   grid.x blocks split the (sampled) reference tiles, grid.y = groups of 4*QT query tiles.
+// ------------------------------------------------------------------------------------------
+template <int KT, int QT, bool SAMPLE>
+__global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_tiled_kernel(
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
+    const float *__restrict__ thrg, int qtiles, long long ntiles, long long stride,
+    float *__restrict__ umin, int m_padded, u64 *__restrict__ rec, unsigned *__restrict__ counts,
+    const unsigned *__restrict__ ctl, unsigned slice)
+{
+    constexpr int WAVES = FILTER_BLOCK / 64;
+    constexpr int CHUNKS = KT * 64;                 // 16-byte chunks of A per tile
+    constexpr int CPT = (CHUNKS + FILTER_BLOCK - 1) / FILTER_BLOCK;
+    __shared__ h8 s_a[2][CHUNKS];
+    __shared__ f4v s_n[2][8];
+    if (!SAMPLE && ctl[KNN_CTL_FALLBACK] != 0u)
+        return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qt0 = (blockIdx.y * WAVES + wib) * QT;   // this wave's first query tile
+    const int nq = max(0, min(QT, qtiles - qt0));      // wave-uniform; 0 = padding wave
+
+    const long long ns = (ntiles + stride - 1) / stride;
+    const long long i0 = ns * blockIdx.x / gridDim.x;
+    const long long i1 = ns * (blockIdx.x + 1) / gridDim.x;
+
+    h8 qf[QT][KT];
+    float th[QT], um[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int tt = min(qt0 + min(t, max(nq - 1, 0)), qtiles - 1);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+            qf[t][kk] = qfg[((size_t)tt * KT + kk) * 64 + lane];
+        th[t] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + (lane & 31)] : -INFINITY;
+        um[t] = INFINITY;
+    }
+    const size_t list = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wib;
+    u64 *__restrict__ my_rec = SAMPLE ? nullptr : rec + list * slice;
+    unsigned cnt = 0u;
+
+    if (i0 < i1) {
+        h8 stage_a[CPT];
+        f4v stage_n = {0.f, 0.f, 0.f, 0.f};
+        auto fetch = [&](long long i) {
+            const long long tile = i * stride;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int c = tid + j * FILTER_BLOCK;
+                if (c < CHUNKS)
+                    stage_a[j] = rf[(size_t)tile * CHUNKS + c];
+            }
+            if (tid < 8)
+                stage_n = *(const f4v *)(rn + (size_t)tile * 32 + 4 * tid);
+        };
+        auto park = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int c = tid + j * FILTER_BLOCK;
+                if (c < CHUNKS)
+                    s_a[buf][c] = stage_a[j];
+            }
+            if (tid < 8)
+                s_n[buf][tid] = stage_n;
+        };
+        fetch(i0);
+        park(0);
+        __syncthreads();
+        for (long long i = i0; i < i1; ++i) {
+            const int buf = (int)((i - i0) & 1);
+            if (i + 1 < i1)
+                fetch(i + 1);  // global loads in flight while this tile is consumed
+            f16v c;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4v v = s_n[buf][2 * g + (lane >> 5)];
+                c[4 * g + 0] = v[0];
+                c[4 * g + 1] = v[1];
+                c[4 * g + 2] = v[2];
+                c[4 * g + 3] = v[3];
+            }
+            f16v d[QT];
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                const h8 a = s_a[buf][kk * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    d[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[t][kk], kk == 0 ? c : d[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f16v &x = d[t];
+                const float m0 = min3f(x[0], x[1], x[2]);
+                const float m1 = min3f(x[3], x[4], x[5]);
+                const float m2 = min3f(x[6], x[7], x[8]);
+                const float m3 = min3f(x[9], x[10], x[11]);
+                const float m4 = min3f(x[12], x[13], x[14]);
+                const float m5 = min3f(m0, m1, m2);
+                const float m6 = min3f(m3, m4, x[15]);
+                if (SAMPLE) {
+                    um[t] = min3f(m5, m6, um[t]);
+                } else {
+                    const float mn = min3f(m5, m6, th[t]);
+                    const bool hit = mn < th[t];
+                    const u64 mask = __ballot(hit);
+                    if (__builtin_expect(mask != 0ull, 0)) {
+                        if (hit) {
+                            const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (pos < slice)
+                                my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) |
+                                              ((u64)(i * stride) << 1) | (u64)(lane >> 5);
+                        }
+                        cnt += (unsigned)__popcll(mask);
+                    }
+                }
+            }
+            if (i + 1 < i1)
+                park(buf ^ 1);  // the other buffer was last read one iteration ago
+            __syncthreads();
+        }
+    }
+    if (SAMPLE) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float v = fminf(um[t], __shfl_xor(um[t], 32, KNN_WAVE));
+            if (lane < 32 && t < nq)
+                umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + lane] = v;
+        }
+    } else if (lane == 0) {
+        counts[list] = cnt;
+    }
+}
+
 // Sample pass: the same MFMA stream over every `stride`-th reference tile, keeping only the
 // running minimum score per query (no thresholds, no branches).  It replaces an exact pre-pass:
 // the minimum is a score of a real reference, which is all knn_threshold needs.  Per-block
@@ -919,6 +1062,69 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
     return hipSuccess;
 }
 
+template <int KT, int QT>
+static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m, int num_cu, hipStream_t s)
+{
+    const int qtiles = (m + 31) / 32;
+    const int m_padded = qtiles * 32;
+    const unsigned gy = (unsigned)((qtiles + 4 * QT - 1) / (4 * QT));
+    const unsigned target_blocks = (unsigned)num_cu * 8;
+    unsigned gx = (target_blocks + gy - 1) / gy;
+    if ((long long)gx > st.ntiles)
+        gx = (unsigned)st.ntiles;
+    if (gx < 1)
+        gx = 1;
+    while ((size_t)gx * 4 * gy > kMaxLists && gx > 1)
+        gx = (gx + 1) / 2;
+    if ((size_t)gx * 4 * gy > kMaxLists)
+        return hipErrorInvalidValue;
+    w.nlists = gx * 4 * gy;
+    w.slice = w.rec_cap / w.nlists;
+
+    long long stride = st.ntiles / 256;
+    if (stride < 1)
+        stride = 1;
+    if (stride > 16)
+        stride = 16;
+    const long long ns = (st.ntiles + stride - 1) / stride;
+    unsigned sb = gx;
+    if ((long long)sb > ns)
+        sb = (unsigned)ns;
+    {
+        const size_t need = (size_t)sb * (size_t)m_padded;
+        if (need > w.umin_cap) {
+            (void)hipFree(w.umin);
+            w.umin = nullptr;
+            w.umin_cap = 0;
+            FTRY(hipMalloc((void **)&w.umin, need * sizeof(float)));
+            w.umin_cap = need;
+        }
+    }
+    hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, true>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                       stride, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice);
+    FTRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
+                       (int)sb, w.qry_norms, w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
+                       w.thr, w.ctl, w.qpart, (m_padded + 255) / 256, w.counts, w.nlists);
+    FTRY(hipGetLastError());
+    if (!st.scan_done)
+        FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
+    if (st.scan_recorded)
+        FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
+    if (w.ev_begin)
+        FTRY(hipEventRecord(w.ev_begin, s));
+    hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                       1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice);
+    FTRY(hipGetLastError());
+    if (w.ev_end)
+        FTRY(hipEventRecord(w.ev_end, s));
+    FTRY(hipEventRecord(st.scan_done, s));
+    st.scan_recorded = true;
+    return hipSuccess;
+}
+
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
                             u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
@@ -945,8 +1151,18 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
         else
             FTRY((launch_filter<2, 16>(st, w, m, num_cu, s)));
         break;
-    case 4: FTRY((launch_filter<4, 4>(st, w, m, num_cu, s))); break;
-    default: FTRY((launch_filter<8, 2>(st, w, m, num_cu, s))); break;
+    case 4:
+        if (qtiles >= 16)
+            FTRY((launch_filter_tiled<4, 4>(st, w, m, num_cu, s)));
+        else
+            FTRY((launch_filter<4, 4>(st, w, m, num_cu, s)));
+        break;
+    default:
+        if (qtiles >= 16)
+            FTRY((launch_filter_tiled<8, 4>(st, w, m, num_cu, s)));
+        else
+            FTRY((launch_filter<8, 2>(st, w, m, num_cu, s)));
+        break;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
     FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records, w.counts, w.nlists, w.slice, w.ctl, keys, s));
