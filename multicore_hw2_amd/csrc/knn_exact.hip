@@ -520,7 +520,7 @@ struct SliceGeom {
 // never shorter than `min_refs` (below that the per-block atomics and query loads dominate).
 SliceGeom slice_refs(long long n, unsigned qgroups, int num_cu, long long min_refs)
 {
-    long long want = (long long)num_cu * 8 / (qgroups ? qgroups : 1);
+    long long want = (long long)num_cu * 20 / (qgroups ? qgroups : 1);  // 4-5 rounds of blocks: small tail
     if (want < 1)
         want = 1;
     long long per = (n + want - 1) / want;
