@@ -314,7 +314,7 @@ __host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double si
     BoundConsts c;
     c.eta2 = k * emax * emax;
     c.eta = sqrt(c.eta2);
-    const double omega = 0x1p-18;                     // MFMA internal accumulation (assumed bound)
+    const double omega = kt * 0x1p-18;                // MFMA internal accumulation, per chained K-step (assumed bound)
     c.gam = (kp + 2.0) * u;
     const double mmax = kp * amax * amax;
     c.rho = (omega + 2.0 * c.gam) * 2.0 * (nmax + mmax) + kp * 0x1p-27;

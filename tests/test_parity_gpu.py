@@ -401,3 +401,44 @@ def test_one_far_away_query_does_not_loosen_the_whole_batch(oracle):
     # the outlier's own threshold is loose (it may keep thousands of survivors); the rest are unchanged
     assert recs["outlier"] < recs["clean"] + 20000, recs
     ix.close()
+
+
+@pytest.mark.parametrize("k", [16, 40, 128])
+def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
+    """The one unproven constant of the filter bound is omega = kt * 2^-18: the matrix core's internal
+    fp32 accumulation error relative to the sum of term magnitudes.  Measured here by rebuilding the
+    exact fp16 operands on the host (same centring / scaling / rounding as knn_frag_kernel) and
+    evaluating N - 2 a.b in float64."""
+    rng = np.random.default_rng(k)
+    m, n = 64, 2048
+    Q = rng.normal(0, 1, (m, k)).astype(np.float32)
+    R = rng.normal(0, 1, (n, k)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    pkg.set_option("path", 2)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    finally:
+        pkg.set_option("path", 0)
+    scores = torch.empty((m, n), dtype=torch.float32, device=dev)
+    qn = torch.empty(m, dtype=torch.float32, device=dev)
+    sigma = np.float32(ix.debug_filter_scores(m, q_d.data_ptr(), scores.data_ptr(), qn.data_ptr())[0])
+    torch.cuda.synchronize()
+    ix.close()
+    lo, hi = R.min(axis=0), R.max(axis=0)
+    c = (np.float32(0.5) * lo + np.float32(0.5) * hi).astype(np.float32)
+    b = ((R - c) * sigma).astype(np.float32).astype(np.float16)
+    a2 = (((Q - c) * sigma).astype(np.float32).astype(np.float16).astype(np.float32) * np.float32(-2)).astype(np.float16)
+    # reference norms as the kernel stores them: sequential fp32 sum of exact products
+    bn = b.astype(np.float32)
+    N = np.zeros(n, dtype=np.float32)
+    for d in range(k):
+        N = (N + bn[:, d] * bn[:, d]).astype(np.float32)
+    terms = a2.astype(np.float64)[:, None, :] * b.astype(np.float64)[None, :, :]
+    exact = N.astype(np.float64)[None, :] + terms.sum(-1)
+    mag = np.abs(N.astype(np.float64))[None, :] + np.abs(terms).sum(-1)
+    S = scores.cpu().numpy().astype(np.float64)
+    rel = float((np.abs(S - exact) / mag).max())
+    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8
+    assert rel <= kt * 2.0 ** -18, rel
+    assert rel <= 2.0 ** -20, rel   # in practice about one fp32 rounding per 16-wide K-step
