@@ -113,13 +113,11 @@ __global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restri
     const long long threads = (long long)gridDim.x * blockDim.x;
     const long long stride = threads / k4 * k4;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gtid >= stride)
-        return;
     const int d0 = (int)(gtid % k4) * 4;
     f4v lo = {INFINITY, INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     unsigned bad = 0;
 #pragma unroll 4
-    for (long long e = gtid; e < count4; e += stride) {
+    for (long long e = gtid < stride ? gtid : count4; e < count4; e += stride) {
         const f4v v = __builtin_nontemporal_load(&R4[e]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -129,14 +127,33 @@ __global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restri
             hi[c] = fmaxf(hi[c], v[c]);
         }
     }
+    // fold the block in LDS first (k <= 128): one guarded global atomic per dimension per block
+    // instead of eight per thread on the same two cache lines
+    __shared__ unsigned s_lo[128], s_hi[128], s_bad;
+    for (int d = threadIdx.x; d < k; d += blockDim.x) {
+        s_lo[d] = 0xFFFFFFFFu;
+        s_hi[d] = 0u;
+    }
+    if (threadIdx.x == 0)
+        s_bad = 0u;
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (lo[c] <= hi[c]) {
-            guarded_atomic_min(&stats[d0 + c], f2ord(lo[c]));
-            guarded_atomic_max(&stats[k + d0 + c], f2ord(hi[c]));
+            atomicMin(&s_lo[d0 + c], f2ord(lo[c]));
+            atomicMax(&s_hi[d0 + c], f2ord(hi[c]));
         }
     if (bad)
-        atomicAdd(&stats[2 * k], bad);
+        atomicAdd(&s_bad, bad);
+    __syncthreads();
+    for (int d = threadIdx.x; d < k; d += blockDim.x) {
+        if (s_lo[d] != 0xFFFFFFFFu)
+            guarded_atomic_min(&stats[d], s_lo[d]);
+        if (s_hi[d] != 0u)
+            guarded_atomic_max(&stats[k + d], s_hi[d]);
+    }
+    if (threadIdx.x == 0 && s_bad)
+        atomicAdd(&stats[2 * k], s_bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -287,9 +304,15 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
     }
     vmax = wave_max_f(vmax);
     nrm = wave_max_f(nrm);
+    __shared__ float s_v[4], s_n[4];
     if ((threadIdx.x & 63) == 0) {
-        guarded_atomic_max(&out[0], __float_as_uint(vmax));
-        guarded_atomic_max(&out[1], __float_as_uint(nrm));
+        s_v[threadIdx.x >> 6] = vmax;
+        s_n[threadIdx.x >> 6] = nrm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        guarded_atomic_max(&out[0], __float_as_uint(fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]))));
+        guarded_atomic_max(&out[1], __float_as_uint(fmaxf(fmaxf(s_n[0], s_n[1]), fmaxf(s_n[2], s_n[3]))));
     }
     if (bad)
         atomicAdd(&out[2], bad);
