@@ -205,8 +205,13 @@ def main():
         roof["algorithmic_bytes_per_launch"] = alg_bytes
 
         cpu = None
+        parity = None
         if world == 1 and args.cpu_queries != 0:
             cpu = cpu_baseline(k, m, n, args.cpu_queries, result_idx)
+        elif world > 1 and args.cpu_queries != 0:
+            # no CPU baseline at N > 1, but never report a number for wrong answers: the reduced
+            # result of the last step must match the oracle on a few queries of the full set
+            parity = parity_spot_check(k, m, n, 8, result_idx)
 
         line = {
             "metric": "queries/sec (brute-force 1-NN, bit-exact vs v0), m=%d n=%d k=%d" % (m, n, k),
@@ -221,6 +226,8 @@ def main():
                        "collective": "rccl all_reduce(min) of %d packed keys" % m if world > 1 else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if parity:
+            line["parity_spot_check"] = parity
         sys.stdout.flush()
         os.dup2(saved_stdout_fd, 1)
         print(json.dumps(line), flush=True)
@@ -229,6 +236,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_spot_check(k, m, n, nq, gpu_idx):
+    """Oracle (OpenMP over queries) on the first nq queries against the whole reference set."""
+    import subprocess
+    from tests.oracle_lib import Oracle
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
+    Q = o.synth(nq * k, 1000)
+    R = o.synth(n * k, 1001)
+    want = o.v0(k, Q, R)
+    if not (want == gpu_idx[:nq]).all():
+        raise SystemExit("PARITY FAILURE: reduced multi-GPU indices differ from the CPU oracle")
+    return "%d/%d sampled queries identical to the CPU oracle over all %d refs" % (nq, nq, n)
 
 
 def cpu_baseline(k, m, n, cpu_queries, gpu_idx):
