@@ -442,3 +442,32 @@ def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
     kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8
     assert rel <= kt * 2.0 ** -18, rel
     assert rel <= 2.0 ** -20, rel   # in practice about one fp32 rounding per 16-wide K-step
+
+
+@pytest.mark.parametrize("k,m", [(16, 1), (16, 7), (16, 300), (3, 5), (8, 64)])
+def test_device_pointers_that_are_only_4_byte_aligned(oracle, path, k, m):
+    """A borrowed device reference set / query batch may start at any float: the 16-byte fast paths
+    (rlane16, frag16, stats4) must step aside and the result stays bit-exact."""
+    n = 70001
+    R, Q = oracle.synth(n * k, 5), oracle.synth(m * k, 6)
+    dev = torch.device("cuda:0")
+    r_buf = torch.empty(n * k + 3, dtype=torch.float32, device=dev)
+    q_buf = torch.empty(m * k + 3, dtype=torch.float32, device=dev)
+    for off in (1, 3):
+        r_buf[off:off + n * k] = torch.from_numpy(R).to(dev)
+        q_buf[off:off + m * k] = torch.from_numpy(Q).to(dev)
+        keys = torch.empty(m, dtype=torch.int64, device=dev)
+        out = torch.empty(m, dtype=torch.int32, device=dev)
+        ix = pkg.KnnIndex(k, r_buf.data_ptr() + 4 * off, n_local=n, refs_on_device=True)
+        pkg.keys_init(keys.data_ptr(), m)
+        ix.query_keys(m, q_buf.data_ptr() + 4 * off, keys.data_ptr())
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+        torch.cuda.synchronize()
+        ix.close()
+        np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R), err_msg=f"offset {off} floats")
+
+
+def test_many_queries_few_references(oracle, path):
+    k, m, n = 16, 70000, 3000
+    Q, R = oracle.synth(m * k, 8), oracle.synth(n * k, 9)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0(k, Q, R))
