@@ -4,8 +4,8 @@
  * implementation through the macros CALLBACK1..CALLBACK10, each naming a function
  *     void vN::cudaCallback(int k, int m, int n, float *searchPoints, float *referencePoints, int **results)
  * (reference sources/src/core.h:12-21, used by sources/src/main.cu:113-171).  This header
- * declares the same names without any CUDA/HIP/thrust include; libknn_ta_compat.a defines
- * v1..v9 as forwarders to the MI355X path (libknn_mi355x.so).  v0 — the serial CPU baseline a
+ * declares the same names without any CUDA/HIP/thrust include; libknn_mi355x.so defines v1..v9
+ * (C++ linkage) as forwarders to its MI355X path.  v0 — the serial CPU baseline a
  * harness compares against (core.cu:27-62) — is deliberately NOT defined by the product: the
  * harness supplies its own (tests/harness/ links the CPU oracle for it).
  *

@@ -53,6 +53,11 @@ def test_library_loads_and_exports_every_declared_symbol():
     # the library must not export divup (the TA harness defines it in its own TU: utils.h:11)
     out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     assert not re.search(r"\bdivup\b", out) and "_Z5divupii" not in out
+    # include/ta_compat.h: v1..v9 forwarders are exported (C++ linkage); v0, the CPU baseline, is
+    # deliberately left to the harness
+    for ns in ("v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9"):
+        assert f"_ZN2{ns}12cudaCallbackEiiiPfS0_PPi" in out, ns
+    assert "_ZN2v012cudaCallbackEiiiPfS0_PPi" not in out
 
 
 def test_option_hooks_reject_unknown_names():
