@@ -51,9 +51,15 @@ def run(o, name, k, m, n, check_q, steps=5):
     line = (f"{name}: k={k} m={m} n={n}: {dt * 1e3:.3f} ms/step, {m / dt:.0f} queries/s, dominant kernel "
             f"{kms / nl:.3f} ms, path={'filter' if st[0] == 2 else 'exact'}, records={st[1]}, fallback={st[2]}, "
             f"index build {tb * 1e3:.1f} ms, bit-exact on {check_q} sampled queries: {ok}")
+    alg = 4.0 * k * n + 4.0 * k * m + 8.0 * m     # algorithmic bytes
+    gbps = alg / (kms / nl * 1e-3) / 1e9
+    line += f", dominant kernel {gbps:.0f} GB/s algorithmic = {gbps / 80:.1f}% of 8 TB/s"
     if st[0] == 2:
         tf = 2.0 * k * m * n / (kms / nl * 1e-3) / 1e12
         line += f", filter MFMA {tf:.0f} TFLOP/s = {tf / 2500 * 100:.1f}% of 2.5 PF dense f16"
+    else:
+        ops = (3.0 * k + 3.0) * m * n / (kms / nl * 1e-3) / 1e12
+        line += f", exact VALU {ops:.1f} T lane-ops/s = {ops / 78.6 * 100:.1f}% of 78.6 T"
     print(line, flush=True)
     ix.close()
     assert ok
@@ -62,7 +68,13 @@ def run(o, name, k, m, n, check_q, steps=5):
 if __name__ == "__main__":
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
-    which = sys.argv[1:] or ["C1", "C2", "C5", "C4"]
+    which = sys.argv[1:] or ["C1", "C2", "C3", "HBM", "C5", "C4"]
+    if "C3" in which:
+        run(o, "C3", 16, 1024, 1 << 24, 32)
+    if "HBM" in which:   # the genuinely HBM-bound rows at the metric's n and k (reference bench 9 shape = m 1)
+        run(o, "m=1", 16, 1, 1 << 24, 1)
+        run(o, "m=8", 16, 8, 1 << 24, 8)
+        run(o, "m=64", 16, 64, 1 << 24, 16)
     if "C1" in which:
         run(o, "C1", 3, 1, 1024, 1)
     if "C2" in which:
