@@ -546,7 +546,59 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_fil
             qf[t][kk] = qfg[((size_t)(qt0 + tt) * KT + kk) * 64 + lane];
     }
 
-    if (t0 < t1) {
+    if constexpr (KT == 1 && QT <= 2) {
+        // Small batches are bound by memory instructions, not MFMAs: per 1 KiB fragment tile the
+        // four broadcast norm loads cost four more TA passes.  Here the wave stages the norms of 8
+        // tiles with ONE coalesced 1 KiB load into a private LDS window (double-buffered) and reads
+        // its C tile back with four broadcast ds_read_b128; fragments are prefetched PF tiles ahead.
+        __shared__ f4v s_nrm[FILTER_BLOCK / 64][2][64];
+        const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (t0 < t1) {
+            const long long nf4 = ntiles * 8;  // float4 chunks in the norm array
+            auto stage = [&](long long chunk_tile, int buf) {
+                const long long i4 = chunk_tile * 8 + lane;
+                s_nrm[wib][buf][lane] = i4 < nf4 ? *(const f4v *)(rn + i4 * 4) : (f4v){0.f, 0.f, 0.f, 0.f};
+            };
+            const long long c0 = t0 & ~7ll;  // chunks are 8 tiles, aligned
+            stage(c0, 0);
+            constexpr int PF = 4;  // fragment tiles in flight per wave; slots are refilled in place
+            h8 ar[PF];                 // (copying a just-loaded register would wait for the load)
+#pragma unroll
+            for (int p = 0; p < PF; ++p)
+                ar[p] = rf[(size_t)min(t0 + p, t1 - 1) * 64 + lane];
+            for (long long base_tile = t0; base_tile < t1; base_tile += PF) {
+#pragma unroll
+                for (int p = 0; p < PF; ++p) {
+                    const long long tile = base_tile + p;
+                    if (tile < t1) {  // wave-uniform
+                        const int buf = (int)(((tile - c0) >> 3) & 1);
+                        if (((tile - c0) & 7) == 0 || tile == t0) {
+                            // entering a chunk: make its norms visible to the whole wave, prefetch the next
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const long long next_chunk = ((tile - c0) & ~7ll) + c0 + 8;
+                            if (next_chunk < t1)
+                                stage(next_chunk, buf ^ 1);
+                        }
+                        h8 a[1] = {ar[p]};
+                        f16v c;
+                        const int ti = (int)((tile - c0) & 7);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f4v v = s_nrm[wib][buf][ti * 8 + 2 * g + (lane >> 5)];
+                            c[4 * g + 0] = v[0];
+                            c[4 * g + 1] = v[1];
+                            c[4 * g + 2] = v[2];
+                            c[4 * g + 3] = v[3];
+                        }
+                        filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice);
+                        ar[p] = rf[(size_t)min(tile + PF, t1 - 1) * 64 + lane];  // refill this slot
+                    }
+                }
+            }
+        }
+    } else if (t0 < t1) {
         h8 a[KT];
         f16v c;
         load_ref_tile<KT>(rf, rn, t0, lane, a, c);
