@@ -599,18 +599,17 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_fil
             }
         }
     } else if (t0 < t1) {
-        h8 a[KT];
-        f16v c;
-        load_ref_tile<KT>(rf, rn, t0, lane, a, c);
-        for (long long tile = t0; tile < t1; ++tile) {
-            h8 an[KT];
-            f16v cn;
-            load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, an, cn);  // prefetch
-            filter_ref_tile<KT, QT>(a, c, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice);
-#pragma unroll
-            for (int kk = 0; kk < KT; ++kk)
-                a[kk] = an[kk];
-            c = cn;
+        // two operand sets used alternately in place (no register copies between tiles)
+        h8 aA[KT], aB[KT];
+        f16v cA, cB;
+        load_ref_tile<KT>(rf, rn, t0, lane, aA, cA);
+        for (long long tile = t0; tile < t1; tile += 2) {
+            load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, aB, cB);  // prefetch
+            filter_ref_tile<KT, QT>(aA, cA, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice);
+            if (tile + 1 < t1) {  // wave-uniform
+                load_ref_tile<KT>(rf, rn, min(tile + 2, t1 - 1), lane, aA, cA);
+                filter_ref_tile<KT, QT>(aB, cB, qf, s_thr, lane, qt0, tile + 1, my_rec, cnt, slice);
+            }
         }
     }
     if (lane == 0)
