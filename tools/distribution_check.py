@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""How the filter behaves off the uniform cube: records re-ranked, fallbacks and step time for a few
+data distributions at k=16, m=1024, n=2^22 (results checked against the oracle on sampled queries)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import multicore_hw2_amd as pkg          # noqa: E402
+from tests.oracle_lib import Oracle      # noqa: E402
+
+o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
+dev = torch.device("cuda:0")
+k, m, n = 16, 1024, 1 << 22
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+
+
+def make(name):
+    if name == "uniform":
+        return torch.rand(m, k, device=dev, generator=g), torch.rand(n, k, device=dev, generator=g)
+    if name == "gaussian":
+        return torch.randn(m, k, device=dev, generator=g), torch.randn(n, k, device=dev, generator=g)
+    if name == "heavy_tail":      # student-t like: a few far outliers stretch the bounding box
+        r = torch.randn(n, k, device=dev, generator=g) / torch.rand(n, 1, device=dev, generator=g).clamp_min(1e-3) ** 0.5
+        q = torch.randn(m, k, device=dev, generator=g)
+        return q, r
+    if name == "clusters64":      # 64 tight clusters: many near-ties inside the filter's error band
+        c = torch.rand(64, k, device=dev, generator=g)
+        r = c[torch.randint(0, 64, (n,), device=dev, generator=g)] + 1e-3 * torch.randn(n, k, device=dev, generator=g)
+        q = c[torch.randint(0, 64, (m,), device=dev, generator=g)] + 1e-3 * torch.randn(m, k, device=dev, generator=g)
+        return q, r
+    if name == "low_rank":        # data on a 4-dimensional subspace of the 16
+        b = torch.randn(4, k, device=dev, generator=g)
+        return torch.randn(m, 4, device=dev, generator=g) @ b, torch.randn(n, 4, device=dev, generator=g) @ b
+    if name == "offset_1e4":
+        return (torch.rand(m, k, device=dev, generator=g) + 1e4), (torch.rand(n, k, device=dev, generator=g) + 1e4)
+    raise ValueError(name)
+
+
+for name in ["uniform", "gaussian", "heavy_tail", "clusters64", "low_rank", "offset_1e4"]:
+    q_d, r_d = make(name)
+    q_d, r_d = q_d.float().contiguous(), r_d.float().contiguous()
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+
+    def step():
+        pkg.keys_init(keys.data_ptr(), m)
+        ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    st = ix.last_stats()
+    sel = np.random.default_rng(0).choice(m, 16, replace=False)
+    Q, R = q_d.cpu().numpy(), r_d.cpu().numpy()
+    ok = (out.cpu().numpy()[sel] == o.v0(k, Q[sel], R)).all()
+    print(f"{name:12s} {dt * 1e3:8.3f} ms/step  path={'filter' if st[0] == 2 else 'exact'}  records={st[1]:9d}  "
+          f"device fallback to exact scan={bool(st[2])}  bit-exact on 16 sampled queries: {ok}", flush=True)
+    ix.close()
