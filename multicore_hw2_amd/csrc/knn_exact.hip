@@ -398,6 +398,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
 {
 #pragma clang fp contract(off)
     // one block per record list (= per filter wave)
+    if (ctl[KNN_CTL_FALLBACK] != 0u)
+        return;  // the exact scan is going to run anyway: do not re-rank a truncated candidate set
     const int k = K > 0 ? K : krt;
     const unsigned want = counts[blockIdx.x];
     const unsigned nrec = min(want, slice);

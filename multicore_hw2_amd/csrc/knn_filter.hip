@@ -514,7 +514,7 @@ template <int KT, int QT>
 __global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_filter_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
-    unsigned *__restrict__ counts, const unsigned *__restrict__ ctl, unsigned slice)
+    unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
 {
     // Records go to a slice of `rec` private to this wave (no shared counter: a single atomic
     // word serialises at ~88 returns/us); counts[wave] = records the wave wanted to write.
@@ -612,8 +612,11 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_fil
             }
         }
     }
-    if (lane == 0)
+    if (lane == 0) {
         counts[list] = cnt;
+        if (cnt > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;  // survivors were dropped: the exact scan will take over
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_tiled_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, long long stride,
     float *__restrict__ umin, int m_padded, u64 *__restrict__ rec, unsigned *__restrict__ counts,
-    const unsigned *__restrict__ ctl, unsigned slice)
+    unsigned *__restrict__ ctl, unsigned slice)
 {
     constexpr int WAVES = FILTER_BLOCK / 64;
     constexpr int CHUNKS = KT * 64;                 // 16-byte chunks of A per tile
@@ -756,6 +759,8 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_tiled_kernel(
         }
     } else if (lane == 0) {
         counts[list] = cnt;
+        if (cnt > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;
     }
 }
 
