@@ -125,7 +125,8 @@ long long knn_get_option(const char *name);
 /* Statistics of the most recent knn_index_query_keys on this index (filled
  * when the stream has completed; call after synchronising):
  *   [0] path taken (1 exact, 2 filter)   [1] candidates re-ranked exactly
- *   [2] candidate-buffer overflow fallbacks   [3] reserved */
+ *   [2] != 0: the device fell back to the exact scan   [3] reference rows outside the filter's
+ *   robust box (scanned exactly on every query) */
 int knn_index_last_stats(knn_index *idx, long long stats[4]);
 
 /* Test hook for the filter's error bound: raw MFMA filter scores S[m][n_local] (row-major,

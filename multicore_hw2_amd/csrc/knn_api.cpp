@@ -371,6 +371,7 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
             records += c < w.slice ? c : w.slice;
         idx->stats[1] = records;
         idx->stats[2] = ctl[KNN_CTL_FALLBACK];
+        idx->stats[3] = idx->filter.n_outliers;
     }
     memcpy(stats, idx->stats, sizeof idx->stats);
     return KNN_OK;

@@ -21,6 +21,11 @@ hipError_t knn_exact_launch(int k, int m, long long n_local, long long base, con
                             const float *r_dev, u64 *keys_dev, int num_cu, const unsigned *gate,
                             hipStream_t stream);
 
+// Exact scan of the rows listed in list_dev[0..count) (global index = base + row).
+hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base, const float *q_dev,
+                                   const float *r_dev, const unsigned *list_dev, u64 *keys_dev, int num_cu,
+                                   const unsigned *gate, hipStream_t stream);
+
 // Exact re-rank of the filter's candidate records (see knn_rerank_kernel).
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev,
                              long long base, const u64 *rec_dev, const unsigned *counts_dev,
@@ -76,6 +81,8 @@ struct FilterState {
     void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
     float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
+    unsigned *outliers = nullptr; // device: rows outside the robust box (excluded from the filter, scanned exactly)
+    unsigned n_outliers = 0;
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
     // 15 % slower than back to back; only the small preparation kernels are meant to overlap.

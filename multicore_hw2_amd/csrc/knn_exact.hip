@@ -202,9 +202,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
                                                              const float *__restrict__ R, int krt,
                                                              int m, long long n, long long base,
                                                              u64 *__restrict__ keys,
-                                                             const unsigned *__restrict__ gate)
+                                                             const unsigned *__restrict__ gate,
+                                                             const unsigned *__restrict__ gather)
 {
 #pragma clang fp contract(off)
+    // gather != null: scan only the listed rows (the filter's outlier references), n = list length
     if (gate && *gate == 0u)
         return;
     const int k = K > 0 ? K : krt;
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
 
     const long long stride = (long long)gridDim.x * KNN_BLOCK;
     for (long long i = (long long)blockIdx.x * KNN_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float *__restrict__ r = R + (size_t)i * k;
+        const long long row = gather ? (long long)gather[i] : i;
+        const float *__restrict__ r = R + (size_t)row * k;
         float acc[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t)
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__rest
                 }
             }
         }
-        const unsigned gidx = (unsigned)(base + i);
+        const unsigned gidx = (unsigned)(base + row);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             if (best[t] > acc[t]) {
@@ -586,7 +589,7 @@ hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float
     if (blocks < 1)
         blocks = 1;
     hipLaunchKernelGGL((knn_exact_rlane<K, QT>), dim3((unsigned)blocks, qt), dim3(KNN_BLOCK), 0, s, q,
-                       r, k, m, n, base, keys, gate);
+                       r, k, m, n, base, keys, gate, (const unsigned *)nullptr);
     return hipGetLastError();
 }
 
@@ -619,6 +622,32 @@ hipError_t knn_exact_launch(int k, int m, long long n, long long base, const flo
     case 16: return launch_rlane_k<16>(k, m, n, base, q, r, keys, num_cu, gate, s);
     default: return launch_rlane_k<0>(k, m, n, base, q, r, keys, num_cu, gate, s);
     }
+}
+
+hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base, const float *q, const float *r,
+                                   const unsigned *list, u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
+{
+    // exact scan of an explicit row list (listed rows in any order: the packed-key min does not care)
+    if (count == 0 || m <= 0)
+        return hipSuccess;
+    constexpr int QT = 4;
+    unsigned qt = (unsigned)knn_divup(m, QT);
+    if (qt > 256u)
+        qt = 256u;
+    long long blocks = ((long long)count + KNN_BLOCK - 1) / KNN_BLOCK;
+    long long cap = (long long)num_cu * 8 / qt;
+    if (cap < 1)
+        cap = 1;
+    if (blocks > cap)
+        blocks = cap;
+    const dim3 grid((unsigned)blocks, qt);
+    switch (k) {
+    case 3: hipLaunchKernelGGL((knn_exact_rlane<3, QT>), grid, dim3(KNN_BLOCK), 0, s, q, r, k, m, (long long)count, base, keys, gate, list); break;
+    case 8: hipLaunchKernelGGL((knn_exact_rlane<8, QT>), grid, dim3(KNN_BLOCK), 0, s, q, r, k, m, (long long)count, base, keys, gate, list); break;
+    case 16: hipLaunchKernelGGL((knn_exact_rlane<16, QT>), grid, dim3(KNN_BLOCK), 0, s, q, r, k, m, (long long)count, base, keys, gate, list); break;
+    default: hipLaunchKernelGGL((knn_exact_rlane<0, QT>), grid, dim3(KNN_BLOCK), 0, s, q, r, k, m, (long long)count, base, keys, gate, list); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,

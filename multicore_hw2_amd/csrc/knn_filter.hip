@@ -29,6 +29,9 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <chrono>
 #include <vector>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -156,6 +159,15 @@ __global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restri
         atomicAdd(&stats[2 * k], s_bad);
 }
 
+// Copies every row_stride-th row into a dense buffer (robust-box statistics are done on the host).
+__global__ __launch_bounds__(256) void knn_sample_rows_kernel(const float *__restrict__ R, int k, long long row_stride,
+                                                              long long samples, float *__restrict__ out)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < samples * k)
+        out[e] = R[(size_t)(e / k) * row_stride * k + (size_t)(e % k)];
+}
+
 // ------------------------------------------------------------------------------------------
 // fp32 AoS rows -> centred, scaled fp16 MFMA operand fragments + fp32 squared norms.
 // Fragment order: frag[(tile*KT + kt)*64 + half*32 + r] holds coordinates 16kt + 8half .. +7 of
@@ -171,7 +183,8 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
                                                        float scale_out, float pad_norm,
                                                        h8 *__restrict__ frag, float *__restrict__ norms,
                                                        unsigned *__restrict__ out, int out_is_partials,
-                                                       unsigned *__restrict__ ctl, float *__restrict__ rowmax)
+                                                       unsigned *__restrict__ ctl, float *__restrict__ rowmax,
+                                                       unsigned *__restrict__ olist, unsigned ocap)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float vmax = 0.0f, nrm = 0.0f;
@@ -179,8 +192,23 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
     if (i < rows_padded) {
         const long long tile = i >> 5;
         const int r = (int)(i & 31);
-        const bool real = i < rows;
+        bool real = i < rows;
         const float *__restrict__ x = X + (size_t)(real ? i : 0) * k;
+        if (olist && real) {
+            // reference rows outside the robust box (|scaled coordinate| > 1) leave the filter: zero
+            // fragment, +INF norm (never a survivor), listed for the exact gather scan
+            bool outside = false;
+            for (int d = 0; d < k; ++d) {
+                const float back = (float)(_Float16)((x[d] - center[d]) * sigma);
+                outside = outside || !(fabsf(back) <= 1.0f);
+            }
+            if (outside) {
+                const unsigned pos = atomicAdd(&out[3], 1u);
+                if (pos < ocap)
+                    olist[pos] = (unsigned)i;
+                real = false;
+            }
+        }
         for (int kk = 0; kk < kt; ++kk) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -254,7 +282,8 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
                                                          long long rows_padded,
                                                          const float *__restrict__ center, float sigma,
                                                          h8 *__restrict__ frag, float *__restrict__ norms,
-                                                         unsigned *__restrict__ out)
+                                                         unsigned *__restrict__ out,
+                                                         unsigned *__restrict__ olist, unsigned ocap)
 {
     __shared__ f4v s_x[256 * 4];
     const long long row0 = (long long)blockIdx.x * 256;
@@ -274,11 +303,12 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
     if (i < rows_padded) {
         const long long tile = i >> 5;
         const int r = (int)(i & 31);
-        const bool real = i < rows;
+        bool real = i < rows;
         const int sw = ((int)threadIdx.x >> 2) & 3;
+        h8 v[2];
+        float rowmax = 0.0f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            h8 v;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int cc = half * 2 + g;
@@ -288,16 +318,26 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
                     const int d = cc * 4 + j;
                     const float sc = real ? (x[j] - center[d]) * sigma : 0.0f;
                     const _Float16 hval = (_Float16)sc;
-                    const float back = (float)hval;
-                    if (!(fabsf(back) < INFINITY))
-                        ++bad;
-                    vmax = fmaxf(vmax, fabsf(back));
+                    const float back = (float)hval;   // beyond fp16 range -> inf -> outlier below
+                    rowmax = fmaxf(rowmax, fabsf(back));
                     nrm = nrm + back * back;
-                    v[g * 4 + j] = hval;
+                    v[half][g * 4 + j] = hval;
                 }
             }
-            frag[(size_t)tile * 64 + half * 32 + r] = v;
         }
+        if (real && !(rowmax <= 1.0f)) {
+            // outside the robust box: out of the filter (zero fragment, +INF norm), into the exact list
+            const unsigned pos = atomicAdd(&out[3], 1u);
+            if (pos < ocap)
+                olist[pos] = (unsigned)i;
+            real = false;
+            v[0] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            v[1] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            rowmax = 0.0f;
+        }
+        vmax = rowmax;
+        frag[(size_t)tile * 64 + r] = v[0];
+        frag[(size_t)tile * 64 + 32 + r] = v[1];
         norms[i] = real ? nrm : INFINITY;
         if (!real)
             nrm = 0.0f;
@@ -476,6 +516,12 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
         d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qf[0][kk], d[0], 0, 0, 0);
+    // The QT steps are ONE basic block: the hit masks are parked in SGPR pairs and looked at once
+    // after the last step.  (With a branch per step the accumulator written by an MFMA was read
+    // in a later block, and the compiler's cross-block MFMA->VALU wait-state count came out short
+    // of the 12 the in-block rule gives: stale accumulator reads, i.e. missed survivors.)
+    u64 masks[QT];
+    u64 any = 0ull;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float th = s_thr[t * 32 + (lane & 31)];
@@ -495,23 +541,30 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
         const float m5 = min3f(m0, m1, m2);
         const float m6 = min3f(m3, m4, x[15]);
         const float mn = min3f(m5, m6, th);
-        const bool hit = mn < th;  // rare: one of this lane's 16 rows may beat the bound
-        const u64 mask = __ballot(hit);
-        if (__builtin_expect(mask != 0ull, 0)) {  // wave-uniform branch
-            if (hit) {
-                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (pos < slice)
-                    my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
-                                  (u64)(lane >> 5);
+        masks[t] = __ballot(mn < th);  // rare: one of this lane's 16 rows may beat the bound
+        any |= masks[t];
+    }
+    if (__builtin_expect(any != 0ull, 0)) {  // wave-uniform
+        const u64 me = 1ull << lane;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const u64 mask = masks[t];
+            if (mask != 0ull) {
+                if (mask & me) {
+                    const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (pos < slice)
+                        my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
+                                      (u64)(lane >> 5);
+                }
+                cnt += (unsigned)__popcll(mask);
             }
-            cnt += (unsigned)__popcll(mask);
         }
     }
 }
 
 template <int KT, int QT>
-__global__ __launch_bounds__(FILTER_BLOCK, (KT * QT <= 16 ? 3 : 2)) void knn_filter_kernel(
+__global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : 2)) void knn_filter_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
     unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
@@ -895,6 +948,7 @@ void knn_filter_free(FilterState &st)
     (void)hipFree(st.center);
     (void)hipFree(st.ref_frags);
     (void)hipFree(st.ref_norms);
+    (void)hipFree(st.outliers);
     if (st.scan_done)
         (void)hipEventDestroy(st.scan_done);
     for (FilterWorkspace &w : st.ws) {
@@ -919,6 +973,15 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
     const int kp = 16 * kt;
     const long long ntiles = (n + 31) / 32;
+    const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[knn build] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     // 1. per-dimension range
     std::vector<unsigned> hstats((size_t)2 * k + 1);
@@ -945,17 +1008,85 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         e = hipStreamSynchronize(s);
     (void)hipFree(dstats);
     FTRY(e);
+    lap("range kernel + sync");
     if (hstats[(size_t)2 * k] != 0u)
         return hipSuccess;  // NaN / Inf among the references: exact path only
 
-    std::vector<float> center((size_t)kp, 0.0f);
+    // 1b. robust box: per dimension [median - w s, median + w s] clipped to [min, max], with
+    // s = 1.4826 * MAD from a strided sample of 4096 rows (median/MAD do not move when a few rows sit
+    // 300 sigma out; mean/std do).  A few far-out rows would otherwise stretch the box, and with it
+    // the fp16 step, for everybody.  ANY box is correct: rows outside it leave the filter and are
+    // scanned exactly on every query, so the box is only worth it if it leaves out a handful of
+    // rows — w doubles from 12 until at most 1 % of the sample falls outside (heavy tails), and a
+    // second mode further out than 96 s (more than 1 % of the rows) keeps the plain [min, max].
+    const long long samples = n < 4096 ? n : 4096;
+    const long long row_stride = n / samples;
+    std::vector<float> samp((size_t)samples * k);
+    {
+        float *dsamp = nullptr;
+        FTRY(hipMalloc((void **)&dsamp, samp.size() * sizeof(float)));
+        hipLaunchKernelGGL(knn_sample_rows_kernel, dim3((unsigned)((samples * k + 255) / 256)), dim3(256), 0, s, r, k,
+                           row_stride, samples, dsamp);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(samp.data(), dsamp, samp.size() * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        (void)hipFree(dsamp);
+        FTRY(e);
+        lap("sample rows + copy");
+    }
+    std::vector<float> center((size_t)kp, 0.0f), col((size_t)samples), blo((size_t)k), bhi((size_t)k);
+    std::vector<double> med((size_t)k), mad((size_t)k);
+    for (int d = 0; d < k; ++d) {
+        for (long long i = 0; i < samples; ++i)
+            col[(size_t)i] = samp[(size_t)i * k + d];
+        std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
+        med[(size_t)d] = col[(size_t)(samples / 2)];
+        for (long long i = 0; i < samples; ++i)
+            col[(size_t)i] = fabsf(col[(size_t)i] - (float)med[(size_t)d]);
+        std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
+        mad[(size_t)d] = 1.4826 * (double)col[(size_t)(samples / 2)];
+    }
+    bool clipped = false;
+    for (double w = 12.0; w <= 96.0 && !clipped; w *= 2.0) {
+        for (int d = 0; d < k; ++d) {
+            float lo = ord2f_host(hstats[(size_t)d]), hi = ord2f_host(hstats[(size_t)k + d]);
+            const double sr = mad[(size_t)d];
+            if (sr > 0.0 && sr < 1e30) {
+                const double rlo = med[(size_t)d] - w * sr, rhi = med[(size_t)d] + w * sr;
+                if (rlo > (double)lo && rlo < (double)hi)
+                    lo = (float)rlo;
+                if (rhi < (double)hi && rhi > (double)lo)
+                    hi = (float)rhi;
+            }
+            blo[(size_t)d] = lo;
+            bhi[(size_t)d] = hi;
+        }
+        long long outside = 0;
+        for (long long i = 0; i < samples; ++i) {
+            bool out = false;
+            for (int d = 0; d < k && !out; ++d) {
+                const float x = samp[(size_t)i * k + d];
+                out = x < blo[(size_t)d] || x > bhi[(size_t)d];
+            }
+            outside += out;
+        }
+        clipped = outside * 100 <= samples;
+    }
+    if (!clipped)
+        for (int d = 0; d < k; ++d) {
+            blo[(size_t)d] = ord2f_host(hstats[(size_t)d]);
+            bhi[(size_t)d] = ord2f_host(hstats[(size_t)k + d]);
+        }
     double h = 0.0;
     for (int d = 0; d < k; ++d) {
-        const float lo = ord2f_host(hstats[(size_t)d]), hi = ord2f_host(hstats[(size_t)k + d]);
+        const float lo = blo[(size_t)d], hi = bhi[(size_t)d];
         const float c = 0.5f * lo + 0.5f * hi;
         center[(size_t)d] = c;
         h = fmax(h, fmax((double)hi - (double)c, (double)c - (double)lo));
     }
+    lap("median / MAD box (host)");
     if (!(h <= 1e15) || (h != 0.0 && h < 1e-15))
         return hipSuccess;
     float sigma = 1.0f;
@@ -977,6 +1108,9 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         e = hipMalloc(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
     if (e == hipSuccess)
         e = hipMalloc((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+    const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);  // more outliers than this: no filter
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
     if (e == hipSuccess)
         e = hipMalloc((void **)&dout, 4 * sizeof(unsigned));
     if (e == hipSuccess)
@@ -984,31 +1118,34 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     if (e == hipSuccess)
         e = hipMemcpyAsync(st.center, center.data(), (size_t)kp * sizeof(float), hipMemcpyHostToDevice, s);
     unsigned hout[4] = {0, 0, 0, 0};
+    lap("allocations");
     if (e == hipSuccess) {
         const long long rows_padded = ntiles * 32;
         if (k == 16 && ((uintptr_t)r & 15u) == 0)
             hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s,
                                (const f4v *)r, n, rows_padded, st.center, sigma, (h8 *)st.ref_frags,
-                               st.ref_norms, dout);
+                               st.ref_norms, dout, st.outliers, ocap);
         else
             hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
                                n, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
-                               st.ref_norms, dout, 0, nullptr, nullptr);
+                               st.ref_norms, dout, 0, nullptr, nullptr, st.outliers, ocap);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);  // also keeps `center` alive until the copy is done
+    lap("fragment kernel + sync");
     (void)hipFree(dout);
     if (e != hipSuccess) {
         knn_filter_free(st);
         return e;
     }
-    if (hout[2] != 0u) {  // a scaled coordinate fell out of fp16 range (cannot happen with |b| <= 1)
+    if (hout[2] != 0u || hout[3] > ocap) {  // fp16 range trouble, or too many rows outside the box
         knn_filter_free(st);
         return hipSuccess;
     }
+    st.n_outliers = hout[3];
     memcpy(&st.bmax, &hout[0], 4);
     memcpy(&st.nmax, &hout[1], 4);
     st.usable = true;
@@ -1055,7 +1192,7 @@ static hipError_t prep_queries(FilterState &st, FilterWorkspace &w, int m, const
     const unsigned blocks = (unsigned)((rows_padded + 255) / 256);
     hipLaunchKernelGGL(knn_frag_kernel, dim3(blocks), dim3(256), 0, s, q, (long long)m, rows_padded, st.k, st.kt,
                        st.center, st.sigma, -2.0f, 0.0f, (h8 *)w.qry_frags, w.qry_norms, w.qpart, 1, w.ctl,
-                       w.qry_amax);
+                       w.qry_amax, nullptr, 0u);
     return hipGetLastError();
 }
 
@@ -1245,6 +1382,8 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
     FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records, w.counts, w.nlists, w.slice, w.ctl, keys, s));
+    // rows outside the robust box never entered the filter: exact scan of that (short) list
+    FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
     return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl + KNN_CTL_FALLBACK, s);
 }

@@ -106,6 +106,26 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
         assert re.search(r"v_(pk_)?mul_f32", body), name
 
 
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
+def test_filter_kernels_keep_mfma_results_12_wait_states_from_their_readers(tmp_path):
+    """tools/mfma_hazard_audit.py: every v_mfma result in the filter kernels is first touched by a
+    VALU/memory instruction >= 12 wait states later in fall-through order (a per-step branch
+    between MFMA and reader once left only 6: stale accumulators, missed survivors)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import mfma_hazard_audit
+    finally:
+        sys.path.pop(0)
+    src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", "knn_filter.hip")
+    asm = tmp_path / "knn_filter.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", "-o", str(asm), src])
+    bad, n_mfma = mfma_hazard_audit.audit(asm.read_text())
+    assert n_mfma >= 300, n_mfma
+    assert not bad, bad[:5]
+
+
 WORKER = r"""
 import os, sys
 import numpy as np

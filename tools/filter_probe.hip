@@ -278,8 +278,8 @@ int main()
     std::vector<float> hc(16, 0.5f), hthr(1024, -5.0f);   // thresholds no score can reach: no hits
     CHK(hipMemcpy(center, hc.data(), 64, hipMemcpyHostToDevice));
     CHK(hipMemcpy(thr, hthr.data(), 4096, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (const f4v *)refs, n, n, center, 2.0f, rf, rn, out);
-    hipLaunchKernelGGL(knn_frag_kernel, dim3(4), dim3(256), 0, 0, q, 1024ll, 1024ll, 16, 1, center, 2.0f, -2.0f, 0.0f, qf, sink + 0, out, 0, (unsigned *)nullptr, (float *)nullptr);
+    hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (const f4v *)refs, n, n, center, 2.0f, rf, rn, out, (unsigned *)sink, 0u);
+    hipLaunchKernelGGL(knn_frag_kernel, dim3(4), dim3(256), 0, 0, q, 1024ll, 1024ll, 16, 1, center, 2.0f, -2.0f, 0.0f, qf, sink + 0, out, 0, (unsigned *)nullptr, (float *)nullptr, (unsigned *)nullptr, 0u);
     CHK(hipDeviceSynchronize());
     for (int round = 0; round < 2; ++round) {
         if (run<0>("0 production (8 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;

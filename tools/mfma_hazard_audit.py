@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Static audit of MFMA -> VALU wait states in the filter kernels' gfx950 ISA.
+
+Why: the in-block rule the compiler applies for `v_mfma_f32_32x32x16_f16` (8 passes) is 12 wait
+states between the MFMA and the first VALU instruction that reads (or overwrites) its result.
+When the reader sat in a LATER basic block (a per-step `if (hit)` branch between them) the
+inserted s_nops only made up 6, and with no other MFMA in between the accumulator was read
+stale about once in 60 launches (k = 17, last query tile of a group: wrong nearest index).
+The kernels now keep MFMA and reader in one block; this audit walks every function in
+fall-through order and reports any MFMA result touched by a VALU/memory instruction fewer than
+NEED wait states later, so a future edit that re-introduces the pattern fails on the CPU.
+
+usage: mfma_hazard_audit.py file.s [need=12]   (file.s from `hipcc -S --cuda-device-only`)
+"""
+import re
+import sys
+
+NEED = 12
+
+
+def _regs(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def audit(text, need=NEED):
+    """-> list of (function, wait_states, mfma_line, reader_line) violations."""
+    ins = []
+    for ln, raw in enumerate(text.split("\n"), 1):
+        s = raw.strip()
+        if re.match(r"^_Z\w+:", s):
+            ins.append((ln, "FUNC", s.split(":")[0]))
+            continue
+        if not s or s[0] in ";." or s.endswith(":"):
+            continue
+        s = s.split(";")[0].strip()
+        if s:
+            ins.append((ln, "I", s))
+    found, cur, n_mfma = [], None, 0
+    for i, (ln, kind, s) in enumerate(ins):
+        if kind == "FUNC":
+            cur = s
+            continue
+        if not s.startswith("v_mfma"):
+            continue
+        n_mfma += 1
+        dst = _regs(s.split(None, 1)[1].split(", ")[0])
+        states = 0
+        for ln2, k2, s2 in ins[i + 1:i + 60]:
+            if k2 == "FUNC" or s2.startswith(("s_endpgm", "s_branch", "s_setpc")):
+                break
+            if s2.startswith("v_mfma"):
+                o2 = s2.split(None, 1)[1].split(", ")
+                if _regs(o2[0]) & dst:
+                    break  # accumulate chain / overwritten by the next MFMA: the XDL rule, not this one
+                states += 1
+                continue
+            if s2.startswith("s_nop"):
+                states += int(s2.split()[1]) + 1
+                continue
+            if s2.startswith(("v_", "global_", "ds_", "buffer_", "flat_", "scratch_")):
+                touched = _regs(s2.split(None, 1)[1]) if " " in s2 else set()
+                if touched & dst:
+                    if states < need:
+                        found.append((cur, states, ln, ln2))
+                    break
+            states += 1
+            if states >= need:
+                break
+    return found, n_mfma
+
+
+if __name__ == "__main__":
+    need = int(sys.argv[2]) if len(sys.argv) > 2 else NEED
+    bad, n = audit(open(sys.argv[1]).read(), need)
+    for f in bad:
+        print("%s: %d wait states (MFMA line %d, reader line %d)" % f)
+    print("%d MFMAs audited, %d short of %d wait states" % (n, len(bad), need))
+    sys.exit(1 if bad else 0)
