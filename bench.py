@@ -43,6 +43,13 @@ def parse_args():
     ap.add_argument("--workload", default="c3", help="c2 | c3 | c4 | c5 | k,m,n")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact VALU only, 2 force MFMA filter")
     ap.add_argument("--filter-qt", type=int, default=0, help="tuning: query tiles per filter wave (0 auto)")
+    ap.add_argument("--filter-rounds", type=int, default=0, help="tuning: filter blocks per resident slot (0 default)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="batches in flight (1..4), each on its own stream / workspace slot; 0 = 2 for shards of "
+                         ">= 8M references (scans chained), 3 below (scans free to overlap)")
+    ap.add_argument("--filter-chain", type=int, default=0, help="0 auto, 1 scans of different slots chained, 2 free")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket every N-th launch of the dominant kernel with HIP events (roofline.kernel_avg_ms)")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
@@ -87,6 +94,10 @@ def main():
     pkg.set_option("path", args.path)
     if args.filter_qt:
         pkg.set_option("filter_qt", args.filter_qt)
+    if args.filter_rounds:
+        pkg.set_option("filter_rounds", args.filter_rounds)
+    if args.filter_chain:
+        pkg.set_option("filter_chain", args.filter_chain)
 
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)
@@ -101,16 +112,18 @@ def main():
     # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
     # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
-    keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(2)]
-    outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
+    inflight = args.inflight if args.inflight > 0 else (2 if n_local >= (1 << 23) else 3)
+    nbuf = 1 if args.serial else max(1, min(4, inflight))
+    keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     t0 = time.perf_counter()
     index = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo,
                          refs_on_device=True, stream=stream)
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) * 1e3
-    nstreams = 1 if args.serial else 2
+    nstreams = nbuf
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    pending = [None, None]   # in-flight all-reduce of each buffer
+    pending = [None] * nbuf   # in-flight all-reduce of each buffer
 
     def finish(b):
         """Complete the step that used buffer b: wait for its all-reduce (stream-side), unpack."""
@@ -123,9 +136,9 @@ def main():
                                     stream=st.cuda_stream)
 
     def step(i):
-        b = i & 1
+        b = i % nbuf
         st = streams[b % nstreams]
-        finish(b)                      # buffer b was last used by step i-2
+        finish(b)                      # buffer b was last used by step i-nbuf
         with torch.cuda.stream(st):
             pkg.keys_init(keys[b].data_ptr(), m, device=local_rank, stream=st.cuda_stream)
             index.query_keys(m, q_d.data_ptr(), keys[b].data_ptr(), stream=st.cuda_stream, slot=b)
@@ -135,12 +148,12 @@ def main():
             else:
                 pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank,
                                     stream=st.cuda_stream)
-        if dist is not None:
-            finish(b ^ 1)              # step i-1: its all-reduce ran beside this step's scan
+        if dist is not None and nbuf > 1:
+            finish((i - 1) % nbuf)     # step i-1: its all-reduce ran beside this step's scan
 
     def drain():
-        finish(0)
-        finish(1)
+        for b in range(nbuf):
+            finish(b)
 
     def fence():
         if dist is not None:
@@ -151,7 +164,7 @@ def main():
         step(i)
     drain()
     fence()
-    index.timing(True)
+    index.timing(max(1, args.time_every))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -163,6 +176,7 @@ def main():
     # roofline block can show both the pipelined-phase duration and the kernel's own
     torch.cuda.synchronize()
     alone_n, alone_ms = 0, 0.0
+    index.timing(1)
     if nstreams > 1:
         for _ in range(5):
             with torch.cuda.stream(streams[0]):
@@ -178,7 +192,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     qps = m * args.steps / elapsed
     stats = index.last_stats()
-    result_idx = outs[(args.steps - 1) & 1].cpu().numpy()
+    result_idx = outs[(args.steps - 1) % nbuf].cpu().numpy()
 
     if rank == 0:
         kern_avg_ms = kern_ms / max(launches, 1)
@@ -217,6 +231,13 @@ def main():
             roof["frac_alone"] = roof["frac"] * kern_avg_ms / (alone_ms / alone_n)
         roof["kernel_avg_ms"] = kern_avg_ms
         roof["kernel_launches_timed"] = launches
+        chain = pkg.get_option("filter_chain") if hasattr(pkg, "get_option") else 0
+        roof["launches_overlap"] = bool(path_taken == 2 and nstreams > 1 and
+                                        (chain == 2 or (chain == 0 and n_local < (1 << 23))))
+        if roof["launches_overlap"]:
+            roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
+                           "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \
+                           "are the same kernel with the GPU to itself"
         roof["algorithmic_bytes_per_launch"] = alg_bytes
 
         cpu = None

@@ -118,6 +118,10 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             on a single GPU.
  *   "filter_qt" tuning: query tiles (of 32) each filter wave keeps in registers: 8, 16 or 32
  *             (0 = chosen from m)
+ *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
+ *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
+ *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the
+ *             shard is >= 8M references, where overlapping scans slow each other down)
  * Returns KNN_EINVAL for an unknown name or value. */
 int knn_set_option(const char *name, long long value);
 long long knn_get_option(const char *name);
@@ -138,8 +142,9 @@ int knn_debug_filter_scores(knn_index *idx, int m, const float *queries_dev, flo
                             float *qnorm_dev, double consts[8]);
 
 /* Bench support: time the index's dominant kernel (the one the roofline is quoted for) with a
- * HIP event pair recorded on the caller's stream around each launch.  enable != 0 starts
- * recording for every later knn_index_query_keys, 0 stops and drops the record. */
+ * HIP event pair recorded on the caller's stream around the launch.  enable = N > 0 brackets every
+ * N-th later knn_index_query_keys (1 = all; an event record costs the stream ~5 us, which shows
+ * in sub-100-us steps), 0 stops and drops the record. */
 int knn_index_timing(knn_index *idx, int enable);
 /* Waits for the recorded events, returns how many launches were timed and their summed
  * duration in milliseconds, and clears the record. */

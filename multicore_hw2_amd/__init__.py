@@ -175,7 +175,8 @@ class KnnIndex:
         return list(consts)
 
     def timing(self, enable):
-        _check(lib().knn_index_timing(self._h, 1 if enable else 0))
+        """True / N > 0: bracket every (N-th) dominant-kernel launch with HIP events; False / 0: stop."""
+        _check(lib().knn_index_timing(self._h, int(enable)))
 
     def timing_read(self):
         """(launches, total_ms) of the dominant kernel since timing(True) / the last read."""

@@ -62,6 +62,8 @@ int fail(int code, const char *what, const char *detail = nullptr)
 std::atomic<long long> g_opt_path{0};
 std::atomic<long long> g_opt_shards{0};
 std::atomic<long long> g_opt_filter_qt{0};
+std::atomic<long long> g_opt_filter_rounds{0};
+std::atomic<long long> g_opt_filter_chain{0};
 
 struct DeviceGuard {
     int prev = -1;
@@ -91,7 +93,8 @@ struct knn_index {
     float *owned_refs = nullptr;  // set when the index copied the references itself
     long long stats[4] = {0, 0, 0, 0};
     FilterState filter;           // MFMA filter layouts + workspace (usable == false: exact only)
-    bool timing = false;
+    int timing = 0;            // 0 off, N > 0: bracket every N-th dominant-kernel launch with events
+    unsigned long long timing_seq = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // one pair per timed launch
     size_t events_used = 0;
     int last_slot = 0;
@@ -133,6 +136,18 @@ int knn_set_option(const char *name, long long value)
         g_opt_filter_qt = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "filter_chain")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: filter_chain must be 0 (auto), 1 (chained) or 2 (free)");
+        g_opt_filter_chain = value;
+        return KNN_OK;
+    }
+    if (!strcmp(name, "filter_rounds")) {
+        if (value < 0 || value > 64)
+            return fail(KNN_EINVAL, "knn_set_option: filter_rounds must be in [0, 64]");
+        g_opt_filter_rounds = value;
+        return KNN_OK;
+    }
     return fail(KNN_EINVAL, "knn_set_option: unknown option", name);
 }
 
@@ -144,6 +159,10 @@ long long knn_get_option(const char *name)
         return g_opt_shards;
     if (name && !strcmp(name, "filter_qt"))
         return g_opt_filter_qt;
+    if (name && !strcmp(name, "filter_rounds"))
+        return g_opt_filter_rounds;
+    if (name && !strcmp(name, "filter_chain"))
+        return g_opt_filter_chain;
     return -1;
 }
 
@@ -284,7 +303,7 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
     idx->stats[2] = 0;
     hipStream_t s = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
-    if (idx->timing) {
+    if (idx->timing > 0 && idx->timing_seq++ % (unsigned long long)idx->timing == 0) {
         if (idx->events_used == idx->events.size()) {
             std::pair<hipEvent_t, hipEvent_t> fresh;
             HIP_TRY(hipEventCreate(&fresh.first));
@@ -299,6 +318,8 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;
         idx->filter.force_qt = (int)g_opt_filter_qt;
+        idx->filter.force_rounds = (int)g_opt_filter_rounds;
+        idx->filter.chain_policy = (int)g_opt_filter_chain;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));
@@ -330,7 +351,8 @@ int knn_index_timing(knn_index *idx, int enable)
 {
     if (!idx)
         return fail(KNN_EINVAL, "knn_index_timing: null index");
-    idx->timing = enable != 0;
+    idx->timing = enable > 0 ? enable : 0;
+    idx->timing_seq = 0;
     idx->events_used = 0;
     return KNN_OK;
 }

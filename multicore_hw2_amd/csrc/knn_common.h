@@ -49,7 +49,7 @@ enum {
     KNN_CTL_WORDS = 8
 };
 
-#define KNN_SLOTS 2  // independent query workspaces per index: two batches may be in flight
+#define KNN_SLOTS 4  // independent query workspaces per index: up to four batches may be in flight
 
 // Per-batch scratch of the filter path (one per slot).
 struct FilterWorkspace {
@@ -81,6 +81,8 @@ struct FilterState {
     void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
     float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
+    int force_rounds = 0;      // tuning hook: filter blocks per resident slot (0 = default)
+    int chain_policy = 0;      // scans of different slots: 0 auto (chained when long), 1 always chained, 2 never
     unsigned *outliers = nullptr; // device: rows outside the robust box (excluded from the filter, scanned exactly)
     unsigned n_outliers = 0;
     FilterWorkspace ws[KNN_SLOTS];

@@ -345,35 +345,40 @@ def test_ta_style_harness_through_the_cpp_function_pointer_boundary(tmp_path, or
         assert [int(t) for t in line.split(",") if t] == g.tolist()
 
 
-def test_two_workspace_slots_run_concurrent_batches_on_two_streams(oracle):
-    """knn_index_query_keys_slot: two different query batches in flight at once (slot 0 / stream A,
-    slot 1 / stream B) against one index, repeated; both must stay bit-exact."""
+@pytest.mark.parametrize("chain", [0, 1, 2], ids=["auto", "chained", "free"])
+def test_workspace_slots_run_concurrent_batches_on_their_own_streams(oracle, chain):
+    """knn_index_query_keys_slot: four different query batches in flight at once (slot b on stream b)
+    against one index, repeated, with the scans chained or free to overlap; all stay bit-exact."""
     k, n = 16, 1 << 19
     R = oracle.synth(n * k, 77)
     dev = torch.device("cuda:0")
     r_d = torch.from_numpy(R).to(dev)
-    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
-    ms = (1024, 300)
-    Qs = [oracle.synth(ms[0] * k, 78), oracle.synth(ms[1] * k, 79)]
-    q_d = [torch.from_numpy(q).to(dev) for q in Qs]
-    keys = [torch.empty(m, dtype=torch.int64, device=dev) for m in ms]
-    outs = [torch.empty(m, dtype=torch.int32, device=dev) for m in ms]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    torch.cuda.synchronize()
-    for _ in range(6):
-        for b in range(2):
-            s = streams[b].cuda_stream
-            pkg.keys_init(keys[b].data_ptr(), ms[b], stream=s)
-            ix.query_keys(ms[b], q_d[b].data_ptr(), keys[b].data_ptr(), stream=s, slot=b)
-            pkg.keys_to_indices(keys[b].data_ptr(), ms[b], outs[b].data_ptr(), stream=s)
-    torch.cuda.synchronize()
-    for b in range(2):
-        np.testing.assert_array_equal(outs[b].cpu().numpy(), oracle.v0(k, Qs[b], R), err_msg=f"slot {b}")
-    ix.close()
+    pkg.set_option("filter_chain", chain)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+        ms = (1024, 300, 77, 2000)
+        Qs = [oracle.synth(ms[b] * k, 78 + b) for b in range(4)]
+        q_d = [torch.from_numpy(q).to(dev) for q in Qs]
+        keys = [torch.empty(m, dtype=torch.int64, device=dev) for m in ms]
+        outs = [torch.empty(m, dtype=torch.int32, device=dev) for m in ms]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        torch.cuda.synchronize()
+        for _ in range(6):
+            for b in range(4):
+                s = streams[b].cuda_stream
+                pkg.keys_init(keys[b].data_ptr(), ms[b], stream=s)
+                ix.query_keys(ms[b], q_d[b].data_ptr(), keys[b].data_ptr(), stream=s, slot=b)
+                pkg.keys_to_indices(keys[b].data_ptr(), ms[b], outs[b].data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        for b in range(4):
+            np.testing.assert_array_equal(outs[b].cpu().numpy(), oracle.v0(k, Qs[b], R), err_msg=f"slot {b}")
+        ix.close()
+    finally:
+        pkg.set_option("filter_chain", 0)
     with pytest.raises(pkg.KnnError):
         ix2 = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
         try:
-            ix2.query_keys(8, q_d[0].data_ptr(), keys[0].data_ptr(), slot=2)
+            ix2.query_keys(8, q_d[0].data_ptr(), keys[0].data_ptr(), slot=4)
         finally:
             ix2.close()
 
