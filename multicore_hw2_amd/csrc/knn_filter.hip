@@ -1013,13 +1013,14 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         return hipSuccess;  // NaN / Inf among the references: exact path only
 
     // 1b. robust box: per dimension [median - w s, median + w s] clipped to [min, max], with
-    // s = 1.4826 * MAD from a strided sample of 4096 rows (median/MAD do not move when a few rows sit
+    // s = 1.4826 * MAD from a strided sample of up to 4096 rows (median/MAD do not move when a few rows sit
     // 300 sigma out; mean/std do).  A few far-out rows would otherwise stretch the box, and with it
     // the fp16 step, for everybody.  ANY box is correct: rows outside it leave the filter and are
     // scanned exactly on every query, so the box is only worth it if it leaves out a handful of
     // rows — w doubles from 12 until at most 1 % of the sample falls outside (heavy tails), and a
     // second mode further out than 96 s (more than 1 % of the rows) keeps the plain [min, max].
-    const long long samples = n < 4096 ? n : 4096;
+    const long long want = k <= 16 ? 4096 : 65536 / k;  // host work stays ~1 ms at any k
+    const long long samples = n < want ? n : want;
     const long long row_stride = n / samples;
     std::vector<float> samp((size_t)samples * k);
     {

@@ -4,7 +4,7 @@ import sys, time
 sys.path.insert(0, ".")
 import torch
 import multicore_hw2_amd as pkg
-k, n = 16, 1 << 24
+k, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 1 << 24)
 dev = torch.device("cuda:0")
 R = torch.empty(n * k, dtype=torch.float32, device=dev)
 pkg.synth_fill_device(R.data_ptr(), n * k, 1001)

@@ -15,7 +15,7 @@ import multicore_hw2_amd as pkg          # noqa: E402
 from tests.oracle_lib import Oracle      # noqa: E402
 
 
-def run(o, name, k, m, n, check_q, steps=5):
+def run(o, name, k, m, n, check_q, steps=30, warm=10):
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
@@ -33,7 +33,7 @@ def run(o, name, k, m, n, check_q, steps=5):
         pkg.keys_init(keys.data_ptr(), m, stream=stream)
         ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=stream)
         pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), stream=stream)
-    for _ in range(2):
+    for _ in range(warm):   # one batch in flight, serial: a functional check with timing, not the bench
         step()
     torch.cuda.synchronize()
     ix.timing(True)
