@@ -23,6 +23,11 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
 {
     constexpr int KT = 1, QT = 32;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {   // where this wave runs: HW_REG_HW_ID (4) and HW_REG_XCC_ID (20)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        stamps[4096 + blockIdx.x * 4 + (threadIdx.x >> 6)] = ((unsigned long long)xcc << 32) | hw;
+        stamps[8192 + blockIdx.x * 4 + (threadIdx.x >> 6)] = r0;
+    }
     __shared__ float s_thr[QT * 32];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
@@ -241,14 +246,71 @@ static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, co
         if (ms < best) best = ms;
     }
     const double tiles = (double)ntiles * 32;
-    std::vector<unsigned long long> hs(4096);
-    CHK(hipMemcpy(hs.data(), g_stamps, 4096 * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> hs(3 * 4096);
+    CHK(hipMemcpy(hs.data(), g_stamps, 3 * 4096 * 8, hipMemcpyDeviceToHost));
     std::vector<double> clk;
     for (int w = 0; w < 2048; ++w)
         if (hs[2 * w + 1])
             clk.push_back((double)hs[2 * w] / (double)hs[2 * w + 1] * 0.1);   // GHz
     std::sort(clk.begin(), clk.end());
     const double ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+    {   // per-wave wall time (s_memrealtime, 10 ns ticks): how uneven are equal shares of tiles?
+        std::vector<double> dur;
+        for (int w = 0; w < 2048; ++w)
+            if (hs[2 * w + 1])
+                dur.push_back((double)hs[2 * w + 1] * 0.01);   // us
+        std::sort(dur.begin(), dur.end());
+        if (!dur.empty())
+        if (VAR == 0) {   // by XCC, and by how many of the kernel's waves share the SIMD
+            double sum[8] = {0}, cnt[8] = {0};
+            std::vector<unsigned long long> key(2048);
+            for (int w = 0; w < 2048; ++w) {
+                const unsigned hw = (unsigned)hs[4096 + w], xcc = (unsigned)(hs[4096 + w] >> 32) & 7u;
+                sum[xcc] += (double)hs[2 * w + 1] * 0.01;
+                cnt[xcc] += 1;
+                // se[15:13] sh[12] cu[11:8] simd[5:4]
+                key[w] = ((unsigned long long)xcc << 16) | (hw & 0xFF30u);
+            }
+            printf("    by XCC (avg us / waves):");
+            for (int x = 0; x < 8; ++x)
+                printf(" %.0f/%.0f", cnt[x] ? sum[x] / cnt[x] : 0.0, cnt[x]);
+            printf("\n");
+            double s1 = 0, n1 = 0, s2 = 0, n2 = 0, s3 = 0, n3 = 0;
+            for (int w = 0; w < 2048; ++w) {
+                int same = 0;
+                for (int v = 0; v < 2048; ++v)
+                    same += key[v] == key[w];
+                const double d = (double)hs[2 * w + 1] * 0.01;
+                if (same == 1) { s1 += d; n1 += 1; } else if (same == 2) { s2 += d; n2 += 1; } else { s3 += d; n3 += 1; }
+            }
+            {   // deciles, and the two waves of each SIMD: first to finish vs second
+                std::vector<double> dd;
+                for (int w = 0; w < 2048; ++w)
+                    dd.push_back((double)hs[2 * w + 1] * 0.01);
+                std::sort(dd.begin(), dd.end());
+                printf("    deciles us:");
+                for (int q = 0; q <= 10; ++q)
+                    printf(" %.0f", dd[std::min<size_t>(dd.size() - 1, dd.size() * q / 10)]);
+                printf("\n");
+                double fs = 0, ss = 0, np = 0;
+                for (int w = 0; w < 2048; ++w)
+                    for (int v = w + 1; v < 2048; ++v)
+                        if (key[v] == key[w]) {
+                            const double a = (double)hs[2 * w + 1] * 0.01, b = (double)hs[2 * v + 1] * 0.01;
+                            fs += std::min(a, b);
+                            ss += std::max(a, b);
+                            np += 1;
+                        }
+                printf("    SIMD pairs: %.0f, first to finish avg %.0f us, second avg %.0f us\n", np, np ? fs / np : 0.0, np ? ss / np : 0.0);
+            }
+            unsigned long long rmin = ~0ull, rmax = 0;
+            for (int w = 0; w < 2048; ++w) { rmin = std::min(rmin, hs[8192 + w]); rmax = std::max(rmax, hs[8192 + w]); }
+            printf("    waves alone on their SIMD: %.0f (avg %.0f us), two per SIMD: %.0f (avg %.0f us), more: %.0f (avg %.0f us); start spread %.1f us\n",
+                   n1, n1 ? s1 / n1 : 0.0, n2, n2 ? s2 / n2 : 0.0, n3, n3 ? s3 / n3 : 0.0, (double)(rmax - rmin) * 0.01);
+        }
+            printf("    per-wave us: min %.0f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f  (%zu waves)\n", dur.front(),
+                   dur[dur.size() / 10], dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(), dur.size());
+    }
     printf("%-44s %8.3f ms  %7.1f TFLOP/s  %6.1f ns = %5.1f cycles per tile per SIMD at the in-kernel clock %.2f GHz\n", name, best,
            tiles * 32768 / (best * 1e-3) / 1e12, best * 1e6 / (tiles / 1024.0), best * 1e6 / (tiles / 1024.0) * ghz, ghz);
     return 0;
@@ -266,8 +328,8 @@ int main()
     CHK(hipMalloc(&rn, n * 4));
     CHK(hipMalloc(&thr, 1024 * 4));
     CHK(hipMalloc(&sink, 4096));
-    CHK(hipMalloc(&g_stamps, 4096 * 8));
-    CHK(hipMemset(g_stamps, 0, 4096 * 8));
+    CHK(hipMalloc(&g_stamps, 3 * 4096 * 8));
+    CHK(hipMemset(g_stamps, 0, 3 * 4096 * 8));
     CHK(knn_synth_fill_launch(refs, n * 16, 1001, 0, 0));
     CHK(knn_synth_fill_launch(q, 1024 * 16, 1000, 0, 0));
     float *center;
