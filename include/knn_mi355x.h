@@ -43,6 +43,12 @@ extern "C" {
 void cudaCallback(int k, int m, int n, float *searchPoints, float *referencePoints,
                   int **results);
 
+/* The host-input entry points (cudaCallback, knn_index_query_host, knn_index_create from host
+ * rows) keep their device staging buffers in a small per-device pool between calls — hipMalloc +
+ * hipFree cost more than the scan at the reference's test sizes.  At most 8 buffers / 4 GiB per
+ * device; knn_trim() gives them all back to the runtime (returns the number of bytes released). */
+long long knn_trim(void);
+
 /* ------------------------------------------------------------------------
  * 2. Device-resident index API (not in the reference; cudaCallback is
  *    create + query + destroy over all GPUs).  Lets a caller keep the

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 __all__ = ["lib", "lib_path", "cudaCallback", "KnnIndex", "KnnError", "KEY_INIT", "set_option",
-           "get_option", "device_count", "EXPORTED_SYMBOLS", "shard_bounds"]
+           "get_option", "trim", "device_count", "EXPORTED_SYMBOLS", "shard_bounds"]
 
 KEY_INIT = 0x7F80000000000000
 
@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_destroy", "knn_keys_init", "knn_index_query_keys", "knn_keys_to_indices",
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
-    "knn_debug_filter_scores", "knn_index_query_keys_slot",
+    "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -88,6 +88,13 @@ def set_option(name, value):
 
 def get_option(name):
     return lib().knn_get_option(name.encode())
+
+
+def trim():
+    """Release the pooled device staging buffers of the host-input entry points; bytes released."""
+    f = lib().knn_trim
+    f.restype = ctypes.c_longlong
+    return int(f())
 
 
 def shard_bounds(n, shards):

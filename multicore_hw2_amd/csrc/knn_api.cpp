@@ -15,6 +15,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -81,6 +83,72 @@ struct DeviceGuard {
     }
 };
 
+// Staging buffers of the host-input entry points (cudaCallback, knn_index_query_host, indexes created
+// from host rows).  A one-shot call otherwise spends 0.3-0.5 ms in hipMalloc + hipFree (hipFree
+// alone 0.22 ms) around a 0.1-0.4 ms scan at TA scale; the pool keeps up to kPoolSlots freed buffers
+// per device (at most kPoolBytes in total) and hands one back when it is at least as large as, and
+// at most twice, the size asked for.  Buffers are only returned to it after the stream work that
+// used them has been waited for.
+constexpr int kPoolDevices = 64;
+constexpr size_t kPoolSlots = 8;
+constexpr size_t kPoolBytes = 4ull << 30;
+struct PoolEntry {
+    void *p;
+    size_t bytes;
+};
+std::mutex g_pool_mu;
+std::vector<PoolEntry> g_pool[kPoolDevices];
+
+// device `dev` must be current
+hipError_t pool_get(int dev, size_t bytes, void **out)
+{
+    *out = nullptr;
+    if (bytes == 0)
+        bytes = 1;
+    if (dev >= 0 && dev < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        std::vector<PoolEntry> &v = g_pool[dev];
+        size_t best = v.size();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].bytes >= bytes && v[i].bytes / 2 <= bytes && (best == v.size() || v[i].bytes < v[best].bytes))
+                best = i;
+        if (best != v.size()) {
+            *out = v[best].p;
+            v.erase(v.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    return hipMalloc(out, bytes);
+}
+
+// `bytes` = the size the buffer was asked for with (its real size may be larger: that is fine, the
+// pool then under-estimates what it holds by at most 2x)
+void pool_put(int dev, void *p, size_t bytes)
+{
+    if (!p)
+        return;
+    if (bytes == 0)
+        bytes = 1;
+    std::vector<void *> drop;
+    if (dev >= 0 && dev < kPoolDevices && bytes <= kPoolBytes) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        std::vector<PoolEntry> &v = g_pool[dev];
+        size_t held = bytes;
+        for (const PoolEntry &e : v)
+            held += e.bytes;
+        while (!v.empty() && (v.size() >= kPoolSlots || held > kPoolBytes)) {  // oldest first
+            held -= v.front().bytes;
+            drop.push_back(v.front().p);
+            v.erase(v.begin());
+        }
+        v.push_back(PoolEntry{p, bytes});
+    } else {
+        drop.push_back(p);
+    }
+    for (void *d : drop)
+        (void)hipFree(d);
+}
+
 }  // namespace
 
 struct knn_index {
@@ -90,7 +158,8 @@ struct knn_index {
     long long base = 0;
     int num_cu = 256;
     const float *refs = nullptr;  // device, AoS [n][k]
-    float *owned_refs = nullptr;  // set when the index copied the references itself
+    float *owned_refs = nullptr;  // set when the index copied the references itself (pooled)
+    size_t owned_bytes = 0;
     long long stats[4] = {0, 0, 0, 0};
     FilterState filter;           // MFMA filter layouts + workspace (usable == false: exact only)
     int timing = 0;            // 0 off, N > 0: bracket every N-th dominant-kernel launch with events
@@ -105,6 +174,29 @@ extern "C" {
 const char *knn_last_error(void) { return g_err.c_str(); }
 
 const char *knn_version(void) { return "knn_mi355x 0.1 (gfx950)"; }
+
+long long knn_trim(void)
+{
+    long long released = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess)
+        ndev = 0;
+    for (int dev = 0; dev < kPoolDevices && dev < ndev; ++dev) {
+        std::vector<PoolEntry> take;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mu);
+            take.swap(g_pool[dev]);
+        }
+        if (take.empty())
+            continue;
+        DeviceGuard guard(dev);
+        for (const PoolEntry &e : take) {
+            (void)hipFree(e.p);
+            released += (long long)e.bytes;
+        }
+    }
+    return released;
+}
 
 int knn_device_count(void)
 {
@@ -221,7 +313,8 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
             idx->refs = refs;
         } else {
             const size_t bytes = (size_t)n_local * (size_t)k * sizeof(float);
-            hipError_t e = hipMalloc((void **)&idx->owned_refs, bytes);
+            hipError_t e = pool_get(device, bytes, (void **)&idx->owned_refs);
+            idx->owned_bytes = bytes;
             if (e != hipSuccess) {
                 delete idx;
                 return fail(KNN_ENOMEM, "knn_index_create: hipMalloc(refs)", hipGetErrorString(e));
@@ -230,7 +323,8 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
             if (e == hipSuccess)
                 e = hipStreamSynchronize(s);  // the host buffer may be freed right after return
             if (e != hipSuccess) {
-                (void)hipFree(idx->owned_refs);
+                (void)hipStreamSynchronize(s);
+                pool_put(device, idx->owned_refs, bytes);
                 delete idx;
                 return fail(KNN_EHIP, "knn_index_create: H2D copy of refs", hipGetErrorString(e));
             }
@@ -260,8 +354,11 @@ void knn_index_destroy(knn_index *idx)
         return;
     {
         DeviceGuard guard(idx->device);
-        if (idx->owned_refs)
-            (void)hipFree(idx->owned_refs);
+        if (idx->owned_refs) {
+            // the pool must never hand out memory a kernel may still be reading
+            (void)hipDeviceSynchronize();
+            pool_put(idx->device, idx->owned_refs, idx->owned_bytes);
+        }
         knn_filter_free(idx->filter);
         for (auto &ev : idx->events) {
             (void)hipEventDestroy(ev.first);
@@ -436,10 +533,11 @@ int query_keys_host(knn_index *idx, int m, const float *queries_host, u64 *keys_
     float *q_dev = nullptr;
     u64 *keys_dev = nullptr;
     const size_t qbytes = (size_t)m * (size_t)idx->k * sizeof(float);
+    const size_t kbytes = (size_t)m * sizeof(u64);
     int rc = KNN_OK;
-    hipError_t e = hipMalloc((void **)&q_dev, qbytes);
+    hipError_t e = pool_get(idx->device, qbytes, (void **)&q_dev);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&keys_dev, (size_t)m * sizeof(u64));
+        e = pool_get(idx->device, kbytes, (void **)&keys_dev);
     if (e == hipSuccess)
         e = hipMemcpy(q_dev, queries_host, qbytes, hipMemcpyHostToDevice);
     if (e != hipSuccess)
@@ -449,12 +547,14 @@ int query_keys_host(knn_index *idx, int m, const float *queries_host, u64 *keys_
     if (rc == KNN_OK)
         rc = knn_index_query_keys(idx, m, q_dev, keys_dev, nullptr);
     if (rc == KNN_OK) {
-        e = hipMemcpy(keys_host, keys_dev, (size_t)m * sizeof(u64), hipMemcpyDeviceToHost);
+        e = hipMemcpy(keys_host, keys_dev, kbytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
             rc = fail(KNN_EHIP, "query: D2H keys", hipGetErrorString(e));
     }
-    (void)hipFree(q_dev);
-    (void)hipFree(keys_dev);
+    if (rc != KNN_OK)
+        (void)hipDeviceSynchronize();  // nothing in flight may still use the buffers going back to the pool
+    pool_put(idx->device, q_dev, qbytes);
+    pool_put(idx->device, keys_dev, kbytes);
     return rc;
 }
 
@@ -519,13 +619,26 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         // (rates measured on MI355X: 58e12 exact lane-ops/s, ~3.4e-14 s per filtered pair).
         const double pairs = (double)m * (double)(hi - lo);
         const double t_exact = (3.0 * k + 3.0) * pairs / 58e12;
-        const double t_filter = 3e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * pairs + 1e-4;
+        const double t_filter = 1.6e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * pairs + 1e-4;
         const int want_filter = g_opt_path == 2 || (g_opt_path == 0 && m >= 5 && t_filter < t_exact);
+        static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = index_create_impl(&idx, (int)(g % ndev), k, hi - lo,
                                    referencePoints + (size_t)lo * (size_t)k, 0, lo, nullptr, want_filter);
+        const auto t1 = std::chrono::steady_clock::now();
         if (rc == KNN_OK)
             rc = query_keys_host(idx, m, searchPoints, keys.data());
+        const auto t2 = std::chrono::steady_clock::now();
         knn_index_destroy(idx);
+        if (trace) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                return std::chrono::duration<double, std::milli>(b - a).count();
+            };
+            fprintf(stderr, "[knn call] shard %lld rows %lld filter %d: create (alloc + H2D + layouts) %.3f ms, "
+                            "query (stage + scan + D2H) %.3f ms, destroy %.3f ms\n",
+                    g, hi - lo, want_filter, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+        }
         shard_rc[(size_t)g] = rc;
         if (rc != KNN_OK)
             shard_err[(size_t)g] = g_err;

@@ -530,3 +530,22 @@ def test_repeated_filter_launches_never_miss_a_survivor(oracle, k):
                 np.testing.assert_array_equal(got, want, err_msg=f"rep {rep} shape {(m, n)}")
     finally:
         pkg.set_option("path", 0)
+
+
+def test_pooled_staging_buffers_are_reused_and_can_be_trimmed(oracle):
+    """Host-input calls keep their device staging buffers between calls (knn_trim releases them):
+    a sequence of calls with growing, shrinking and equal sizes stays bit-exact, and the pool holds
+    something afterwards."""
+    pkg.trim()
+    rng = np.random.default_rng(99)
+    for (k, m, n) in [(16, 100, 5000), (16, 100, 5000), (3, 1000, 40000), (16, 64, 300), (8, 7, 100000),
+                      (16, 100, 5000), (16, 1024, 70000)]:
+        Q = rng.random((m, k), dtype=np.float32)
+        R = rng.random((n, k), dtype=np.float32)
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0(k, Q, R), err_msg=str((k, m, n)))
+    held = pkg.trim()
+    assert held > 0
+    assert pkg.trim() == 0
+    Q = rng.random((50, 4), dtype=np.float32)
+    R = rng.random((999, 4), dtype=np.float32)
+    np.testing.assert_array_equal(pkg.cudaCallback(4, 50, 999, Q, R), oracle.v0(4, Q, R))
