@@ -124,6 +124,9 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             on a single GPU.
  *   "filter_qt" tuning: query tiles (of 32) each filter wave keeps in registers: 8, 16 or 32
  *             (0 = chosen from m)
+ *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
+ *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
+ *             (shards of at least 32 MiB)
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

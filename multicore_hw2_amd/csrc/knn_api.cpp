@@ -66,6 +66,7 @@ std::atomic<long long> g_opt_shards{0};
 std::atomic<long long> g_opt_filter_qt{0};
 std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
+std::atomic<long long> g_opt_stream{0};
 
 struct DeviceGuard {
     int prev = -1;
@@ -147,6 +148,34 @@ void pool_put(int dev, void *p, size_t bytes)
     }
     for (void *d : drop)
         (void)hipFree(d);
+}
+
+// Two non-blocking streams per device for the streamed one-shot path (created once: a stream costs
+// ~0.1 ms to create, more than a TA-scale call).
+struct DeviceStreams {
+    hipStream_t copy = nullptr, compute = nullptr;
+};
+DeviceStreams g_streams[kPoolDevices];
+
+// device `dev` must be current
+hipError_t streams_get(int dev, DeviceStreams *out)
+{
+    if (dev < 0 || dev >= kPoolDevices)
+        return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    DeviceStreams &d = g_streams[dev];
+    if (!d.copy) {
+        hipError_t e = hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (!d.compute) {
+        hipError_t e = hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            return e;
+    }
+    *out = d;
+    return hipSuccess;
 }
 
 }  // namespace
@@ -234,6 +263,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_filter_chain = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "stream")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: stream must be 0 (auto), 1 (never) or 2 (whenever the shard is >= 32 MiB)");
+        g_opt_stream = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "filter_rounds")) {
         if (value < 0 || value > 64)
             return fail(KNN_EINVAL, "knn_set_option: filter_rounds must be in [0, 64]");
@@ -255,6 +290,8 @@ long long knn_get_option(const char *name)
         return g_opt_filter_rounds;
     if (name && !strcmp(name, "filter_chain"))
         return g_opt_filter_chain;
+    if (name && !strcmp(name, "stream"))
+        return g_opt_stream;
     return -1;
 }
 
@@ -577,6 +614,87 @@ extern "C" int knn_index_query_host(knn_index *idx, int m, const float *queries_
     return KNN_OK;
 }
 
+namespace {
+
+// One shard of a one-shot call, exact kernels only, with the scan hidden under the host-to-device
+// copy: the rows go over in chunks on a copy stream and every chunk is scanned (min-folded into the
+// same keys) on a compute stream as soon as it has landed.  The reference copies everything first
+// (core.cu:885-891) and its own timings are dominated by that copy (README.md:291-292); for
+// k = 16, m <= ~1300 the exact scan of a chunk takes less than its PCIe transfer, so the call
+// costs the transfer plus one chunk's scan.
+int run_shard_streamed(int device, int k, int m, long long rows, long long base, const float *queries_host,
+                       const float *refs_host, u64 *keys_host)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "cudaCallback: hipSetDevice failed");
+    hipDeviceProp_t prop;
+    int num_cu = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        num_cu = prop.multiProcessorCount;
+    DeviceStreams st;
+    HIP_TRY(streams_get(device, &st));
+    const size_t row_bytes = (size_t)k * sizeof(float);
+    const size_t rbytes = (size_t)rows * row_bytes, qbytes = (size_t)m * row_bytes, kbytes = (size_t)m * sizeof(u64);
+    // up to 16 chunks, each 32..128 MiB (pageable copies have a fixed cost of ~0.1 ms each: sixteen
+    // 4 MiB chunks took 6-20 ms where one 64 MiB copy takes 1.3) and a multiple of 1024 rows
+    long long chunk_rows = (rows + 15) / 16;
+    const long long lo_rows = (long long)((32u << 20) / row_bytes) + 1, hi_rows = (long long)((128u << 20) / row_bytes);
+    chunk_rows = std::max(lo_rows, std::min(hi_rows, chunk_rows));
+    chunk_rows = (chunk_rows + 1023) / 1024 * 1024;
+    const long long nchunks = (rows + chunk_rows - 1) / chunk_rows;
+
+    float *r_dev = nullptr, *q_dev = nullptr;
+    u64 *keys_dev = nullptr;
+    std::vector<hipEvent_t> events;
+    hipError_t e = pool_get(device, rbytes, (void **)&r_dev);
+    if (e == hipSuccess)
+        e = pool_get(device, qbytes, (void **)&q_dev);
+    if (e == hipSuccess)
+        e = pool_get(device, kbytes, (void **)&keys_dev);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(q_dev, queries_host, qbytes, hipMemcpyHostToDevice, st.compute);
+    if (e == hipSuccess)
+        e = knn_keys_fill_launch(keys_dev, m, st.compute);
+    for (long long c = 0; c < nchunks && e == hipSuccess; ++c) {
+        const long long r0 = c * chunk_rows, r1 = std::min(rows, r0 + chunk_rows);
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess)
+            break;
+        events.push_back(ev);
+        // pageable source: the call returns once the chunk is staged, while the GPU still scans the
+        // previous one
+        e = hipMemcpyAsync(r_dev + (size_t)r0 * k, refs_host + (size_t)r0 * k, (size_t)(r1 - r0) * row_bytes,
+                           hipMemcpyHostToDevice, st.copy);
+        if (e == hipSuccess)
+            e = hipEventRecord(ev, st.copy);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(st.compute, ev, 0);
+        if (e == hipSuccess)
+            e = knn_exact_launch(k, m, r1 - r0, base + r0, q_dev, r_dev + (size_t)r0 * k, keys_dev, num_cu, nullptr,
+                                 st.compute);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(keys_host, keys_dev, kbytes, hipMemcpyDeviceToHost, st.compute);
+    const hipError_t e_sync1 = hipStreamSynchronize(st.copy);
+    const hipError_t e_sync2 = hipStreamSynchronize(st.compute);
+    if (e == hipSuccess)
+        e = e_sync1 != hipSuccess ? e_sync1 : e_sync2;
+    for (hipEvent_t ev : events)
+        (void)hipEventDestroy(ev);
+    if (e != hipSuccess)
+        (void)hipDeviceSynchronize();  // nothing in flight may still use the buffers going back to the pool
+    pool_put(device, r_dev, rbytes);
+    pool_put(device, q_dev, qbytes);
+    pool_put(device, keys_dev, kbytes);
+    if (e != hipSuccess)
+        return fail(KNN_EHIP, "cudaCallback: streamed shard", hipGetErrorString(e));
+    return KNN_OK;
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------
 // The drop-in entry point (reference core.h:71, core.cu:1282-1297 -> v8, core.cu:856-958).
 // ---------------------------------------------------------------------------------------------
@@ -620,9 +738,30 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         const double pairs = (double)m * (double)(hi - lo);
         const double t_exact = (3.0 * k + 3.0) * pairs / 58e12;
         const double t_filter = 1.6e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * pairs + 1e-4;
-        const int want_filter = g_opt_path == 2 || (g_opt_path == 0 && m >= 5 && t_filter < t_exact);
+        int want_filter = g_opt_path == 2 || (g_opt_path == 0 && m >= 5 && t_filter < t_exact);
         static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
+        // Third option: the exact scan chunk by chunk under the copy (pageable H2D measured at
+        // ~50 GB/s): costs the longer of the two plus one chunk's scan.
+        const double bytes = 4.0 * k * (double)(hi - lo);
+        const double t_h2d = bytes / 50e9;
+        const double nchunks = std::max(std::min(16.0, bytes / (double)(32u << 20)), bytes / (double)(128u << 20));
+        const double t_streamed = std::max(t_h2d, t_exact) + t_exact / nchunks + 1e-4 * nchunks + 1e-4;
+        const double t_staged = t_h2d + (want_filter ? t_filter : t_exact);
+        const bool streamed = g_opt_path != 2 && g_opt_stream != 1 && bytes >= (double)(32u << 20) &&
+                              (g_opt_stream == 2 || t_streamed < t_staged);
+        if (streamed) {
+            const int rc = run_shard_streamed((int)(g % ndev), k, m, hi - lo, lo, searchPoints,
+                                              referencePoints + (size_t)lo * (size_t)k, keys.data());
+            shard_rc[(size_t)g] = rc;
+            if (rc != KNN_OK)
+                shard_err[(size_t)g] = g_err;
+            if (trace)
+                fprintf(stderr, "[knn call] shard %lld rows %lld streamed exact scan: %.3f ms (model: streamed %.3f, staged %.3f)\n",
+                        g, hi - lo, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                        t_streamed * 1e3, t_staged * 1e3);
+            return;
+        }
         int rc = index_create_impl(&idx, (int)(g % ndev), k, hi - lo,
                                    referencePoints + (size_t)lo * (size_t)k, 0, lo, nullptr, want_filter);
         const auto t1 = std::chrono::steady_clock::now();

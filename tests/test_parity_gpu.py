@@ -549,3 +549,20 @@ def test_pooled_staging_buffers_are_reused_and_can_be_trimmed(oracle):
     Q = rng.random((50, 4), dtype=np.float32)
     R = rng.random((999, 4), dtype=np.float32)
     np.testing.assert_array_equal(pkg.cudaCallback(4, 50, 999, Q, R), oracle.v0(4, Q, R))
+
+
+@pytest.mark.parametrize("k,m,n", [(16, 1024, 1200001), (3, 77, 6 << 20), (16, 5, 1 << 20), (33, 130, 700000)])
+def test_streamed_one_shot_scan_matches_v0(oracle, k, m, n):
+    """cudaCallback's chunked path (exact scan of each chunk under the copy of the next): forced on,
+    alone and with the reference set split into several shards, against the staged paths."""
+    Q, R = oracle.synth(m * k, 31), oracle.synth(n * k, 32)
+    R[(n // 2) * k:(n // 2 + 1) * k] = R[:k]          # a duplicate row in a later chunk: lower index must win
+    want = oracle.v0(k, Q, R)
+    try:
+        for stream, shards in [(2, 0), (2, 3), (1, 0), (0, 0)]:
+            pkg.set_option("stream", stream)
+            pkg.set_option("shards", shards)
+            np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), want, err_msg=f"stream={stream} shards={shards}")
+    finally:
+        pkg.set_option("stream", 0)
+        pkg.set_option("shards", 0)
