@@ -6,11 +6,13 @@ The product is ``libknn_mi355x.so`` (hand-written HIP for gfx950 + a C-ABI, see
 ``include/knn_mi355x.h``).  This package only binds it with ctypes so that tests and
 ``bench.py`` drive exactly the entry points a C/C++ caller would.  There is no CPU fallback:
 importing works anywhere, but every compute entry raises if the library is missing or no GPU
-is visible.  PyTorch is *not* imported here; callers that hold torch tensors pass
-``tensor.data_ptr()`` / ``torch.cuda.current_stream().cuda_stream``.
+is visible.  PyTorch is plumbing only: callers that hold torch tensors pass ``tensor.data_ptr()`` /
+``torch.cuda.current_stream().cuda_stream``; ``lib()`` imports torch (when installed) just before the
+dlopen so the process ends up with one HIP runtime whatever the import order was.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -46,6 +48,15 @@ def lib():
     if not os.path.exists(lib_path):
         raise KnnError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
+    # A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64 (same SONAME as
+    # the system one this library is linked against): whichever is mapped first serves both, but if
+    # the system one came first torch later finds "No HIP GPUs".  So when torch is installed it is
+    # imported before the dlopen — tests, bench.py and smoke() share device memory with it anyway.
+    if "torch" not in sys.modules and os.environ.get("KNN_MI355X_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(lib_path)
     c_int, c_ll, c_vp, c_ull = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_ulonglong
     L.cudaCallback.argtypes = [c_int, c_int, c_int, c_vp, c_vp, ctypes.POINTER(ctypes.POINTER(c_int))]
