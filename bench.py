@@ -240,8 +240,8 @@ def main():
         roof["kernel_avg_ms"] = kern_avg_ms
         roof["kernel_launches_timed"] = launches
         chain = pkg.get_option("filter_chain") if hasattr(pkg, "get_option") else 0
-        roof["launches_overlap"] = bool(path_taken == 2 and nstreams > 1 and
-                                        (chain == 2 or (chain == 0 and n_local < (1 << 23))))
+        roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or
+                                                          (chain == 0 and n_local < (1 << 23))))
         if roof["launches_overlap"]:
             roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
                            "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \
