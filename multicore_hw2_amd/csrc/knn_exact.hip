@@ -568,13 +568,23 @@ hipError_t launch_rlane_k(int k, int m, long long n, long long base, const float
     constexpr int QT = 4;
     if (K == 16 && m <= 2 * QT && n >= 4096 && ((uintptr_t)r & 15u) == 0) {
         // HBM-bound shape: LDS-staged, fully coalesced reference tiles
-        const unsigned gy = (unsigned)knn_divup(m, QT);
+        // query tile sized to the batch: a lone query should not pay for four (the spare VALU work
+        // costs power, hence clock, hence bandwidth)
+        const int qt16 = m == 1 ? 1 : m == 2 ? 2 : QT;
+        const unsigned gy = (unsigned)knn_divup(m, qt16);
         long long gx = (n + KNN_BLOCK - 1) / KNN_BLOCK;
         const long long capx = (long long)num_cu * 8 / gy;
         if (gx > capx)
             gx = capx;
-        hipLaunchKernelGGL((knn_exact_rlane16<QT>), dim3((unsigned)gx, gy), dim3(KNN_BLOCK), 0, s, q,
-                           (const f4x *)r, m, n, base, keys, gate);
+        if (qt16 == 1)
+            hipLaunchKernelGGL((knn_exact_rlane16<1>), dim3((unsigned)gx, gy), dim3(KNN_BLOCK), 0, s, q,
+                               (const f4x *)r, m, n, base, keys, gate);
+        else if (qt16 == 2)
+            hipLaunchKernelGGL((knn_exact_rlane16<2>), dim3((unsigned)gx, gy), dim3(KNN_BLOCK), 0, s, q,
+                               (const f4x *)r, m, n, base, keys, gate);
+        else
+            hipLaunchKernelGGL((knn_exact_rlane16<QT>), dim3((unsigned)gx, gy), dim3(KNN_BLOCK), 0, s, q,
+                               (const f4x *)r, m, n, base, keys, gate);
         return hipGetLastError();
     }
     unsigned qt = (unsigned)knn_divup(m, QT);
