@@ -567,3 +567,20 @@ def test_streamed_one_shot_scan_matches_v0(oracle, k, m, n):
     finally:
         pkg.set_option("stream", 0)
         pkg.set_option("shards", 0)
+
+
+def test_randomised_differential_cases_against_the_oracle(oracle):
+    """tools/fuzz_parity.py, 80 seeded cases: random k, m, n, data distribution (ties, clusters, heavy
+    tails, offsets, a stray NaN/Inf), forced path, shard count and one-shot strategy."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                               "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = np.random.default_rng(2026)
+    try:
+        for case in range(80):
+            assert fuzz.one_case(oracle, rng, case), case
+    finally:
+        for name in ("path", "shards", "stream"):
+            pkg.set_option(name, 0)

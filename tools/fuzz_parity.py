@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the drop-in entry against the CPU oracle: random shapes,
+distributions, paths, shard counts and one-shot strategies.  usage: fuzz_parity.py [cases] [seed]
+Exit status 1 on the first mismatch (prints the case so it can be replayed)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import multicore_hw2_amd as pkg              # noqa: E402
+from tests.oracle_lib import Oracle           # noqa: E402
+
+
+def make_data(rng, kind, rows, k):
+    if kind == "uniform":
+        return rng.random((rows, k), dtype=np.float32)
+    if kind == "gauss":
+        return rng.normal(0, 1, (rows, k)).astype(np.float32)
+    if kind == "offset":
+        return (rng.random((rows, k), dtype=np.float32) * np.float32(rng.choice([1e-3, 1.0, 50.0])) +
+                np.float32(rng.choice([-1e4, 3.0, 1e5]))).astype(np.float32)
+    if kind == "grid":            # few distinct values: many exact ties
+        return rng.integers(0, 4, (rows, k)).astype(np.float32)
+    if kind == "clusters":
+        c = rng.random((8, k), dtype=np.float32)
+        return (c[rng.integers(0, 8, rows)] + rng.normal(0, 1e-3, (rows, k))).astype(np.float32)
+    if kind == "heavy":
+        x = rng.normal(0, 1, (rows, k)) / np.sqrt(np.maximum(rng.random((rows, 1)), 1e-4))
+        return x.astype(np.float32)
+    raise ValueError(kind)
+
+
+def one_case(o, rng, case):
+    k = int(rng.choice([1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 32, 33, 48, 64, 100, 128, 130]))
+    m = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 100, 257, 1000, 1024, 2049]))
+    n = int(rng.choice([1, 2, 31, 33, 1000, 4097, 65535, 65536, 70001, 200000, 600000]))
+    if k * n > 40_000_000 or k * m * n > 3e11:
+        n = max(1, min(n, 40_000_000 // k, int(3e11 // (k * m))))
+    kind = str(rng.choice(["uniform", "gauss", "offset", "grid", "clusters", "heavy"]))
+    path = int(rng.choice([0, 0, 1, 2]))
+    shards = int(rng.choice([0, 0, 2, 5]))
+    stream = int(rng.choice([0, 1, 2]))
+    R = make_data(rng, kind, n, k)
+    Q = make_data(rng, kind, m, k)
+    if rng.random() < 0.3 and n > 4:              # some queries coincide with references
+        Q[: min(m, 8)] = R[rng.integers(0, n, min(m, 8))]
+    if rng.random() < 0.1:
+        R[rng.integers(0, n), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3e38]))
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, path=path, shards=shards, stream=stream)
+    pkg.set_option("path", path)
+    pkg.set_option("shards", shards)
+    pkg.set_option("stream", stream)
+    got = pkg.cudaCallback(k, m, n, Q, R)
+    want = o.v0(k, Q, R)
+    if not (got == want).all():
+        j = int(np.flatnonzero(got != want)[0])
+        print("MISMATCH", desc, "query", j, "got", int(got[j]), "want", int(want[j]), flush=True)
+        return False
+    return True
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    try:
+        for case in range(cases):
+            if not one_case(o, rng, case):
+                return 1
+            if case % 25 == 24:
+                print("%d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
+    finally:
+        for name in ("path", "shards", "stream"):
+            pkg.set_option(name, 0)
+    print("all %d cases bit-exact (seed %d)" % (cases, seed))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
