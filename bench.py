@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--filter-rounds", type=int, default=0, help="tuning: filter blocks per resident slot (0 default)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight (1..4), each on its own stream / workspace slot; 0 = 2 for shards of "
-                         ">= 8M references (scans chained), 3 below (scans free to overlap)")
+                         ">= 16M references (scans chained), 3 below (scans free to overlap)")
     ap.add_argument("--filter-chain", type=int, default=0, help="0 auto, 1 scans of different slots chained, 2 free")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every N-th launch of the dominant kernel with HIP events (roofline.kernel_avg_ms)")
@@ -113,7 +113,7 @@ def main():
     # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
     # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
-    inflight = args.inflight if args.inflight > 0 else (2 if n_local >= (1 << 23) else 3)
+    inflight = args.inflight if args.inflight > 0 else (2 if n_local >= (1 << 24) else 3)
     nbuf = 1 if args.serial else max(1, min(4, inflight))
     keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(nbuf)]
     outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(nbuf)]
@@ -241,7 +241,7 @@ def main():
         roof["kernel_launches_timed"] = launches
         chain = pkg.get_option("filter_chain") if hasattr(pkg, "get_option") else 0
         roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or
-                                                          (chain == 0 and n_local < (1 << 23))))
+                                                          (chain == 0 and n_local < (1 << 24))))
         if roof["launches_overlap"]:
             roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
                            "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \

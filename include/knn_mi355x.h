@@ -130,7 +130,7 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the
- *             shard is >= 8M references, where overlapping scans slow each other down)
+ *             shard is >= 16M references: a launch's duration then stays that of the kernel alone)
  * Returns KNN_EINVAL for an unknown name or value. */
 int knn_set_option(const char *name, long long value);
 long long knn_get_option(const char *name);

@@ -1268,10 +1268,11 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
     // 3. the filter proper (timed: the dominant kernel).  Ordered after the other slot's scan.
     if (!st.scan_done)
         FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
-    // Scans of different slots: one after the other when they are long (two 256-VGPR kernels sharing
-    // the SIMDs run ~15 % slower each, and the per-launch duration stays meaningful); free to overlap
-    // when they are short (heads fill the other's tail, no event round trip: -17 % per step at n = 2M).
-    const bool no_chain = st.chain_policy == 2 || (st.chain_policy == 0 && st.ntiles < (1ll << 18));
+    // Scans of different slots: free to overlap (heads fill the other's tail, no event round trip:
+    // -17 % per step at n = 2M, -5 % at 8M, -2.5 % at 16M with three batches in flight) unless the
+    // shard is >= 16M rows, where they are chained so that a launch's duration stays that of the kernel
+    // itself (the roofline is quoted from it; two 256-VGPR scans sharing the SIMDs take ~1.7x as long each).
+    const bool no_chain = st.chain_policy == 2 || (st.chain_policy == 0 && st.ntiles < (1ll << 19));
     if (st.scan_recorded && !no_chain)
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
@@ -1336,10 +1337,11 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     FTRY(hipGetLastError());
     if (!st.scan_done)
         FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
-    // Scans of different slots: one after the other when they are long (two 256-VGPR kernels sharing
-    // the SIMDs run ~15 % slower each, and the per-launch duration stays meaningful); free to overlap
-    // when they are short (heads fill the other's tail, no event round trip: -17 % per step at n = 2M).
-    const bool no_chain = st.chain_policy == 2 || (st.chain_policy == 0 && st.ntiles < (1ll << 18));
+    // Scans of different slots: free to overlap (heads fill the other's tail, no event round trip:
+    // -17 % per step at n = 2M, -5 % at 8M, -2.5 % at 16M with three batches in flight) unless the
+    // shard is >= 16M rows, where they are chained so that a launch's duration stays that of the kernel
+    // itself (the roofline is quoted from it; two 256-VGPR scans sharing the SIMDs take ~1.7x as long each).
+    const bool no_chain = st.chain_policy == 2 || (st.chain_policy == 0 && st.ntiles < (1ll << 19));
     if (st.scan_recorded && !no_chain)
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
