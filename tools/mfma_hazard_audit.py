@@ -6,8 +6,8 @@ states between the MFMA and the first VALU instruction that reads (or overwrites
 When the reader sat in a LATER basic block (a per-step `if (hit)` branch between them) the
 inserted s_nops only made up 6, and with no other MFMA in between the accumulator was read
 stale about once in 60 launches (k = 17, last query tile of a group: wrong nearest index).
-The kernels now keep MFMA and reader in one block; this audit walks every function in
-fall-through order and reports any MFMA result touched by a VALU/memory instruction fewer than
+The kernels now keep MFMA and reader in one block; this audit follows every path from each MFMA
+(fall-through and taken branches) and reports any MFMA result touched by a VALU/memory instruction fewer than
 NEED wait states later, so a future edit that re-introduces the pattern fails on the CPU.
 
 usage: mfma_hazard_audit.py file.s [need=12]   (file.s from `hipcc -S --cuda-device-only`)
@@ -29,50 +29,84 @@ def _regs(tok):
 
 
 def audit(text, need=NEED):
-    """-> list of (function, wait_states, mfma_line, reader_line) violations."""
-    ins = []
+    """-> (violations, number of MFMAs audited); a violation is (function, wait_states, mfma_line,
+    reader_line).  Every path from an MFMA is followed — fall-through AND taken branches — until
+    `need` wait states have gone by, the result has been overwritten, or the function ends."""
+    ins = []          # (line, kind, text): kind FUNC | LABEL | I
     for ln, raw in enumerate(text.split("\n"), 1):
         s = raw.strip()
         if re.match(r"^_Z\w+:", s):
             ins.append((ln, "FUNC", s.split(":")[0]))
+            continue
+        m = re.match(r"^(\.LBB[\w.]+):", s)
+        if m:
+            ins.append((ln, "LABEL", m.group(1)))
             continue
         if not s or s[0] in ";." or s.endswith(":"):
             continue
         s = s.split(";")[0].strip()
         if s:
             ins.append((ln, "I", s))
+    label_at = {t: i for i, (_, kind, t) in enumerate(ins) if kind == "LABEL"}
     found, cur, n_mfma = [], None, 0
     for i, (ln, kind, s) in enumerate(ins):
         if kind == "FUNC":
             cur = s
             continue
-        if not s.startswith("v_mfma"):
+        if kind != "I" or not s.startswith("v_mfma"):
             continue
         n_mfma += 1
         dst = _regs(s.split(None, 1)[1].split(", ")[0])
-        states = 0
-        for ln2, k2, s2 in ins[i + 1:i + 60]:
-            if k2 == "FUNC" or s2.startswith(("s_endpgm", "s_branch", "s_setpc")):
-                break
-            if s2.startswith("v_mfma"):
-                o2 = s2.split(None, 1)[1].split(", ")
-                if _regs(o2[0]) & dst:
-                    break  # accumulate chain / overwritten by the next MFMA: the XDL rule, not this one
-                states += 1
-                continue
-            if s2.startswith("s_nop"):
-                states += int(s2.split()[1]) + 1
-                continue
-            if s2.startswith(("v_", "global_", "ds_", "buffer_", "flat_", "scratch_")):
-                touched = _regs(s2.split(None, 1)[1]) if " " in s2 else set()
-                if touched & dst:
-                    if states < need:
-                        found.append((cur, states, ln, ln2))
+        work = [(i + 1, 0)]
+        seen = {}
+        while work:
+            j, states = work.pop()
+            while j < len(ins) and states < need:
+                if seen.get(j, need + 1) <= states:
+                    break  # reached before with no more wait states behind it
+                seen[j] = states
+                ln2, k2, s2 = ins[j]
+                if k2 == "FUNC":
                     break
-            states += 1
-            if states >= need:
-                break
-    return found, n_mfma
+                if k2 == "LABEL":
+                    j += 1
+                    continue
+                if s2.startswith(("s_endpgm", "s_setpc", "s_trap")):
+                    break
+                if s2.startswith("s_branch"):
+                    t = label_at.get(s2.split()[1])
+                    if t is None:
+                        break
+                    states += 1
+                    j = t
+                    continue
+                if s2.startswith("s_cbranch"):
+                    t = label_at.get(s2.split()[-1])
+                    if t is not None:
+                        work.append((t, states + 1))
+                    states += 1
+                    j += 1
+                    continue
+                if s2.startswith("v_mfma"):
+                    o2 = s2.split(None, 1)[1].split(", ")
+                    if _regs(o2[0]) & dst:
+                        break  # accumulate chain / overwritten by the next MFMA: the XDL rule, not this one
+                    states += 1
+                    j += 1
+                    continue
+                if s2.startswith("s_nop"):
+                    states += int(s2.split()[1]) + 1
+                    j += 1
+                    continue
+                if s2.startswith(("v_", "global_", "ds_", "buffer_", "flat_", "scratch_")):
+                    touched = _regs(s2.split(None, 1)[1]) if " " in s2 else set()
+                    if touched & dst:
+                        if states < need:
+                            found.append((cur, states, ln, ln2))
+                        break
+                states += 1
+                j += 1
+    return sorted(set(found)), n_mfma
 
 
 if __name__ == "__main__":
