@@ -126,6 +126,36 @@ def test_filter_kernels_keep_mfma_results_12_wait_states_from_their_readers(tmp_
     assert not bad, bad[:5]
 
 
+
+def test_hazard_audit_sees_a_short_cross_block_read_and_accepts_a_padded_one():
+    """The audit itself: a hand-written ISA fragment with an MFMA result read 3 wait states later
+    through a not-taken branch is reported; the same fragment padded with s_nop is not; a reader
+    reached only through the TAKEN branch is reported too."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import mfma_hazard_audit
+    finally:
+        sys.path.pop(0)
+    frag = """
+_Z4testv:
+	v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]
+	v_cmp_lt_f32_e32 vcc, v30, v31
+	s_cbranch_vccnz .LBB0_2
+.LBB0_1:
+%s	v_min3_f32 v32, v0, v1, v2
+	s_endpgm
+.LBB0_2:
+%s	v_add_f32_e32 v33, v15, v15
+	s_branch .LBB0_1
+"""
+    bad, n = mfma_hazard_audit.audit(frag % ("", "\ts_nop 11\n"))
+    assert n == 1 and [b[1] for b in bad] == [2], bad          # fall-through reader, 2 wait states
+    bad, n = mfma_hazard_audit.audit(frag % ("\ts_nop 9\n", ""))
+    assert [b[1] for b in bad] == [2], bad                        # reader behind the taken branch
+    bad, n = mfma_hazard_audit.audit(frag % ("\ts_nop 9\n", "\ts_nop 9\n"))
+    assert not bad, bad
+
+
 WORKER = r"""
 import os, sys
 import numpy as np
