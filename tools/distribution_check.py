@@ -39,10 +39,24 @@ def make(name):
         return torch.randn(m, 4, device=dev, generator=g) @ b, torch.randn(n, 4, device=dev, generator=g) @ b
     if name == "offset_1e4":
         return (torch.rand(m, k, device=dev, generator=g) + 1e4), (torch.rand(n, k, device=dev, generator=g) + 1e4)
+    if name == "mixture1000":     # 1000 Gaussian blobs, sigma 0.05 of the box: embedding-like, not degenerate
+        c = torch.rand(1000, k, device=dev, generator=g)
+        r = c[torch.randint(0, 1000, (n,), device=dev, generator=g)] + 0.05 * torch.randn(n, k, device=dev, generator=g)
+        q = c[torch.randint(0, 1000, (m,), device=dev, generator=g)] + 0.05 * torch.randn(m, k, device=dev, generator=g)
+        return q, r
+    if name == "unit_sphere":     # L2-normalised rows (cosine-similarity style data)
+        r = torch.randn(n, k, device=dev, generator=g)
+        q = torch.randn(m, k, device=dev, generator=g)
+        return q / q.norm(dim=1, keepdim=True), r / r.norm(dim=1, keepdim=True)
+    if name == "bytes_0_255":     # integer-valued descriptors (SIFT-like): exact ties are common
+        r = torch.randint(0, 256, (n, k), device=dev, generator=g).float()
+        q = torch.randint(0, 256, (m, k), device=dev, generator=g).float()
+        return q, r
     raise ValueError(name)
 
 
-for name in ["uniform", "gaussian", "heavy_tail", "clusters64", "low_rank", "offset_1e4"]:
+for name in ["uniform", "gaussian", "heavy_tail", "clusters64", "low_rank", "offset_1e4", "mixture1000", "unit_sphere",
+             "bytes_0_255"]:
     q_d, r_d = make(name)
     q_d, r_d = q_d.float().contiguous(), r_d.float().contiguous()
     keys = torch.empty(m, dtype=torch.int64, device=dev)
