@@ -115,8 +115,11 @@ def main():
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
     inflight = args.inflight if args.inflight > 0 else (2 if n_local >= (1 << 24) else 3)
     nbuf = 1 if args.serial else max(1, min(4, inflight))
-    keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(nbuf)]
-    outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    # Key / result buffers: [group][batch]; without a collective only group 0 is used.
+    keys_all = torch.empty((2, nbuf, m), dtype=torch.int64, device=dev)
+    outs_all = torch.empty((2, nbuf, m), dtype=torch.int32, device=dev)
+    keys = [keys_all[0, b] for b in range(nbuf)]
+    outs = [outs_all[0, b] for b in range(nbuf)]
     t0 = time.perf_counter()
     index = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo,
                          refs_on_device=True, stream=stream)
@@ -124,37 +127,56 @@ def main():
     prep_ms = (time.perf_counter() - t0) * 1e3
     nstreams = nbuf
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    pending = [None] * nbuf   # in-flight all-reduce of each buffer
+    # N > 1: the exchange step.  The nbuf batches in flight form a group whose packed keys are
+    # min-reduced over the ranks by ONE all-reduce (nbuf x m keys) on a stream of its own, followed by
+    # one unpack; the next group's scans run meanwhile on the batch streams (two groups of buffers).
+    # A collective per batch cost ~10 us of stream round trips even on one rank, comparable to the
+    # 85 us step of a 2M-row shard.
+    reduce_stream = torch.cuda.Stream(device=dev) if dist is not None else None
+    group_done = [None, None]      # event: group g's buffers hold final indices and may be reused
+    batch_done = [None] * nbuf     # events of the current group's scans
+    state = {"filled": 0, "group": 0, "last": (0, 0)}
 
-    def finish(b):
-        """Complete the step that used buffer b: wait for its all-reduce (stream-side), unpack."""
-        if pending[b] is not None:
-            st = streams[b % nstreams]
-            with torch.cuda.stream(st):
-                pending[b].wait()
-                pending[b] = None
-                pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank,
-                                    stream=st.cuda_stream)
+    def flush_group():
+        """All-reduce + unpack the batches enqueued so far in the current group."""
+        g, filled = state["group"], state["filled"]
+        if dist is None or filled == 0:
+            return
+        for b in range(filled):
+            reduce_stream.wait_event(batch_done[b])
+        with torch.cuda.stream(reduce_stream):
+            # keys < 2^63 (distance bits of a non-negative float): int64 MIN == unsigned MIN
+            dist.all_reduce(keys_all[g, :filled], op=dist.ReduceOp.MIN)
+            pkg.keys_to_indices(keys_all[g].data_ptr(), filled * m, outs_all[g].data_ptr(), device=local_rank,
+                                stream=reduce_stream.cuda_stream)
+            group_done[g] = reduce_stream.record_event()
+        state["group"], state["filled"] = g ^ 1, 0
 
     def step(i):
-        b = i % nbuf
+        b = state["filled"] if dist is not None else i % nbuf
         st = streams[b % nstreams]
-        finish(b)                      # buffer b was last used by step i-nbuf
         with torch.cuda.stream(st):
-            pkg.keys_init(keys[b].data_ptr(), m, device=local_rank, stream=st.cuda_stream)
-            index.query_keys(m, q_d.data_ptr(), keys[b].data_ptr(), stream=st.cuda_stream, slot=b)
             if dist is not None:
-                # keys < 2^63 (distance bits of a non-negative float): int64 MIN == unsigned MIN
-                pending[b] = dist.all_reduce(keys[b], op=dist.ReduceOp.MIN, async_op=True)
+                g = state["group"]
+                if group_done[g] is not None:
+                    st.wait_event(group_done[g])     # the previous use of these buffers is complete
+                kb, ob = keys_all[g, b], outs_all[g, b]
             else:
-                pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), device=local_rank,
-                                    stream=st.cuda_stream)
-        if dist is not None and nbuf > 1:
-            finish((i - 1) % nbuf)     # step i-1: its all-reduce ran beside this step's scan
+                g, kb, ob = 0, keys[b], outs[b]
+            pkg.keys_init(kb.data_ptr(), m, device=local_rank, stream=st.cuda_stream)
+            index.query_keys(m, q_d.data_ptr(), kb.data_ptr(), stream=st.cuda_stream, slot=b)
+            if dist is not None:
+                batch_done[b] = st.record_event()
+            else:
+                pkg.keys_to_indices(kb.data_ptr(), m, ob.data_ptr(), device=local_rank, stream=st.cuda_stream)
+        state["last"] = (g, b)
+        if dist is not None:
+            state["filled"] += 1
+            if state["filled"] == nbuf:
+                flush_group()
 
     def drain():
-        for b in range(nbuf):
-            finish(b)
+        flush_group()
 
     def fence():
         if dist is not None:
@@ -200,7 +222,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     qps = m * args.steps / elapsed
     stats = index.last_stats()
-    result_idx = outs[(args.steps - 1) % nbuf].cpu().numpy()
+    result_idx = outs_all[state["last"][0], state["last"][1]].cpu().numpy()
 
     if rank == 0:
         kern_avg_ms = kern_ms / max(launches, 1)
@@ -267,7 +289,8 @@ def main():
                        "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "batches_in_flight": nstreams, "setup_steps": SETUP_STEPS,
-                       "collective": "rccl all_reduce(min) of %d packed keys" % m if world > 1 else None},
+                       "collective": ("rccl all_reduce(min) of %d x %d packed keys per %d batches" % (nbuf, m, nbuf))
+                       if world > 1 else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if parity:
