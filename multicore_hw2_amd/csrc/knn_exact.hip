@@ -521,8 +521,10 @@ struct SliceGeom {
     unsigned nslices;
 };
 
-// Slice the references so the grid has ~8 blocks per CU (each block 4 waves) but a slice is
-// never shorter than `min_refs` (below that the per-block atomics and query loads dominate).
+// Slice the references so the grid has ~20 blocks per CU (each block 4 waves) but a slice is
+// never shorter than `min_refs` rows.  32 rows, not more: a block walks its slice serially at
+// ~0.6 us per row (4 queries per lane), so 512-row slices put a 0.3 ms floor under every launch
+// with n <= 2.6M — (16, 1024, 1024) took 0.42 ms, 0.10 ms with 32-row slices.
 SliceGeom slice_refs(long long n, unsigned qgroups, int num_cu, long long min_refs)
 {
     long long want = (long long)num_cu * 20 / (qgroups ? qgroups : 1);  // 4-5 rounds of blocks: small tail
@@ -544,17 +546,17 @@ hipError_t launch_qreg_k(int m, long long n, long long base, const float *q, con
     // queries per block: 1024 (QP=2) when m fills most of it, else 512 (QP=1), else 256 (unpacked)
     if (m > 3 * KNN_WAVE * KNN_WAVES) {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 4 * KNN_WAVE);
-        const SliceGeom g = slice_refs(n, qg, num_cu, 512);
+        const SliceGeom g = slice_refs(n, qg, num_cu, 32);
         hipLaunchKernelGGL((knn_exact_qreg<K, 2>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
                            m, n, base, keys, g.refs_per_block, gate);
     } else if (m > KNN_WAVE * KNN_WAVES) {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 2 * KNN_WAVE);
-        const SliceGeom g = slice_refs(n, qg, num_cu, 512);
+        const SliceGeom g = slice_refs(n, qg, num_cu, 32);
         hipLaunchKernelGGL((knn_exact_qreg<K, 1>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
                            m, n, base, keys, g.refs_per_block, gate);
     } else {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * KNN_WAVE);
-        const SliceGeom g = slice_refs(n, qg, num_cu, 512);
+        const SliceGeom g = slice_refs(n, qg, num_cu, 32);
         hipLaunchKernelGGL((knn_exact_qreg1<K>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r, m,
                            n, base, keys, g.refs_per_block, gate);
     }
