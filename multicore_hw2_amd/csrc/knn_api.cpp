@@ -17,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -91,7 +92,7 @@ struct DeviceGuard {
 // at most twice, the size asked for.  Buffers are only returned to it after the stream work that
 // used them has been waited for.
 constexpr int kPoolDevices = 64;
-constexpr size_t kPoolSlots = 8;
+constexpr size_t kPoolSlots = 64;
 constexpr size_t kPoolBytes = 4ull << 30;
 struct PoolEntry {
     void *p;
@@ -150,6 +151,46 @@ void pool_put(int dev, void *p, size_t bytes)
         (void)hipFree(d);
 }
 
+std::unordered_map<void *, std::pair<int, size_t>> g_live;  // pooled buffers handed to the filter code
+
+}  // namespace
+
+hipError_t knn_dev_alloc(void **p, size_t bytes)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    e = pool_get(dev, bytes, p);
+    if (e == hipSuccess && *p) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_live[*p] = std::make_pair(dev, bytes);
+    }
+    return e;
+}
+
+hipError_t knn_dev_free(void *p)
+{
+    if (!p)
+        return hipSuccess;
+    std::pair<int, size_t> info(-1, 0);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) {
+            info = it->second;
+            g_live.erase(it);
+        }
+    }
+    if (info.first < 0)
+        return hipFree(p);
+    (void)hipDeviceSynchronize();  // hipFree's implicit wait: nothing may still be using the buffer
+    pool_put(info.first, p, info.second);
+    return hipSuccess;
+}
+
+namespace {
+
 // Two non-blocking streams per device for the streamed one-shot path (created once: a stream costs
 // ~0.1 ms to create, more than a TA-scale call).
 struct DeviceStreams {
@@ -196,6 +237,7 @@ struct knn_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // one pair per timed launch
     size_t events_used = 0;
     int last_slot = 0;
+    bool filter_wanted = false;  // the creator asked for the filter layouts explicitly (one-shot cost model)
 };
 
 extern "C" {
@@ -369,6 +411,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
         }
     }
     // MFMA filter layouts (skipped for small shards and when the exact path is forced)
+    idx->filter_wanted = build_filter > 0;
     if (build_filter < 0)
         build_filter = g_opt_path == 2 || n_local >= 65536;
     if (n_local > 0 && g_opt_path != 1 && build_filter) {
@@ -447,7 +490,8 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         ev = &idx->events[idx->events_used++];
     }
     const long long path = g_opt_path;
-    const bool use_filter = idx->filter.usable && (path == 2 || (path == 0 && m >= 5 && idx->n >= 65536));
+    const bool use_filter = idx->filter.usable &&
+                            (path == 2 || (path == 0 && m >= 5 && (idx->n >= 65536 || idx->filter_wanted)));
     if (use_filter) {
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;
@@ -735,9 +779,15 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         // One-shot call: the filter layouts cost two extra passes over the shard plus a few
         // allocations, so build them only where that is cheaper than the exact VALU scan
         // (rates measured on MI355X: 58e12 exact lane-ops/s, ~3.4e-14 s per filtered pair).
+        // The exact rate holds for the compile-time dimensions (queries in registers, scalar row
+        // loads); any other k runs the generic row-per-lane kernel at ~5e12 (measured: (17, 5000,
+        // 300000) 12.6 ms, (128, 1024, 300000) 34.7 ms).  The filter costs kt MFMAs per tile pair.
         const double pairs = (double)m * (double)(hi - lo);
-        const double t_exact = (3.0 * k + 3.0) * pairs / 58e12;
-        const double t_filter = 1.6e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * pairs + 1e-4;
+        const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
+        const double t_exact = (3.0 * k + 3.0) * pairs / (fast_k || m < 48 ? 58e12 : 5e12);
+        const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+        const double t_filter = k > 128 ? 1e30
+                                        : 1.0e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * kt * pairs + 1e-4;
         int want_filter = g_opt_path == 2 || (g_opt_path == 0 && m >= 5 && t_filter < t_exact);
         static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();

@@ -94,6 +94,10 @@ struct FilterState {
 
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
 // (and returns hipSuccess) when the data rules the filter out.
+// pooled device memory for the CURRENT device (knn_api.cpp); knn_dev_free waits for the device first
+hipError_t knn_dev_alloc(void **p, size_t bytes);
+hipError_t knn_dev_free(void *p);
+
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.

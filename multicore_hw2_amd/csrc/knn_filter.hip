@@ -26,6 +26,17 @@
 // the gated exact kernels scan everything instead: results are bit-exact either way.
 #include "knn_common.h"
 
+// Device buffers of an index come from the library's pool (knn_api.cpp): a one-shot cudaCallback that
+// builds the filter layouts makes ~20 allocations, and hipMalloc + hipFree (a device-wide sync and
+// ~0.2 ms each) cost more than its kernels.  Stand-alone tools that include this file define KNN_NO_POOL.
+#ifdef KNN_NO_POOL
+#define KNN_DEV_ALLOC(p, bytes) hipMalloc(p, bytes)
+#define KNN_DEV_FREE(p) hipFree(p)
+#else
+#define KNN_DEV_ALLOC(p, bytes) knn_dev_alloc((void **)(p), bytes)
+#define KNN_DEV_FREE(p) knn_dev_free((void *)(p))
+#endif
+
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -87,24 +98,41 @@ __global__ __launch_bounds__(256) void knn_ref_stats_kernel(const float *__restr
     const long long threads = (long long)gridDim.x * blockDim.x;
     const long long stride = threads / k * k;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gtid >= stride)
-        return;
     const int d = (int)(gtid % k);
     float lo = INFINITY, hi = -INFINITY;
     unsigned bad = 0;
-    for (long long e = gtid; e < count; e += stride) {
+    for (long long e = gtid < stride ? gtid : count; e < count; e += stride) {
         const float v = R[e];
         if (!(fabsf(v) < INFINITY))
             ++bad;
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
     }
+    // fold the block in LDS first (k <= 128): one guarded global atomic per dimension per block —
+    // per-thread atomics on the same 2k words ran at the single-word rate (1.4 ms for a 20 MB shard)
+    __shared__ unsigned s_lo[128], s_hi[128], s_bad;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        s_lo[i] = 0xFFFFFFFFu;
+        s_hi[i] = 0u;
+    }
+    if (threadIdx.x == 0)
+        s_bad = 0u;
+    __syncthreads();
     if (lo <= hi) {
-        guarded_atomic_min(&stats[d], f2ord(lo));
-        guarded_atomic_max(&stats[k + d], f2ord(hi));
+        atomicMin(&s_lo[d], f2ord(lo));
+        atomicMax(&s_hi[d], f2ord(hi));
     }
     if (bad)
-        atomicAdd(&stats[2 * k], bad);
+        atomicAdd(&s_bad, bad);
+    __syncthreads();
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        if (s_lo[i] != 0xFFFFFFFFu)
+            guarded_atomic_min(&stats[i], s_lo[i]);
+        if (s_hi[i] != 0u)
+            guarded_atomic_max(&stats[k + i], s_hi[i]);
+    }
+    if (threadIdx.x == 0 && s_bad)
+        atomicAdd(&stats[2 * k], s_bad);
 }
 
 // Same, 16 bytes per lane per step (k % 4 == 0, 16-byte aligned rows): every lane keeps four fixed
@@ -945,22 +973,22 @@ static const float kAmaxLimit = 1024.0f;           // queries far outside the re
 
 void knn_filter_free(FilterState &st)
 {
-    (void)hipFree(st.center);
-    (void)hipFree(st.ref_frags);
-    (void)hipFree(st.ref_norms);
-    (void)hipFree(st.outliers);
+    (void)KNN_DEV_FREE(st.center);
+    (void)KNN_DEV_FREE(st.ref_frags);
+    (void)KNN_DEV_FREE(st.ref_norms);
+    (void)KNN_DEV_FREE(st.outliers);
     if (st.scan_done)
         (void)hipEventDestroy(st.scan_done);
     for (FilterWorkspace &w : st.ws) {
-        (void)hipFree(w.qry_frags);
-        (void)hipFree(w.qry_norms);
-        (void)hipFree(w.qry_amax);
-        (void)hipFree(w.thr);
-        (void)hipFree(w.ctl);
-        (void)hipFree(w.records);
-        (void)hipFree(w.counts);
-        (void)hipFree(w.umin);
-        (void)hipFree(w.qpart);
+        (void)KNN_DEV_FREE(w.qry_frags);
+        (void)KNN_DEV_FREE(w.qry_norms);
+        (void)KNN_DEV_FREE(w.qry_amax);
+        (void)KNN_DEV_FREE(w.thr);
+        (void)KNN_DEV_FREE(w.ctl);
+        (void)KNN_DEV_FREE(w.records);
+        (void)KNN_DEV_FREE(w.counts);
+        (void)KNN_DEV_FREE(w.umin);
+        (void)KNN_DEV_FREE(w.qpart);
     }
     st = FilterState();
 }
@@ -991,7 +1019,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     }
     hstats[(size_t)2 * k] = 0u;
     unsigned *dstats = nullptr;
-    FTRY(hipMalloc((void **)&dstats, hstats.size() * sizeof(unsigned)));
+    FTRY(KNN_DEV_ALLOC((void **)&dstats, hstats.size() * sizeof(unsigned)));
     hipError_t e = hipMemcpyAsync(dstats, hstats.data(), hstats.size() * sizeof(unsigned),
                                   hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
@@ -1006,26 +1034,26 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         e = hipMemcpyAsync(hstats.data(), dstats, hstats.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);
-    (void)hipFree(dstats);
+    (void)KNN_DEV_FREE(dstats);
     FTRY(e);
     lap("range kernel + sync");
     if (hstats[(size_t)2 * k] != 0u)
         return hipSuccess;  // NaN / Inf among the references: exact path only
 
     // 1b. robust box: per dimension [median - w s, median + w s] clipped to [min, max], with
-    // s = 1.4826 * MAD from a strided sample of up to 4096 rows (median/MAD do not move when a few rows sit
+    // s = 1.4826 * MAD from a strided sample of up to 1024 rows (median/MAD do not move when a few rows sit
     // 300 sigma out; mean/std do).  A few far-out rows would otherwise stretch the box, and with it
     // the fp16 step, for everybody.  ANY box is correct: rows outside it leave the filter and are
     // scanned exactly on every query, so the box is only worth it if it leaves out a handful of
     // rows — w doubles from 12 until at most 1 % of the sample falls outside (heavy tails), and a
     // second mode further out than 96 s (more than 1 % of the rows) keeps the plain [min, max].
-    const long long want = k <= 16 ? 4096 : 65536 / k;  // host work stays ~1 ms at any k
+    const long long want = k <= 16 ? 1024 : (16384 / k > 256 ? 16384 / k : 256);  // host work ~0.2 ms at any k
     const long long samples = n < want ? n : want;
     const long long row_stride = n / samples;
     std::vector<float> samp((size_t)samples * k);
     {
         float *dsamp = nullptr;
-        FTRY(hipMalloc((void **)&dsamp, samp.size() * sizeof(float)));
+        FTRY(KNN_DEV_ALLOC((void **)&dsamp, samp.size() * sizeof(float)));
         hipLaunchKernelGGL(knn_sample_rows_kernel, dim3((unsigned)((samples * k + 255) / 256)), dim3(256), 0, s, r, k,
                            row_stride, samples, dsamp);
         e = hipGetLastError();
@@ -1033,7 +1061,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
             e = hipMemcpyAsync(samp.data(), dsamp, samp.size() * sizeof(float), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess)
             e = hipStreamSynchronize(s);
-        (void)hipFree(dsamp);
+        (void)KNN_DEV_FREE(dsamp);
         FTRY(e);
         lap("sample rows + copy");
     }
@@ -1104,16 +1132,16 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     st.ntiles = ntiles;
     st.sigma = sigma;
     unsigned *dout = nullptr;
-    e = hipMalloc((void **)&st.center, (size_t)kp * sizeof(float));
+    e = KNN_DEV_ALLOC((void **)&st.center, (size_t)kp * sizeof(float));
     if (e == hipSuccess)
-        e = hipMalloc(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
+        e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+        e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
     const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);  // more outliers than this: no filter
     if (e == hipSuccess)
-        e = hipMalloc((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
+        e = KNN_DEV_ALLOC((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
     if (e == hipSuccess)
-        e = hipMalloc((void **)&dout, 4 * sizeof(unsigned));
+        e = KNN_DEV_ALLOC((void **)&dout, 4 * sizeof(unsigned));
     if (e == hipSuccess)
         e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), s);
     if (e == hipSuccess)
@@ -1137,7 +1165,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);  // also keeps `center` alive until the copy is done
     lap("fragment kernel + sync");
-    (void)hipFree(dout);
+    (void)KNN_DEV_FREE(dout);
     if (e != hipSuccess) {
         knn_filter_free(st);
         return e;
@@ -1156,31 +1184,31 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
 static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
 {
     if (!w.ctl)
-        FTRY(hipMalloc((void **)&w.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
     if (!w.records) {
-        FTRY(hipMalloc((void **)&w.records, (size_t)kRecordCapacity * sizeof(u64)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.records, (size_t)kRecordCapacity * sizeof(u64)));
         w.rec_cap = kRecordCapacity;
     }
     if (!w.counts)
-        FTRY(hipMalloc((void **)&w.counts, (size_t)kMaxLists * sizeof(unsigned)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.counts, (size_t)kMaxLists * sizeof(unsigned)));
     if (m > w.m_cap) {
-        (void)hipFree(w.qry_frags);
-        (void)hipFree(w.qry_norms);
-        (void)hipFree(w.thr);
+        (void)KNN_DEV_FREE(w.qry_frags);
+        (void)KNN_DEV_FREE(w.qry_norms);
+        (void)KNN_DEV_FREE(w.thr);
         w.qry_frags = nullptr;
         w.qry_norms = nullptr;
         w.thr = nullptr;
         w.m_cap = 0;
         const size_t qtiles = (size_t)(m + 31) / 32;
-        FTRY(hipMalloc(&w.qry_frags, qtiles * st.kt * 64 * 16));
-        FTRY(hipMalloc((void **)&w.qry_norms, qtiles * 32 * sizeof(float)));
-        (void)hipFree(w.qry_amax);
+        FTRY(KNN_DEV_ALLOC(&w.qry_frags, qtiles * st.kt * 64 * 16));
+        FTRY(KNN_DEV_ALLOC((void **)&w.qry_norms, qtiles * 32 * sizeof(float)));
+        (void)KNN_DEV_FREE(w.qry_amax);
         w.qry_amax = nullptr;
-        FTRY(hipMalloc((void **)&w.qry_amax, qtiles * 32 * sizeof(float)));
-        FTRY(hipMalloc((void **)&w.thr, qtiles * 32 * sizeof(float)));
-        (void)hipFree(w.qpart);
+        FTRY(KNN_DEV_ALLOC((void **)&w.qry_amax, qtiles * 32 * sizeof(float)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.thr, qtiles * 32 * sizeof(float)));
+        (void)KNN_DEV_FREE(w.qpart);
         w.qpart = nullptr;
-        FTRY(hipMalloc((void **)&w.qpart, 3 * ((qtiles * 32 + 255) / 256) * sizeof(unsigned)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.qpart, 3 * ((qtiles * 32 + 255) / 256) * sizeof(unsigned)));
         w.m_cap = (int)(qtiles * 32);
     }
     return hipSuccess;
@@ -1247,10 +1275,10 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
     {   // per-block minima buffer, grown on demand
         const size_t need = (size_t)sb * (size_t)m_padded;
         if (need > w.umin_cap) {
-            (void)hipFree(w.umin);
+            (void)KNN_DEV_FREE(w.umin);
             w.umin = nullptr;
             w.umin_cap = 0;
-            FTRY(hipMalloc((void **)&w.umin, need * sizeof(float)));
+            FTRY(KNN_DEV_ALLOC((void **)&w.umin, need * sizeof(float)));
             w.umin_cap = need;
         }
     }
@@ -1320,10 +1348,10 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     {
         const size_t need = (size_t)sb * (size_t)m_padded;
         if (need > w.umin_cap) {
-            (void)hipFree(w.umin);
+            (void)KNN_DEV_FREE(w.umin);
             w.umin = nullptr;
             w.umin_cap = 0;
-            FTRY(hipMalloc((void **)&w.umin, need * sizeof(float)));
+            FTRY(KNN_DEV_ALLOC((void **)&w.umin, need * sizeof(float)));
             w.umin_cap = need;
         }
     }

@@ -2,6 +2,7 @@
 // epilogue on the production data path (same fragment layout, loads and pipelining as
 // knn_filter_kernel), timed on synthetic data.  Results are NOT checked: this tool only prices
 // instruction mixes.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o filter_probe filter_probe.hip
+#define KNN_NO_POOL
 #include "../multicore_hw2_amd/csrc/knn_filter.hip"
 #include "../multicore_hw2_amd/csrc/knn_exact.hip"
 #include <algorithm>
