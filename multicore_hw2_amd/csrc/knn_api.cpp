@@ -412,8 +412,13 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     }
     // MFMA filter layouts (skipped for small shards and when the exact path is forced)
     idx->filter_wanted = build_filter > 0;
-    if (build_filter < 0)
-        build_filter = g_opt_path == 2 || n_local >= 65536;
+    if (build_filter < 0) {
+        // library policy: shards of >= 65536 rows; for dimensions the exact kernels have no
+        // compile-time form for (they run ~10x slower there) already from 4096 rows
+        const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
+        build_filter = g_opt_path == 2 || n_local >= 65536 || (!fast_k && k <= 128 && n_local >= 4096);
+        idx->filter_wanted = build_filter && n_local < 65536 && g_opt_path != 2;
+    }
     if (n_local > 0 && g_opt_path != 1 && build_filter) {
         hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s);
         if (e != hipSuccess) {

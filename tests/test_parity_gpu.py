@@ -584,3 +584,25 @@ def test_randomised_differential_cases_against_the_oracle(oracle):
     finally:
         for name in ("path", "shards", "stream"):
             pkg.set_option(name, 0)
+
+
+@pytest.mark.parametrize("k,expect_filter", [(17, True), (16, False), (100, True)])
+def test_index_policy_builds_the_filter_early_for_dimensions_without_a_compiled_exact_kernel(oracle, k, expect_filter):
+    """Resident index of 20000 rows: k = 16 has compile-time exact kernels (no filter below 65536
+    rows); k = 17 / 100 would run the generic row-per-lane kernel ~10x slower, so the MFMA filter is
+    built and used from 4096 rows.  Either way indices are bit-exact."""
+    m, n = 600, 20000
+    Q, R = oracle.synth(m * k, 41), oracle.synth(n * k, 42)
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    pkg.keys_init(keys.data_ptr(), m)
+    ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+    pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+    torch.cuda.synchronize()
+    path_taken = ix.last_stats()[0]
+    ix.close()
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R))
+    assert (path_taken == 2) == expect_filter, path_taken
