@@ -27,10 +27,9 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
                                    const unsigned *gate, hipStream_t stream);
 
 // Exact re-rank of the filter's candidate records (see knn_rerank_kernel).
-hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev,
-                             long long base, const u64 *rec_dev, const unsigned *counts_dev,
-                             unsigned nlists, unsigned slice, unsigned *ctl_dev, u64 *keys_dev,
-                             hipStream_t stream);
+hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
+                             const u64 *records, const unsigned short *record_rows, const unsigned *counts,
+                             unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, hipStream_t stream);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
@@ -60,6 +59,7 @@ struct FilterWorkspace {
     float *thr = nullptr;      // device [qtiles*32]
     unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
     u64 *records = nullptr;    // device [rec_cap]: nlists slices of `slice` records, one per wave
+    bool has_rows = false;     // the last scan wrote a row mask next to every record
     unsigned rec_cap = 0;
     unsigned *counts = nullptr;// device [nlists]: records each wave produced (may exceed slice)
     unsigned nlists = 0, slice = 0;

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                                                                const float *__restrict__ R, int krt,
                                                                long long n, long long base,
                                                                const u64 *__restrict__ rec,
+                                                               const unsigned short *__restrict__ rec_rows,
                                                                const unsigned *__restrict__ counts,
                                                                unsigned slice, unsigned *__restrict__ ctl,
                                                                u64 *__restrict__ keys)
@@ -424,7 +425,9 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
             qi = (unsigned)(e >> 32);
             const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
             const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
-            if (ri < n) {
+            // rows the filter already proved to be above the threshold are not the answer: skip them
+            const unsigned rmask = rec_rows ? rec_rows[(size_t)blockIdx.x * slice + (c >> 4)] : 0xFFFFu;
+            if (ri < n && ((rmask >> reg) & 1u)) {
                 const float *__restrict__ q = Q + (size_t)qi * k;
                 const float *__restrict__ r = R + (size_t)ri * k;
                 float acc = 0.0f;
@@ -477,6 +480,80 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
         }
         // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
         if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+            key_atomic_min(&keys[qi], key);
+    }
+}
+
+// Re-rank for records that carry a row mask (deep-K filter): ONE THREAD per record walks the set bits
+// of its mask.  With the 16-lanes-per-record form above only ~1 lane in 16 had a row to evaluate
+// (the mask usually has a single bit), and at k = 128 a row is a serial chain of 128 subtract /
+// multiply / add steps: 0.33 ms for C5's 640k records, most lanes idle.
+template <int K>
+__device__ __forceinline__ float v0_row_distance(const float *__restrict__ q, const float *__restrict__ r, int krt)
+{
+#pragma clang fp contract(off)
+    const int k = K > 0 ? K : krt;
+    float acc = 0.0f;
+    int d = 0;
+    for (; d + 16 <= k; d += 16) {  // chunks of 16 with all 32 loads in flight; order stays d = 0..k-1
+        float qv[16], rv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            qv[j] = q[d + j];
+            rv[j] = r[d + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float diff = qv[j] - rv[j];
+            const float sq = diff * diff;
+            acc = acc + sq;
+        }
+    }
+    for (; d < k; ++d) {
+        const float diff = q[d] - r[d];
+        const float sq = diff * diff;
+        acc = acc + sq;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_rows_kernel(const float *__restrict__ Q,
+                                                                    const float *__restrict__ R, int k,
+                                                                    long long n, long long base,
+                                                                    const u64 *__restrict__ rec,
+                                                                    const unsigned short *__restrict__ rec_rows,
+                                                                    const unsigned *__restrict__ counts,
+                                                                    unsigned slice, unsigned *__restrict__ ctl,
+                                                                    u64 *__restrict__ keys)
+{
+    if (ctl[KNN_CTL_FALLBACK] != 0u)
+        return;
+    const unsigned want = counts[blockIdx.x];
+    const unsigned nrec = min(want, slice);
+    if (threadIdx.x == 0 && want > slice)
+        ctl[KNN_CTL_FALLBACK] = 1u;
+    const u64 *__restrict__ list = rec + (size_t)blockIdx.x * slice;
+    const unsigned short *__restrict__ rows = rec_rows + (size_t)blockIdx.x * slice;
+    for (unsigned c = threadIdx.x; c < nrec; c += KNN_BLOCK) {
+        const u64 e = list[c];
+        unsigned rm = rows[c];
+        const unsigned qi = (unsigned)(e >> 32);
+        const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
+        const float *__restrict__ q = Q + (size_t)qi * k;
+        u64 key = ~0ull;
+        while (rm) {
+            const unsigned reg = (unsigned)__builtin_ctz(rm);
+            rm &= rm - 1u;
+            const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+            if (ri < n) {
+                const float acc = v0_row_distance<0>(q, R + (size_t)ri * k, k);
+                if (acc < INFINITY) {  // false for NaN too: v0 never selects those
+                    const u64 cand = pack_key(acc, (unsigned)(base + ri));
+                    key = cand < key ? cand : key;
+                }
+            }
+        }
+        if (key != ~0ull && key < keys[qi])
             key_atomic_min(&keys[qi], key);
     }
 }
@@ -663,14 +740,19 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
 }
 
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
-                             const u64 *rec, const unsigned *counts, unsigned nlists, unsigned slice,
-                             unsigned *ctl, u64 *keys, hipStream_t s)
+                             const u64 *rec, const unsigned short *rec_rows, const unsigned *counts,
+                             unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, hipStream_t s)
 {
     if (nlists == 0)
         return hipSuccess;
+    if (rec_rows) {
+        hipLaunchKernelGGL(knn_rerank_rows_kernel, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows,
+                           counts, slice, ctl, keys);
+        return hipGetLastError();
+    }
 #define KNN_RERANK(KK)                                                                                     \
-    hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, counts, \
-                       slice, ctl, keys)
+    hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows, \
+                       counts, slice, ctl, keys)
     switch (k) {
     case 3: KNN_RERANK(3); break;
     case 4: KNN_RERANK(4); break;

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_tiled_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, long long stride,
     float *__restrict__ umin, int m_padded, u64 *__restrict__ rec, unsigned *__restrict__ counts,
-    unsigned *__restrict__ ctl, unsigned slice)
+    unsigned *__restrict__ ctl, unsigned slice, unsigned short *__restrict__ rec_rows)
 {
     constexpr int WAVES = FILTER_BLOCK / 64;
     constexpr int CHUNKS = KT * 64;                 // 16-byte chunks of A per tile
@@ -748,6 +748,9 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_tiled_kernel(
     }
     const size_t list = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wib;
     u64 *__restrict__ my_rec = SAMPLE ? nullptr : rec + list * slice;
+    // which of the lane's 16 rows are under the threshold: the re-rank reads only those (at k = 128 a
+    // record's 16 rows are 8 KiB; without the mask the re-rank of C5's 640k records cost as much as the scan)
+    unsigned short *__restrict__ my_rows = SAMPLE ? nullptr : rec_rows + list * slice;
     unsigned cnt = 0u;
 
     if (i0 < i1) {
@@ -818,9 +821,15 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_tiled_kernel(
                         if (hit) {
                             const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            if (pos < slice)
+                            if (pos < slice) {
                                 my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) |
                                               ((u64)(i * stride) << 1) | (u64)(lane >> 5);
+                                unsigned rm = 0u;
+#pragma unroll
+                                for (int r16 = 0; r16 < 16; ++r16)
+                                    rm |= x[r16] < th[t] ? (1u << r16) : 0u;
+                                my_rows[pos] = (unsigned short)rm;
+                            }
                         }
                         cnt += (unsigned)__popcll(mask);
                     }
@@ -1186,7 +1195,8 @@ static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
     if (!w.ctl)
         FTRY(KNN_DEV_ALLOC((void **)&w.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
     if (!w.records) {
-        FTRY(KNN_DEV_ALLOC((void **)&w.records, (size_t)kRecordCapacity * sizeof(u64)));
+        // 8-byte records followed by their 2-byte row masks (written by the deep-K kernel only)
+        FTRY(KNN_DEV_ALLOC((void **)&w.records, (size_t)kRecordCapacity * (sizeof(u64) + sizeof(unsigned short))));
         w.rec_cap = kRecordCapacity;
     }
     if (!w.counts)
@@ -1253,6 +1263,7 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
         return hipErrorInvalidValue;
     w.nlists = gx * 4 * gy;
     w.slice = w.rec_cap / w.nlists;
+    w.has_rows = false;
 
     // 1. sample pass over every stride-th tile (about 1/16 of the shard) -> per-query minima
     long long stride = st.ntiles / 256;
@@ -1357,7 +1368,8 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     }
     hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, true>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
                        (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                       stride, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice);
+                       stride, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                       (unsigned short *)(w.records + w.rec_cap));
     FTRY(hipGetLastError());
     hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
                        (int)sb, w.qry_norms, w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
@@ -1376,7 +1388,9 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         FTRY(hipEventRecord(w.ev_begin, s));
     hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                        (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                       1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice);
+                       1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                       (unsigned short *)(w.records + w.rec_cap));
+    w.has_rows = true;
     FTRY(hipGetLastError());
     if (w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));
@@ -1426,7 +1440,9 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
         break;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
-    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records, w.counts, w.nlists, w.slice, w.ctl, keys, s));
+    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records,
+                           w.has_rows ? (const unsigned short *)(w.records + w.rec_cap) : nullptr, w.counts, w.nlists,
+                           w.slice, w.ctl, keys, s));
     // rows outside the robust box never entered the filter: exact scan of that (short) list
     FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
