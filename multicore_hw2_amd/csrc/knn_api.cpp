@@ -413,10 +413,9 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     // MFMA filter layouts (skipped for small shards and when the exact path is forced)
     idx->filter_wanted = build_filter > 0;
     if (build_filter < 0) {
-        // library policy: shards of >= 65536 rows; for dimensions the exact kernels have no
-        // compile-time form for (they run ~10x slower there) already from 4096 rows
-        const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
-        build_filter = g_opt_path == 2 || n_local >= 65536 || (!fast_k && k <= 128 && n_local >= 4096);
+        // library policy: shards of >= 65536 rows; for 32 < k <= 128 (3k+3 exact lane-ops per pair,
+        // one query per lane above k = 64) the MFMA filter pays off from 4096 rows already
+        build_filter = g_opt_path == 2 || n_local >= 65536 || (k > 32 && k <= 128 && n_local >= 4096);
         idx->filter_wanted = build_filter && n_local < 65536 && g_opt_path != 2;
     }
     if (n_local > 0 && g_opt_path != 1 && build_filter) {
@@ -783,13 +782,14 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         knn_index *idx = nullptr;
         // One-shot call: the filter layouts cost two extra passes over the shard plus a few
         // allocations, so build them only where that is cheaper than the exact VALU scan
-        // (rates measured on MI355X: 58e12 exact lane-ops/s, ~3.4e-14 s per filtered pair).
-        // The exact rate holds for the compile-time dimensions (queries in registers, scalar row
-        // loads); any other k runs the generic row-per-lane kernel at ~5e12 (measured: (17, 5000,
-        // 300000) 12.6 ms, (128, 1024, 300000) 34.7 ms).  The filter costs kt MFMAs per tile pair.
+        // (~3.4e-14 s per filtered pair and K-step).
+        // Exact rates measured on MI355X (lane-ops/s): compile-time K 58e12; run-time k in chunks of 16
+        // (knn_exact_qregn) ~45e12 packed (k <= 64), ~22e12 one query per lane (k <= 128); beyond that,
+        // and for m < 48 at any k, the row-per-lane kernels.  The filter costs kt MFMAs per tile pair.
         const double pairs = (double)m * (double)(hi - lo);
         const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
-        const double t_exact = (3.0 * k + 3.0) * pairs / (fast_k || m < 48 ? 58e12 : 5e12);
+        const double exact_rate = (fast_k || m < 48) ? 58e12 : k <= 64 ? 45e12 : k <= 128 ? 22e12 : 5e12;
+        const double t_exact = (3.0 * k + 3.0) * pairs / exact_rate;
         const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
         const double t_filter = k > 128 ? 1e30
                                         : 1.0e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * kt * pairs + 1e-4;

@@ -130,6 +130,105 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restr
     }
 }
 
+// Any k up to 16*KC without a compile-time K: the same scheme (queries in VGPRs, rows through
+// wave-uniform scalar loads), dimensions in chunks of 16 with the last chunk guarded by uniform
+// branches.  PACK = two queries per lane as a float2 (KC <= 4), else one (KC <= 8, k <= 128).  The
+// generic row-per-lane kernel runs ~10x below this for m >= 48.
+template <bool PACK> struct QregLane;
+template <> struct QregLane<true> {
+    typedef f2 T;
+    static __device__ __forceinline__ f2 make(float a, float b) { return (f2){a, b}; }
+    static __device__ __forceinline__ float second(const f2 &v) { return v.y; }
+    static __device__ __forceinline__ float first(const f2 &v) { return v.x; }
+};
+template <> struct QregLane<false> {
+    typedef float T;
+    static __device__ __forceinline__ float make(float a, float) { return a; }
+    static __device__ __forceinline__ float second(const float &) { return INFINITY; }
+    static __device__ __forceinline__ float first(const float &v) { return v; }
+};
+
+template <int KC, bool PACK>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qregn(const float *__restrict__ Q,
+                                                             const float *__restrict__ R, int k, int m,
+                                                             long long n, long long base,
+                                                             u64 *__restrict__ keys,
+                                                             long long refs_per_block,
+                                                             const unsigned *__restrict__ gate)
+{
+#pragma clang fp contract(off)
+    if (gate && *gate == 0u)
+        return;
+    typedef QregLane<PACK> L;
+    typedef typename L::T T;
+    constexpr int KM = 16 * KC;
+    constexpr int QL = PACK ? 2 : 1;  // queries per lane
+    const int lane = threadIdx.x & (KNN_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q0 = (blockIdx.y * KNN_WAVES + wave) * (QL * KNN_WAVE);
+    if (q0 >= m)
+        return;
+    const int qa = min(q0 + lane, m - 1);
+    const int qb = min(q0 + KNN_WAVE + lane, m - 1);
+    T q[KM];
+#pragma unroll
+    for (int d = 0; d < KM; ++d)
+        q[d] = L::make(d < k ? Q[(size_t)qa * k + d] : 0.0f, PACK && d < k ? Q[(size_t)qb * k + d] : 0.0f);
+    float best0 = INFINITY, best1 = INFINITY;
+    unsigned bidx0 = 0u, bidx1 = 0u;
+
+    const long long i0 = (long long)blockIdx.x * refs_per_block;
+    const long long i1 = min(n, i0 + refs_per_block);
+    unsigned gidx = (unsigned)(base + i0);
+    const float *__restrict__ r = R + (size_t)i0 * k;
+    for (long long i = i0; i < i1; ++i, ++gidx, r += k) {
+        T acc = L::make(0.0f, 0.0f);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int rem = k - 16 * c;  // wave-uniform
+            if (rem >= 16) {
+                float rv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    rv[j] = r[16 * c + j];  // wave-uniform address -> scalar loads
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const T diff = q[16 * c + j] - L::make(rv[j], rv[j]);
+                    const T sq = diff * diff;
+                    acc = acc + sq;
+                }
+            } else if (rem > 0) {
+#pragma unroll
+                for (int j = 0; j < 15; ++j)
+                    if (j < rem) {
+                        const float rj = r[16 * c + j];
+                        const T diff = q[16 * c + j] - L::make(rj, rj);
+                        const T sq = diff * diff;
+                        acc = acc + sq;
+                    }
+            }
+        }
+        if (best0 > L::first(acc)) {
+            best0 = L::first(acc);
+            bidx0 = gidx;
+        }
+        if (PACK && best1 > L::second(acc)) {
+            best1 = L::second(acc);
+            bidx1 = gidx;
+        }
+    }
+    if (q0 + lane < m && best0 < INFINITY) {
+        const u64 key = pack_key(best0, bidx0);
+        if (key < keys[q0 + lane])
+            key_atomic_min(&keys[q0 + lane], key);
+    }
+    if (PACK && q0 + KNN_WAVE + lane < m && best1 < INFINITY) {
+        const u64 key = pack_key(best1, bidx1);
+        if (key < keys[q0 + KNN_WAVE + lane])
+            key_atomic_min(&keys[q0 + KNN_WAVE + lane], key);
+    }
+}
+
 // One query per lane, no packing: m in [~48, 128*KNN_WAVES) where pairs would idle lanes.
 template <int K>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__restrict__ Q,
@@ -700,6 +799,28 @@ hipError_t knn_exact_launch(int k, int m, long long n, long long base, const flo
         case 8: return launch_qreg_k<8>(m, n, base, q, r, keys, num_cu, gate, s);
         case 16: return launch_qreg_k<16>(m, n, base, q, r, keys, num_cu, gate, s);
         default: break;
+        }
+        if (k <= 128 && n >= 2048) {  // no compile-time K: chunked run-time-k form of the same kernel
+            // (below ~2k rows its query prologue, 16*KC loads per lane, costs more than the scan)
+            const int kc = (k + 15) / 16;
+            const bool pack = kc <= 4;
+            const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * (pack ? 2 : 1) * KNN_WAVE);
+            const SliceGeom g = slice_refs(n, qg, num_cu, 32);
+            const dim3 grid(g.nslices, qg), block(KNN_BLOCK);
+#define KNN_QREGN(KCV, PK)                                                                                  \
+    hipLaunchKernelGGL((knn_exact_qregn<KCV, PK>), grid, block, 0, s, q, r, k, m, n, base, keys, g.refs_per_block, gate)
+            switch (kc) {
+            case 1: KNN_QREGN(1, true); break;
+            case 2: KNN_QREGN(2, true); break;
+            case 3: KNN_QREGN(3, true); break;
+            case 4: KNN_QREGN(4, true); break;
+            case 5: KNN_QREGN(5, false); break;
+            case 6: KNN_QREGN(6, false); break;
+            case 7: KNN_QREGN(7, false); break;
+            default: KNN_QREGN(8, false); break;
+            }
+#undef KNN_QREGN
+            return hipGetLastError();
         }
     }
     switch (k) {
