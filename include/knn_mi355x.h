@@ -45,7 +45,7 @@ void cudaCallback(int k, int m, int n, float *searchPoints, float *referencePoin
 
 /* The host-input entry points (cudaCallback, knn_index_query_host, knn_index_create from host
  * rows) keep their device staging buffers in a small per-device pool between calls — hipMalloc +
- * hipFree cost more than the scan at the reference's test sizes.  At most 8 buffers / 4 GiB per
+ * hipFree cost more than the scan at the reference's test sizes.  At most 64 buffers / 4 GiB per
  * device; knn_trim() gives them all back to the runtime (returns the number of bytes released). */
 long long knn_trim(void);
 
