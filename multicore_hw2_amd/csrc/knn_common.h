@@ -27,9 +27,18 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
                                    const unsigned *gate, hipStream_t stream);
 
 // Exact re-rank of the filter's candidate records (see knn_rerank_kernel).
+// Record lists [list_base[i], list_base[i+1]) belong to piece i of the batch, whose records number their
+// queries from qrow_base[i] (see plan_pieces in knn_filter.hip); unused entries have list_base = ~0.
+struct RerankPieces {
+    unsigned list_base[4] = {0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    unsigned qrow_base[4] = {0u, 0u, 0u, 0u};
+    int n = 1;
+};
+
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
                              const u64 *records, const unsigned short *record_rows, const unsigned *counts,
-                             unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, hipStream_t stream);
+                             unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
+                             hipStream_t stream);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
@@ -59,6 +68,7 @@ struct FilterWorkspace {
     float *thr = nullptr;      // device [qtiles*32]
     unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
     u64 *records = nullptr;    // device [rec_cap]: nlists slices of `slice` records, one per wave
+    RerankPieces pieces;
     bool has_rows = false;     // the last scan wrote a row mask next to every record
     unsigned rec_cap = 0;
     unsigned *counts = nullptr;// device [nlists]: records each wave produced (may exceed slice)

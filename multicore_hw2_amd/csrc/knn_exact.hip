@@ -497,10 +497,15 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                                                                const unsigned short *__restrict__ rec_rows,
                                                                const unsigned *__restrict__ counts,
                                                                unsigned slice, unsigned *__restrict__ ctl,
-                                                               u64 *__restrict__ keys)
+                                                               u64 *__restrict__ keys, RerankPieces pieces)
 {
 #pragma clang fp contract(off)
-    // one block per record list (= per filter wave)
+    // one block per record list (= per filter wave); the list's piece gives its first query
+    unsigned qrow_base = pieces.qrow_base[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (blockIdx.x >= pieces.list_base[i])
+            qrow_base = pieces.qrow_base[i];
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;  // the exact scan is going to run anyway: do not re-rank a truncated candidate set
     const int k = K > 0 ? K : krt;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
         if (c < nrec * 16u) {
             const u64 e = list[c >> 4];
             const unsigned reg = c & 15u;
-            qi = (unsigned)(e >> 32);
+            qi = (unsigned)(e >> 32) + qrow_base;
             const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
             const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
             // rows the filter already proved to be above the threshold are not the answer: skip them
@@ -862,18 +867,19 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
 
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
                              const u64 *rec, const unsigned short *rec_rows, const unsigned *counts,
-                             unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, hipStream_t s)
+                             unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
+                             hipStream_t s)
 {
     if (nlists == 0)
         return hipSuccess;
-    if (rec_rows) {
+    if (rec_rows) {  // deep-K scans are never cut into pieces
         hipLaunchKernelGGL(knn_rerank_rows_kernel, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows,
                            counts, slice, ctl, keys);
         return hipGetLastError();
     }
 #define KNN_RERANK(KK)                                                                                     \
     hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows, \
-                       counts, slice, ctl, keys)
+                       counts, slice, ctl, keys, pieces)
     switch (k) {
     case 3: KNN_RERANK(3); break;
     case 4: KNN_RERANK(4); break;

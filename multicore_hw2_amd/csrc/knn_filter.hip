@@ -597,13 +597,17 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : 2)) void k
     const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
     unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
 {
+    // One launch covers a PIECE of the batch: `qtiles` query tiles in groups of QT; qfg / thrg / rec /
+    // counts arrive already offset to the piece and records carry piece-relative query numbers (the
+    // re-rank adds the piece's first query: one more live value in this kernel costs it 6 %) (a batch is cut into pieces
+    // with different QT so that a ragged tail does not pay for a full group, see plan_pieces()).
     // Records go to a slice of `rec` private to this wave (no shared counter: a single atomic
     // word serialises at ~88 returns/us); counts[wave] = records the wave wanted to write.
     __shared__ float s_thr[QT * 32];
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;
     const int lane = threadIdx.x & 63;
-    const int qt0 = blockIdx.y * QT;
+    const int qt0 = blockIdx.y * QT;       // relative to the piece
     const int nq = min(QT, qtiles - qt0);  // wave-uniform
     for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
         s_thr[i] = i < nq * 32 ? thrg[(size_t)qt0 * 32 + i] : -INFINITY;
@@ -862,12 +866,12 @@ template <int KT, int QT>
 __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_sample_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg, int qtiles,
     long long ntiles, long long stride, float *__restrict__ umin, int m_padded,
-    const unsigned *__restrict__ ctl)
+    const unsigned *__restrict__ ctl, int qt_base)
 {
     __shared__ float s_min[FILTER_BLOCK / 64][QT * 32];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int qt0 = blockIdx.y * QT;
+    const int qt0 = qt_base + blockIdx.y * QT;
     const int nq = min(QT, qtiles - qt0);
     const long long wave = (long long)blockIdx.x * (FILTER_BLOCK / 64) + wib;
     const long long nwaves = (long long)gridDim.x * (FILTER_BLOCK / 64);
@@ -1235,35 +1239,122 @@ static hipError_t prep_queries(FilterState &st, FilterWorkspace &w, int m, const
     return hipGetLastError();
 }
 
+// A batch's query tiles are cut into pieces, each scanned by a launch whose waves keep QT tiles in
+// registers.  A ragged tail no longer pays for a full group: m = 1100 (35 tiles) used to run two
+// groups of 32 (1.09 ms at C3's n), now 32 + a piece of 8 (0.76 ms).  Costs per piece measured at
+// n = 2^24: QT 32: 0.54 ms, 16: 0.31, 8: 0.22, 2: 0.11.
+struct FilterPiece {
+    int qt;       // query tiles per wave
+    int begin;    // first query tile
+    int count;    // query tiles in the piece
+    unsigned gx, gy, list_base;
+};
+
+static int plan_pieces(int kt, int qtiles, int force_qt, FilterPiece out[4])
+{
+    int np = 0, pos = 0, rem = qtiles;
+    auto push = [&](int qt, int cnt) {
+        out[np].qt = qt;
+        out[np].begin = pos;
+        out[np].count = cnt;
+        ++np;
+        pos += cnt;
+        rem -= cnt;
+    };
+    if (force_qt > 0 && kt == 1) {
+        push(force_qt, rem);
+        return np;
+    }
+    if (kt == 1) {
+        if (rem >= 32)
+            push(32, rem / 32 * 32);
+        if (rem > 18)
+            push(32, rem);
+        else if (rem > 16) {
+            push(16, 16);
+            push(2, rem);
+        } else if (rem > 8)
+            push(16, rem);
+        else if (rem > 2)
+            push(8, rem);
+        else if (rem > 0)
+            push(2, rem);
+    } else if (kt == 2) {
+        if (rem >= 16)
+            push(16, rem / 16 * 16);
+        if (rem > 8)
+            push(16, rem);
+        else if (rem > 0)
+            push(8, rem);
+    } else if (kt == 4) {
+        push(4, rem);
+    } else {
+        push(2, rem);
+    }
+    return np;
+}
+
 template <int KT, int QT>
+static void launch_sample_piece(const FilterState &st, const FilterWorkspace &w, const FilterPiece &p, unsigned sb,
+                                long long stride, int m_padded, hipStream_t s)
+{
+    hipLaunchKernelGGL((knn_filter_sample_kernel<KT, QT>), dim3(sb, p.gy), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, p.begin + p.count, st.ntiles,
+                       stride, w.umin, m_padded, w.ctl, p.begin);
+}
+
+template <int KT, int QT>
+static void launch_scan_piece(const FilterState &st, const FilterWorkspace &w, const FilterPiece &p, hipStream_t s)
+{
+    hipLaunchKernelGGL((knn_filter_kernel<KT, QT>), dim3(p.gx, p.gy), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags + (size_t)p.begin * KT * 64,
+                       w.thr + (size_t)p.begin * 32, p.count, st.ntiles, w.records + (size_t)p.list_base * w.slice,
+                       w.counts + p.list_base, w.ctl, w.slice);
+}
+
+template <int KT>
 static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int num_cu, hipStream_t s)
 {
     const int qtiles = (m + 31) / 32;
     const int m_padded = qtiles * 32;
-    const unsigned gy = (unsigned)((qtiles + QT - 1) / QT);
-
-    // filter grid: 2 waves per SIMD when the wave's registers are full of query fragments,
-    // more when they are not (small batches are HBM-latency-bound)
-    // (small batches: 5 waves per SIMD measured best: 0.112 -> 0.107 ms at m = 8..64 against 4; 6 is no better)
-    long long waves = (long long)num_cu * (QT * KT > 16 ? 8 : QT * KT == 16 ? 12 : QT * KT <= 2 ? 20 : 16);
-    waves *= st.force_rounds > 0 ? st.force_rounds : 1;
-    if (waves > st.ntiles)
-        waves = st.ntiles;
-    unsigned gx = (unsigned)((waves + 3) / 4);
-    // many query groups (large m): split the references over fewer waves so every wave still
-    // streams a long run of tiles per load of its query fragments
+    FilterPiece pc[4];
+    const int np = plan_pieces(KT, qtiles, st.force_qt, pc);
     const unsigned target_blocks = (unsigned)num_cu * 8;
-    if (gy > 1 && (size_t)gx * gy > target_blocks)
-        gx = (target_blocks + gy - 1) / gy;
-    if (gx < 1)
-        gx = 1;
-    while ((size_t)gx * 4 * gy > kMaxLists && gx > 1)
-        gx = (gx + 1) / 2;
-    if ((size_t)gx * 4 * gy > kMaxLists)
+
+    // grids: 2 waves per SIMD when the wave's registers are full of query fragments, more when they
+    // are not (small batches are HBM-latency-bound; 5 waves per SIMD measured best at m = 8..64)
+    unsigned gy_sum = 0, nlists = 0;
+    for (int i = 0; i < np; ++i) {
+        FilterPiece &p = pc[i];
+        const int qk = p.qt * KT;
+        p.gy = (unsigned)((p.count + p.qt - 1) / p.qt);
+        long long waves = (long long)num_cu * (qk > 16 ? 8 : qk == 16 ? 12 : qk <= 2 ? 20 : 16);
+        waves *= st.force_rounds > 0 ? st.force_rounds : 1;
+        if (waves > st.ntiles)
+            waves = st.ntiles;
+        p.gx = (unsigned)((waves + 3) / 4);
+        // many query groups (large m): split the references over fewer waves so every wave still
+        // streams a long run of tiles per load of its query fragments
+        if (p.gy > 1 && (size_t)p.gx * p.gy > target_blocks)
+            p.gx = (target_blocks + p.gy - 1) / p.gy;
+        if (p.gx < 1)
+            p.gx = 1;
+        while ((size_t)p.gx * 4 * p.gy > kMaxLists / 4 && p.gx > 1)
+            p.gx = (p.gx + 1) / 2;
+        p.list_base = nlists;
+        nlists += p.gx * 4 * p.gy;
+        gy_sum += p.gy;
+    }
+    if (nlists == 0 || nlists > kMaxLists)
         return hipErrorInvalidValue;
-    w.nlists = gx * 4 * gy;
+    w.nlists = nlists;
     w.slice = w.rec_cap / w.nlists;
     w.has_rows = false;
+    w.pieces.n = np;
+    for (int i = 0; i < 4; ++i) {
+        w.pieces.list_base[i] = i < np ? pc[i].list_base : 0xFFFFFFFFu;
+        w.pieces.qrow_base[i] = i < np ? (unsigned)pc[i].begin * 32u : 0u;
+    }
 
     // 1. sample pass over every stride-th tile (about 1/16 of the shard) -> per-query minima
     long long stride = st.ntiles / 256;
@@ -1275,8 +1366,8 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
     unsigned sb = (unsigned)num_cu * 2;  // 2 waves per SIMD, like the main pass
     if (sb > kSampleBlocks)
         sb = kSampleBlocks;
-    if (gy > 1 && (size_t)sb * gy > target_blocks)
-        sb = (target_blocks + gy - 1) / gy;
+    if (gy_sum > 1 && (size_t)sb * gy_sum > target_blocks)
+        sb = (target_blocks + gy_sum - 1) / gy_sum;
     // at least 8 sampled tiles per wave: a wave's prologue (its query fragments, QT KiB) is not
     // worth fewer, and the threshold kernel folds one partial row per block
     if ((long long)sb * 32 > ns)
@@ -1293,10 +1384,27 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
             w.umin_cap = need;
         }
     }
-    hipLaunchKernelGGL((knn_filter_sample_kernel<KT, QT>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
-                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, qtiles, st.ntiles,
-                       stride, w.umin, m_padded, w.ctl);
-    FTRY(hipGetLastError());
+    for (int i = 0; i < np; ++i) {
+        const FilterPiece &p = pc[i];
+        if constexpr (KT == 1) {
+            switch (p.qt) {
+            case 2: launch_sample_piece<1, 2>(st, w, p, sb, stride, m_padded, s); break;
+            case 8: launch_sample_piece<1, 8>(st, w, p, sb, stride, m_padded, s); break;
+            case 16: launch_sample_piece<1, 16>(st, w, p, sb, stride, m_padded, s); break;
+            default: launch_sample_piece<1, 32>(st, w, p, sb, stride, m_padded, s); break;
+            }
+        } else if constexpr (KT == 2) {
+            if (p.qt == 8)
+                launch_sample_piece<2, 8>(st, w, p, sb, stride, m_padded, s);
+            else
+                launch_sample_piece<2, 16>(st, w, p, sb, stride, m_padded, s);
+        } else if constexpr (KT == 4) {
+            launch_sample_piece<4, 4>(st, w, p, sb, stride, m_padded, s);
+        } else {
+            launch_sample_piece<8, 2>(st, w, p, sb, stride, m_padded, s);
+        }
+        FTRY(hipGetLastError());
+    }
 
     // 2. thresholds
     hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
@@ -1316,10 +1424,27 @@ static hipError_t launch_filter(FilterState &st, FilterWorkspace &w, int m, int 
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    hipLaunchKernelGGL((knn_filter_kernel<KT, QT>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles,
-                       st.ntiles, w.records, w.counts, w.ctl, w.slice);
-    FTRY(hipGetLastError());
+    for (int i = 0; i < np; ++i) {
+        const FilterPiece &p = pc[i];
+        if constexpr (KT == 1) {
+            switch (p.qt) {
+            case 2: launch_scan_piece<1, 2>(st, w, p, s); break;
+            case 8: launch_scan_piece<1, 8>(st, w, p, s); break;
+            case 16: launch_scan_piece<1, 16>(st, w, p, s); break;
+            default: launch_scan_piece<1, 32>(st, w, p, s); break;
+            }
+        } else if constexpr (KT == 2) {
+            if (p.qt == 8)
+                launch_scan_piece<2, 8>(st, w, p, s);
+            else
+                launch_scan_piece<2, 16>(st, w, p, s);
+        } else if constexpr (KT == 4) {
+            launch_scan_piece<4, 4>(st, w, p, s);
+        } else {
+            launch_scan_piece<8, 2>(st, w, p, s);
+        }
+        FTRY(hipGetLastError());
+    }
     if (w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));
     if (!no_chain)
@@ -1391,6 +1516,7 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
                        1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
                        (unsigned short *)(w.records + w.rec_cap));
     w.has_rows = true;
+    w.pieces = RerankPieces();
     FTRY(hipGetLastError());
     if (w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));
@@ -1410,39 +1536,25 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     w.ev_end = ev_end;
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {
-    case 1:
-        if ((qtiles <= 2 && st.force_qt == 0) || st.force_qt == 2)
-            FTRY((launch_filter<1, 2>(st, w, m, num_cu, s)));
-        else if (qtiles <= 8 || st.force_qt == 8)
-            FTRY((launch_filter<1, 8>(st, w, m, num_cu, s)));
-        else if (qtiles <= 16 || st.force_qt == 16)
-            FTRY((launch_filter<1, 16>(st, w, m, num_cu, s)));
-        else
-            FTRY((launch_filter<1, 32>(st, w, m, num_cu, s)));
-        break;
-    case 2:
-        if (qtiles <= 8)
-            FTRY((launch_filter<2, 8>(st, w, m, num_cu, s)));
-        else
-            FTRY((launch_filter<2, 16>(st, w, m, num_cu, s)));
-        break;
+    case 1: FTRY(launch_filter<1>(st, w, m, num_cu, s)); break;
+    case 2: FTRY(launch_filter<2>(st, w, m, num_cu, s)); break;
     case 4:
         if (qtiles >= 16)
             FTRY((launch_filter_tiled<4, 4>(st, w, m, num_cu, s)));
         else
-            FTRY((launch_filter<4, 4>(st, w, m, num_cu, s)));
+            FTRY(launch_filter<4>(st, w, m, num_cu, s));
         break;
     default:
         if (qtiles >= 16)
             FTRY((launch_filter_tiled<8, 4>(st, w, m, num_cu, s)));
         else
-            FTRY((launch_filter<8, 2>(st, w, m, num_cu, s)));
+            FTRY(launch_filter<8>(st, w, m, num_cu, s));
         break;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
     FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records,
                            w.has_rows ? (const unsigned short *)(w.records + w.rec_cap) : nullptr, w.counts, w.nlists,
-                           w.slice, w.ctl, keys, s));
+                           w.slice, w.ctl, keys, w.pieces, s));
     // rows outside the robust box never entered the filter: exact scan of that (short) list
     FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)

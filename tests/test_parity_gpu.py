@@ -50,7 +50,8 @@ def test_ragged_shapes_bit_exact(oracle, path, k, m, n):
 
 @pytest.mark.parametrize("k,m,n", [(3, 1024, 65536), (16, 1024, 65536), (16, 64, 1 << 18), (3, 5, 1 << 20),
                                    (16, 1, 1 << 20), (16, 1, 5000), (16, 2, 70001), (16, 5, 70001), (16, 8, 70001),
-                                   (8, 300, 100000),
+                                   (8, 300, 100000), (16, 1057, 70001), (16, 1100, 70001), (16, 1600, 70001),
+                                   (16, 577, 70001), (20, 600, 70001), (20, 1057, 70001), (3, 2100, 70001),
                                    (128, 600, 4100), (40, 513, 9000), (64, 2048, 70000), (33, 1000, 131072)])
 def test_synthetic_uniform_bit_exact(oracle, path, k, m, n):
     Q, R = oracle.synth(m * k, 1000), oracle.synth(n * k, 1001)
