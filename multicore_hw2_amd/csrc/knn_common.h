@@ -38,7 +38,7 @@ struct RerankPieces {
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
                              const u64 *records, const unsigned short *record_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
-                             const unsigned *perm, hipStream_t stream);
+                             hipStream_t stream);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
@@ -93,9 +93,7 @@ struct FilterState {
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
     int force_rounds = 0;      // tuning hook: filter blocks per resident slot (0 = default)
     int chain_policy = 0;      // scans of different slots: 0 auto (chained when long), 1 always chained, 2 never
-    unsigned *perm = nullptr;     // device [ntiles * 32]: original row of every position of the norm-sorted layout
-    long long n_inbox = 0;        // positions [0, n_inbox) are rows inside the robust box, ascending norm
-    unsigned *outliers = nullptr; // = perm + n_inbox: rows outside the box (+INF norm: never survivors), scanned exactly
+    unsigned *outliers = nullptr; // device: rows outside the robust box (excluded from the filter, scanned exactly)
     unsigned n_outliers = 0;
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
@@ -109,9 +107,6 @@ struct FilterState {
 // pooled device memory for the CURRENT device (knn_api.cpp); knn_dev_free waits for the device first
 hipError_t knn_dev_alloc(void **p, size_t bytes);
 hipError_t knn_dev_free(void *p);
-
-hipError_t knn_sort_pairs_u32(void *tmp, size_t *tmp_bytes, const unsigned *keys_in, unsigned *keys_out,
-                              const unsigned *vals_in, unsigned *vals_out, size_t count, hipStream_t stream);
 
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
 void knn_filter_free(FilterState &st);

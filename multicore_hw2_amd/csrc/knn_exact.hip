@@ -497,13 +497,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                                                                const unsigned short *__restrict__ rec_rows,
                                                                const unsigned *__restrict__ counts,
                                                                unsigned slice, unsigned *__restrict__ ctl,
-                                                               u64 *__restrict__ keys, RerankPieces pieces,
-                                                               const unsigned *__restrict__ perm)
+                                                               u64 *__restrict__ keys, RerankPieces pieces)
 {
 #pragma clang fp contract(off)
-    // one block per record list (= per filter wave); the list's piece gives its first query.
-    // Records name POSITIONS of the norm-sorted layout: perm[] gives the caller's row (whose number
-    // goes into the key, so ties still resolve to the lowest original index).
+    // one block per record list (= per filter wave); the list's piece gives its first query
     unsigned qrow_base = pieces.qrow_base[0];
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -535,9 +532,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
             // rows the filter already proved to be above the threshold are not the answer: skip them
             const unsigned rmask = rec_rows ? rec_rows[(size_t)blockIdx.x * slice + (c >> 4)] : 0xFFFFu;
             if (ri < n && ((rmask >> reg) & 1u)) {
-                const long long row = perm ? (long long)perm[ri] : ri;
                 const float *__restrict__ q = Q + (size_t)qi * k;
-                const float *__restrict__ r = R + (size_t)row * k;
+                const float *__restrict__ r = R + (size_t)ri * k;
                 float acc = 0.0f;
                 if (K > 0) {
                     float qv[K > 0 ? K : 1], rv[K > 0 ? K : 1];
@@ -578,7 +574,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                     }
                 }
                 if (acc < INFINITY)  // false for NaN too: v0 never selects those
-                    key = pack_key(acc, (unsigned)(base + row));
+                    key = pack_key(acc, (unsigned)(base + ri));
             }
         }
 #pragma unroll
@@ -632,8 +628,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_rows_kernel(const float 
                                                                     const unsigned short *__restrict__ rec_rows,
                                                                     const unsigned *__restrict__ counts,
                                                                     unsigned slice, unsigned *__restrict__ ctl,
-                                                                    u64 *__restrict__ keys,
-                                                                    const unsigned *__restrict__ perm)
+                                                                    u64 *__restrict__ keys)
 {
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;
@@ -655,10 +650,9 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_rows_kernel(const float 
             rm &= rm - 1u;
             const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
             if (ri < n) {
-                const long long row = perm ? (long long)perm[ri] : ri;
-                const float acc = v0_row_distance<0>(q, R + (size_t)row * k, k);
+                const float acc = v0_row_distance<0>(q, R + (size_t)ri * k, k);
                 if (acc < INFINITY) {  // false for NaN too: v0 never selects those
-                    const u64 cand = pack_key(acc, (unsigned)(base + row));
+                    const u64 cand = pack_key(acc, (unsigned)(base + ri));
                     key = cand < key ? cand : key;
                 }
             }
@@ -874,18 +868,18 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
                              const u64 *rec, const unsigned short *rec_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
-                             const unsigned *perm, hipStream_t s)
+                             hipStream_t s)
 {
     if (nlists == 0)
         return hipSuccess;
     if (rec_rows) {  // deep-K scans are never cut into pieces
         hipLaunchKernelGGL(knn_rerank_rows_kernel, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows,
-                           counts, slice, ctl, keys, perm);
+                           counts, slice, ctl, keys);
         return hipGetLastError();
     }
 #define KNN_RERANK(KK)                                                                                     \
     hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows, \
-                       counts, slice, ctl, keys, pieces, perm)
+                       counts, slice, ctl, keys, pieces)
     switch (k) {
     case 3: KNN_RERANK(3); break;
     case 4: KNN_RERANK(4); break;

@@ -303,103 +303,6 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
         atomicAdd(&out[2], bad);
 }
 
-// ------------------------------------------------------------------------------------------
-// Reference layout, two passes around a stable device sort: the filter's tiles hold the rows in
-// ASCENDING ORDER OF THEIR NORM.  Within a tile (and a chunk of 8 tiles) the norms then differ by a
-// hair, so the scan can use ONE norm per chunk — a lower bound of every row's — folded into the
-// thresholds instead of a 16-register C operand per MFMA (§4.2: the C reads were the scan's
-// bottleneck).  perm[] maps a position of the sorted layout back to the caller's row.
-//   pass A  knn_ref_norms_kernel: norm of every row exactly as the fragment pass will compute it,
-//           +INF for rows outside the robust box and for padding; iota for the sort's values
-//   sort    (norm bits, row) ascending, stable
-//   pass B  knn_ref_gather_frag_kernel: position i <- row perm[i]: fragments, norm, statistics
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ref_row_norm(const float *__restrict__ x, int k, const float *__restrict__ center,
-                                              float sigma, bool &outside)
-{
-    float nrm = 0.0f;
-    outside = false;
-    for (int d = 0; d < k; ++d) {
-        const float back = (float)(_Float16)((x[d] - center[d]) * sigma);  // fp32 subtract, power-of-two scale, RNE
-        outside = outside || !(fabsf(back) <= 1.0f);
-        nrm = nrm + back * back;  // exact products, fp32 sum, d ascending (same order as the fragment pass)
-    }
-    return nrm;
-}
-
-__global__ __launch_bounds__(256) void knn_ref_norms_kernel(const float *__restrict__ X, long long rows,
-                                                            long long rows_padded, int k,
-                                                            const float *__restrict__ center, float sigma,
-                                                            unsigned *__restrict__ norm_bits,
-                                                            unsigned *__restrict__ iota,
-                                                            unsigned *__restrict__ n_outside)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows_padded)
-        return;
-    float nrm = INFINITY;
-    if (i < rows) {
-        bool outside;
-        nrm = ref_row_norm(X + (size_t)i * k, k, center, sigma, outside);
-        if (outside || !(nrm < INFINITY)) {
-            nrm = INFINITY;
-            atomicAdd(n_outside, 1u);  // rare (robust box: <= 1 % of the rows)
-        }
-    }
-    norm_bits[i] = __float_as_uint(nrm);
-    iota[i] = (unsigned)i;
-}
-
-__global__ __launch_bounds__(256) void knn_ref_gather_frag_kernel(const float *__restrict__ X, long long n_inbox,
-                                                                  long long rows_padded, int k, int kt,
-                                                                  const float *__restrict__ center, float sigma,
-                                                                  const unsigned *__restrict__ perm,
-                                                                  h8 *__restrict__ frag, float *__restrict__ norms,
-                                                                  unsigned *__restrict__ out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    float vmax = 0.0f, nrm = 0.0f;
-    unsigned bad = 0;
-    if (i < rows_padded) {
-        const long long tile = i >> 5;
-        const int r = (int)(i & 31);
-        const bool real = i < n_inbox;
-        const float *__restrict__ x = X + (size_t)(real ? perm[i] : 0u) * k;
-        for (int kk = 0; kk < kt; ++kk) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                h8 v;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int d = kk * 16 + half * 8 + j;
-                    float s = 0.0f;
-                    if (real && d < k)
-                        s = (x[d] - center[d]) * sigma;
-                    const _Float16 hval = (_Float16)s;
-                    const float back = (float)hval;
-                    if (!(fabsf(back) < INFINITY))
-                        ++bad;
-                    vmax = fmaxf(vmax, fabsf(back));
-                    nrm = nrm + back * back;
-                    v[j] = hval;
-                }
-                frag[((size_t)tile * kt + kk) * 64 + half * 32 + r] = v;
-            }
-        }
-        norms[i] = real ? nrm : INFINITY;  // (equals the sort key bit for bit)
-        if (!real)
-            nrm = 0.0f;
-    }
-    vmax = wave_max_f(vmax);
-    nrm = wave_max_f(nrm);
-    if ((threadIdx.x & 63) == 0) {
-        guarded_atomic_max(&out[0], __float_as_uint(vmax));
-        guarded_atomic_max(&out[1], __float_as_uint(nrm));
-    }
-    if (bad)
-        atomicAdd(&out[2], bad);
-}
-
 // k = 16 references, 16-byte aligned: the block reads its 256 rows (16 KiB) as fully coalesced
 // 16-byte chunks into LDS (XOR-swizzled so the row reads below are bank-conflict free), then
 // every thread converts its own row.  Same outputs as knn_frag_kernel(scale_out = 1).
@@ -1046,9 +949,7 @@ template <int KT>
 __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restrict__ rf,
                                                                const float *__restrict__ rn,
                                                                const h8 *__restrict__ qfg, int m,
-                                                               long long n, float *__restrict__ scores,
-                                                               const unsigned *__restrict__ perm,
-                                                               long long n_inbox)
+                                                               long long n, float *__restrict__ scores)
 {
     const int lane = threadIdx.x & 63;
     h8 a[KT];
@@ -1063,8 +964,8 @@ __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const long long r = (long long)blockIdx.x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-        if (q < m && r < n)  // position r of the sorted layout is the caller's row perm[r]; rows outside the box: +INF
-            scores[(size_t)q * n + perm[r]] = r < n_inbox ? d[i] : INFINITY;
+        if (q < m && r < n)
+            scores[(size_t)q * n + r] = d[i];
     }
 }
 
@@ -1088,7 +989,7 @@ void knn_filter_free(FilterState &st)
     (void)KNN_DEV_FREE(st.center);
     (void)KNN_DEV_FREE(st.ref_frags);
     (void)KNN_DEV_FREE(st.ref_norms);
-    (void)KNN_DEV_FREE(st.perm);  // (outliers points into it)
+    (void)KNN_DEV_FREE(st.outliers);
     if (st.scan_done)
         (void)hipEventDestroy(st.scan_done);
     for (FilterWorkspace &w : st.ws) {
@@ -1237,72 +1138,47 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         sigma = (float)ldexp(1.0, -ex);
     }
 
-    // 2. norms -> stable sort by norm -> gathered fragments (see the kernels' header comment)
+    // 2. fragments + norms
     st.k = k;
     st.kt = kt;
     st.n = n;
     st.ntiles = ntiles;
     st.sigma = sigma;
-    const long long rows_padded = ntiles * 32;
-    const unsigned nblk = (unsigned)((rows_padded + 255) / 256);
-    unsigned *dout = nullptr, *key_in = nullptr, *val_in = nullptr;
-    void *sort_tmp = nullptr;
-    size_t sort_bytes = 0;
-    unsigned hout[4] = {0, 0, 0, 0};
+    unsigned *dout = nullptr;
     e = KNN_DEV_ALLOC((void **)&st.center, (size_t)kp * sizeof(float));
     if (e == hipSuccess)
         e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
     if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)rows_padded * sizeof(float));
+        e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+    const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);  // more outliers than this: no filter
     if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&st.perm, (size_t)rows_padded * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&key_in, (size_t)rows_padded * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&val_in, (size_t)rows_padded * sizeof(unsigned));
+        e = KNN_DEV_ALLOC((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
     if (e == hipSuccess)
         e = KNN_DEV_ALLOC((void **)&dout, 4 * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = knn_sort_pairs_u32(nullptr, &sort_bytes, key_in, (unsigned *)st.ref_norms, val_in, st.perm,
-                               (size_t)rows_padded, s);  // size query only
-    if (e == hipSuccess)
-        e = KNN_DEV_ALLOC(&sort_tmp, sort_bytes ? sort_bytes : 16);
     if (e == hipSuccess)
         e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(st.center, center.data(), (size_t)kp * sizeof(float), hipMemcpyHostToDevice, s);
+    unsigned hout[4] = {0, 0, 0, 0};
     lap("allocations");
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(knn_ref_norms_kernel, dim3(nblk), dim3(256), 0, s, r, n, rows_padded, k, st.center, sigma,
-                           key_in, val_in, dout + 3);
+        const long long rows_padded = ntiles * 32;
+        if (k == 16 && ((uintptr_t)r & 15u) == 0)
+            hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s,
+                               (const f4v *)r, n, rows_padded, st.center, sigma, (h8 *)st.ref_frags,
+                               st.ref_norms, dout, st.outliers, ocap);
+        else
+            hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
+                               n, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
+                               st.ref_norms, dout, 0, nullptr, nullptr, st.outliers, ocap);
         e = hipGetLastError();
     }
-    if (e == hipSuccess)
-        e = knn_sort_pairs_u32(sort_tmp, &sort_bytes, key_in, (unsigned *)st.ref_norms, val_in, st.perm,
-                               (size_t)rows_padded, s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(s);  // rows outside the box are known: [n_inbox, n) of the sorted layout
-    lap("norms + sort");
-    const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);  // more rows outside than this: no filter
-    if (e == hipSuccess && hout[3] <= ocap) {
-        st.n_outliers = hout[3];
-        st.n_inbox = n - (long long)hout[3];
-        st.outliers = st.perm + st.n_inbox;
-        hipLaunchKernelGGL(knn_ref_gather_frag_kernel, dim3(nblk), dim3(256), 0, s, r, st.n_inbox, rows_padded, k, kt,
-                           st.center, sigma, st.perm, (h8 *)st.ref_frags, st.ref_norms, dout);
-        e = hipGetLastError();
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(hout, dout, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(s);  // also keeps `center` alive until the copy is done
-    }
-    lap("fragment gather + sync");
+        e = hipStreamSynchronize(s);  // also keeps `center` alive until the copy is done
+    lap("fragment kernel + sync");
     (void)KNN_DEV_FREE(dout);
-    (void)KNN_DEV_FREE(key_in);
-    (void)KNN_DEV_FREE(val_in);
-    (void)KNN_DEV_FREE(sort_tmp);
     if (e != hipSuccess) {
         knn_filter_free(st);
         return e;
@@ -1311,6 +1187,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         knn_filter_free(st);
         return hipSuccess;
     }
+    st.n_outliers = hout[3];
     memcpy(&st.bmax, &hout[0], 4);
     memcpy(&st.nmax, &hout[1], 4);
     st.usable = true;
@@ -1677,7 +1554,7 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
     FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records,
                            w.has_rows ? (const unsigned short *)(w.records + w.rec_cap) : nullptr, w.counts, w.nlists,
-                           w.slice, w.ctl, keys, w.pieces, st.perm, s));
+                           w.slice, w.ctl, keys, w.pieces, s));
     // rows outside the robust box never entered the filter: exact scan of that (short) list
     FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
@@ -1693,10 +1570,10 @@ hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float 
     const int qtiles = (m + 31) / 32;
     const dim3 grid((unsigned)st.ntiles, (unsigned)qtiles);
     switch (st.kt) {
-    case 1: hipLaunchKernelGGL(knn_filter_scores_kernel<1>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores, st.perm, st.n_inbox); break;
-    case 2: hipLaunchKernelGGL(knn_filter_scores_kernel<2>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores, st.perm, st.n_inbox); break;
-    case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores, st.perm, st.n_inbox); break;
-    default: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores, st.perm, st.n_inbox); break;
+    case 1: hipLaunchKernelGGL(knn_filter_scores_kernel<1>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 2: hipLaunchKernelGGL(knn_filter_scores_kernel<2>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    default: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     }
     FTRY(hipGetLastError());
     FTRY(hipMemcpyAsync(qnorm_out, w.qry_norms, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -5,7 +5,6 @@
 #define KNN_NO_POOL
 #include "../multicore_hw2_amd/csrc/knn_filter.hip"
 #include "../multicore_hw2_amd/csrc/knn_exact.hip"
-#include "../multicore_hw2_amd/csrc/knn_sort.hip"
 #include <algorithm>
 
 // VAR 0: production epilogue (8 min3 incl. thr, cmp, branch)
@@ -175,22 +174,13 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
             continue;
         }
         f16v d[2];
-        // VAR 12 / 13: srcC = literal zero instead of the norm tile (wrong scores: prices the 16 VGPR
-        // reads per MFMA that the C operand costs)
-        f16v zc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            zc[i] = 0.0f;
-        const bool zero_c = VAR == 12 || VAR == 13;
-        d[0] = zero_c ? __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0][0], zc, 0, 0, 0)
-                      : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0][0], c, 0, 0, 0);
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[0][0], c, 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const float th = s_thr[t * 32 + (lane & 31)];
             if (t + 1 < QT) {
                 if (VAR == 3) __builtin_amdgcn_s_setprio(1);
-                d[(t + 1) & 1] = zero_c ? __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 1][0], zc, 0, 0, 0)
-                                        : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 1][0], c, 0, 0, 0);
+                d[(t + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], qf[t + 1][0], c, 0, 0, 0);
                 if (VAR == 3) __builtin_amdgcn_s_setprio(0);
             }
             const f16v &x = d[t & 1];
@@ -211,7 +201,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
             const float m4 = min3f(x[12], x[13], x[14]);
             const float m5 = min3f(m0, m1, m2);
             const float m6 = min3f(m3, m4, x[15]);
-            if (VAR == 1 || VAR == 13) {
+            if (VAR == 1) {
                 um = min3f(m5, m6, um);
             } else if (VAR == 4) {
                 const float mn = min3f(m5, m6, th);
@@ -367,8 +357,6 @@ int main()
         if (run<11>("11 production epilogue, MFMAs issued in pairs", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<9>("9 MFMA chains, 2 ref tiles prefetched", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<10>("10 production epilogue, 2 ref tiles prefetched", rf, rn, qf, thr, ntiles, sink)) return 1;
-        if (run<12>("12 production epilogue, srcC = 0", rf, rn, qf, thr, ntiles, sink)) return 1;
-        if (run<13>("13 running min, srcC = 0", rf, rn, qf, thr, ntiles, sink)) return 1;
     }
     return 0;
 }
