@@ -177,6 +177,18 @@ dist.all_reduce(t, op=dist.ReduceOp.MIN)
 got = (t.numpy().view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int32)
 want = o.v0_serial(k, Q, R)
 assert (got == want).all(), (rank, np.flatnonzero(got != want)[:5])
+# bench.py's exchange step at N > 1: ONE all-reduce over the [batches in flight, m] block of keys
+B = 3
+Qs = [o.synth(m * k, 2000 + b) for b in range(B)]
+block = np.full((B, m), KEY_INIT, dtype=np.uint64)
+if hi > lo:
+    for b in range(B):
+        block[b] = np.minimum(block[b], o.v0_keys(k, Qs[b], R[lo * k:hi * k], base=lo, threads=1))
+tb = torch.from_numpy(block.view(np.int64).copy())
+dist.all_reduce(tb[:B], op=dist.ReduceOp.MIN)
+gotb = (tb.numpy().view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int32)
+for b in range(B):
+    assert (gotb[b] == o.v0_serial(k, Qs[b], R)).all(), (rank, b)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
