@@ -420,6 +420,12 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     }
     if (n_local > 0 && g_opt_path != 1 && build_filter) {
         hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s);
+        if (e == hipErrorOutOfMemory) {
+            // no room for the fp16 layouts beside the rows: the index still works, exact kernels only
+            (void)hipGetLastError();
+            knn_filter_free(idx->filter);
+            e = hipSuccess;
+        }
         if (e != hipSuccess) {
             knn_index_destroy(idx);
             return fail(KNN_EHIP, "knn_index_create: building the filter layouts", hipGetErrorString(e));
