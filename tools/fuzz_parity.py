@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test of the drop-in entry against the CPU oracle: random shapes,
 distributions, paths, shard counts and one-shot strategies.  usage: fuzz_parity.py [cases] [seed]
+(FUZZ_BIG=1: large shapes, 48 sampled queries checked per case)
 Exit status 1 on the first mismatch (prints the case so it can be replayed)."""
 import os
 import sys
@@ -62,6 +63,34 @@ def one_case(o, rng, case):
     return True
 
 
+def big_case(o, rng, case):
+    """Large shapes (multi-piece batches, multi-chunk streams): every query goes through the GPU, a
+    random sample of 48 is checked against the oracle."""
+    k = int(rng.choice([3, 16, 16, 16, 20, 40]))
+    m = int(rng.choice([577, 1057, 1100, 1600, 2100, 3000, 4096]))
+    n = int(rng.choice([300001, 1 << 20, 3000000, 5000000]))
+    if k * n > 90_000_000:
+        n = 90_000_000 // k
+    kind = str(rng.choice(["uniform", "gauss", "offset", "heavy"]))
+    path = int(rng.choice([0, 0, 2]))
+    shards = int(rng.choice([0, 0, 3]))
+    stream = int(rng.choice([0, 1, 2]))
+    R = make_data(rng, kind, n, k)
+    Q = make_data(rng, kind, m, k)
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, path=path, shards=shards, stream=stream)
+    pkg.set_option("path", path)
+    pkg.set_option("shards", shards)
+    pkg.set_option("stream", stream)
+    got = pkg.cudaCallback(k, m, n, Q, R)
+    sel = rng.choice(m, 48, replace=False)
+    want = o.v0(k, np.ascontiguousarray(Q[sel]), R)
+    if not (got[sel] == want).all():
+        j = int(np.flatnonzero(got[sel] != want)[0])
+        print("MISMATCH", desc, "query", int(sel[j]), "got", int(got[sel][j]), "want", int(want[j]), flush=True)
+        return False
+    return True
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
@@ -70,7 +99,7 @@ def main():
     t0 = time.time()
     try:
         for case in range(cases):
-            if not one_case(o, rng, case):
+            if not (big_case if os.environ.get("FUZZ_BIG") == "1" else one_case)(o, rng, case):
                 return 1
             if case % 25 == 24:
                 print("%d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
