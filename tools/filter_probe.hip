@@ -219,6 +219,8 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
         a[0] = an[0];
         c = cn;
     }
+    if (VAR == 1)
+        sink[1024 + (size_t)wave * 64 + lane] = um;
     if (um == 1.2345f || hits == 0xFFFFFFFFu)
         sink[threadIdx.x] = um + hits;
     if (lane == 0) {   // diagnostic only: shader cycles and 100 MHz ticks this wave ran
@@ -227,11 +229,218 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
     }
 }
 
+
+// ---- round 2 variants: per-query-tile running minima (no compare, no threshold read in the hot loop),
+// NACC accumulators with the MFMA pipeline rotated across reference tiles (no bubble at a tile
+// boundary), NSET operand sets (reference tiles in flight), WPS waves per SIMD.
+// The MFMA and the min3 tree are inline asm: issue order = program order, accumulators pinned to arch
+// VGPRs (left to itself hipcc puts them in AGPRs under a 512-register budget and copies every result
+// back with 16 v_accvgpr_read per tile pair), query fragments pinned to AGPRs when QAGPR.
+// Hazard: the tree of step t reads the accumulator NACC-1 steps after its MFMA was issued
+// (>= 8 (NACC-1) VALU + NACC-1 MFMA issue slots in between; 8-pass XDL write -> VALU read needs 12 wait
+// states: NACC >= 3 has them by construction, NACC = 2 pads with s_nop).
+//   THRREG: thresholds in registers (1 wave per SIMD has the room), else read from LDS at the check.
+// The check (run[t] < thr[t], once per NSET reference tiles) only counts hits here.
+#define MFMA_ASM_V(D, A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C))
+#define MFMA_ASM_A(D, A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "a"(B), "v"(C))
+// One step = the MFMA of step t + NACC - 1 and the tree of step t in ONE statement (hipcc pads every asm
+// boundary with an s_nop: 4 issue cycles).  The five temporaries are "+v": live across the whole loop, so
+// they own their registers (as plain outputs hipcc parks them in whatever is dead at that point — e.g.
+// the C tile an MFMA issued one instruction earlier is still reading).
+#define TREE8 "v_min3_f32 %1, %10, %11, %12\n\t" "v_min3_f32 %2, %13, %14, %15\n\t" "v_min3_f32 %3, %16, %17, %18\n\t" \
+              "v_min3_f32 %4, %19, %20, %21\n\t" "v_min3_f32 %5, %22, %23, %24\n\t" "v_min3_f32 %1, %1, %2, %3\n\t"       \
+              "v_min3_f32 %4, %4, %5, %25\n\t" "v_min3_f32 %6, %1, %4, %6"
+#define TREE4 "v_min3_f32 %1, %10, %11, %12\n\t" "v_min3_f32 %2, %13, %14, %15\n\t" "v_min3_f32 %3, %16, %17, %18\n\t" \
+              "v_min3_f32 %6, %1, %2, %3"
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KEEP_V(X) asm volatile("" ::"v"(X))
+#define KEEP_A(X) asm volatile("" ::"a"(X))
+#else
+#define KEEP_V(X) (void)(X)
+#define KEEP_A(X) (void)(X)
+#endif
+#define TREE0 ""
+#define TREE6 "v_min3_f32 %1, %10, %11, %12\n\t" "v_min3_f32 %2, %13, %14, %15\n\t" "v_min3_f32 %3, %16, %17, %18\n\t" \
+              "v_min3_f32 %4, %19, %20, %21\n\t" "v_min3_f32 %1, %1, %2, %3\n\t" "v_min3_f32 %6, %1, %4, %6"
+#define TREE12 TREE8 "\n\t" "v_min3_f32 %1, %10, %11, %12\n\t" "v_min3_f32 %2, %13, %14, %15\n\t" "v_min3_f32 %3, %16, %17, %18\n\t" \
+              "v_min3_f32 %6, %1, %2, %6"
+#define TREE16 TREE8 "\n\t" TREE8
+// 16 two-operand ops (VOP2) instead of 8 three-operand ones
+#define TREEV2 "v_min_f32 %1, %10, %11\n\t" "v_min_f32 %2, %12, %13\n\t" "v_min_f32 %3, %14, %15\n\t" "v_min_f32 %4, %16, %17\n\t"   \
+               "v_min_f32 %5, %18, %19\n\t" "v_min_f32 %1, %1, %20\n\t" "v_min_f32 %2, %2, %21\n\t" "v_min_f32 %3, %3, %22\n\t"     \
+               "v_min_f32 %4, %4, %23\n\t" "v_min_f32 %5, %5, %24\n\t" "v_min_f32 %1, %1, %25\n\t" "v_min_f32 %2, %2, %3\n\t"       \
+               "v_min_f32 %4, %4, %5\n\t" "v_min_f32 %1, %1, %2\n\t" "v_min_f32 %4, %4, %6\n\t" "v_min_f32 %6, %1, %4"
+// MFMA forms (no tree): literal-zero C; C and D both in AGPRs; accumulate chain (srcC = vdst)
+#define STEP_ASM_C0(DN, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(DN) : "v"(A), "a"(B))
+#define STEP_ASM_CH(DN, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(DN) : "v"(A), "a"(B))
+#define STEP_ASM_AA(DN, A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(DN) : "v"(A), "v"(B), "a"(C))
+// 8 ops, the last one (which needs the two before it) moved to the front: it folds the PREVIOUS step's partial minima
+// (kept in %1 / %4 of the other temporary set, passed as %5 <- unused here) -- see STEP_ASM_D
+#define STEP_ASM(BCLS, CCLS, DN, A, B, C, X, RUN, T, PAD, TREE)                                                        \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %7, %8, %9\n\t" PAD TREE                                                 \
+                 : "=&v"(DN), "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(RUN)                    \
+                 : "v"(A), BCLS(B), CCLS(C), "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(X[4]), "v"(X[5]),         \
+                   "v"(X[6]), "v"(X[7]), "v"(X[8]), "v"(X[9]), "v"(X[10]), "v"(X[11]), "v"(X[12]), "v"(X[13]),         \
+                   "v"(X[14]), "v"(X[15]))
+// deferred fold: this step computes its two partial minima into T[0] / T[3]; the fold of the PREVIOUS step's
+// partials (TP[0], TP[3], the other temporary set) into its running minimum RUNP sits in the middle, so no
+// instruction needs a result produced one or two instructions earlier
+#define STEP_ASM_D(BCLS, CCLS, DN, A, B, C, X, RUNP, T, TP)                                                            \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %9, %10, %11\n\t"                                                        \
+                 "v_min3_f32 %1, %12, %13, %14\n\t" "v_min3_f32 %2, %15, %16, %17\n\t" "v_min3_f32 %3, %18, %19, %20\n\t" \
+                 "v_min3_f32 %4, %21, %22, %23\n\t" "v_min3_f32 %5, %24, %25, %26\n\t"                                   \
+                 "v_min3_f32 %6, %7, %8, %6\n\t"                                                                       \
+                 "v_min3_f32 %1, %1, %2, %3\n\t" "v_min3_f32 %4, %4, %5, %27"                                          \
+                 : "=&v"(DN), "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(RUNP)                   \
+                 : "v"(TP[0]), "v"(TP[3]), "v"(A), BCLS(B), CCLS(C), "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]),       \
+                   "v"(X[4]), "v"(X[5]), "v"(X[6]), "v"(X[7]), "v"(X[8]), "v"(X[9]), "v"(X[10]), "v"(X[11]),           \
+                   "v"(X[12]), "v"(X[13]), "v"(X[14]), "v"(X[15]))
+
+template <int NACC, int WPS, int NSET, bool THRREG, bool QAGPR, int TREE = 8, bool CAGPR = false>
+__global__ __launch_bounds__(FILTER_BLOCK, WPS) void probe_run_kernel(const h8 *__restrict__ rf, const float *__restrict__ rn,
+                                                                       const h8 *__restrict__ qfg, const float *__restrict__ thrg,
+                                                                       long long ntiles, float *__restrict__ sink,
+                                                                       unsigned long long *__restrict__ stamps)
+{
+    constexpr int QT = 32;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __shared__ float s_thr[QT * 32];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < QT * 32; i += FILTER_BLOCK)
+        s_thr[i] = thrg[i];
+    __syncthreads();
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long t0 = ntiles * wave / nwaves, t1 = ntiles * (wave + 1) / nwaves;
+    h8 qf[QT];
+    float run[QT], thv[THRREG ? QT : 1];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        qf[t] = qfg[(size_t)t * 64 + lane];
+        run[t] = INFINITY;
+        if (THRREG)
+            thv[t] = s_thr[t * 32 + (lane & 31)];
+    }
+    unsigned hits = 0;
+    f16v dummy;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        dummy[i] = 1.0f + (float)(lane + i);
+    asm volatile("" : "+v"(dummy));
+    float tmp[2][5] = {{INFINITY, INFINITY, INFINITY, INFINITY, INFINITY}, {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY}};   // alternate: a statement never reads its predecessor's outputs (no boundary s_nop)
+    h8 a[NSET][1];
+    f16v c[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s)
+        load_ref_tile<1>(rf, rn, min(t0 + s, t1 - 1), lane, a[s], c[s]);
+    f16v d[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+        d[j] = c[0];
+#pragma unroll
+    for (int j = 0; j + 1 < NACC; ++j) {
+        if (TREE == 22)
+            STEP_ASM_AA(d[j], a[0][0], qf[j], c[0]);
+        else if (QAGPR)
+            MFMA_ASM_A(d[j], a[0][0], qf[j], c[0]);
+        else
+            MFMA_ASM_V(d[j], a[0][0], qf[j], c[0]);
+    }
+    for (long long tile = t0; tile < t1; tile += NSET) {
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int tt = t + NACC - 1;
+                const int su = tt < QT ? s : (s + 1) % NSET;   // the first NACC-1 steps of the next tile start early
+                f16v &dn = d[tt % NACC];
+                const f16v &x = TREE == 9 ? dummy : d[t % NACC];
+                if constexpr (TREE == 10) {   // deferred fold (the very first fold uses tmp = +INF partials: harmless)
+                    STEP_ASM_D("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[(t + QT - 1) % QT], tmp[t & 1], tmp[(t + 1) & 1]);
+                } else if constexpr (TREE == 0) {
+                    STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE0);
+                } else if constexpr (TREE == 6) {
+                    STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE6);
+                } else if constexpr (TREE == 12) {
+                    STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE12);
+                } else if constexpr (TREE == 16) {
+                    STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE16);
+                } else if constexpr (TREE == 17) {
+                    STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREEV2);
+                } else if constexpr (TREE == 20) {
+                    // (an asm output counts as written at ASMEND: a result nobody reads is dead at once, its
+                    // registers get reused — e.g. for an address — while the MFMA is still going to write them.
+                    // The empty statement keeps the accumulator issued NACC-1 steps ago live until here.)
+                    STEP_ASM_C0(dn, a[su][0], qf[tt % QT]);
+                    KEEP_V(d[t % NACC]);
+                } else if constexpr (TREE == 21) {
+                    STEP_ASM_CH(dn, a[su][0], qf[tt % QT]);
+                    KEEP_V(d[t % NACC]);
+                } else if constexpr (TREE == 22) {
+                    STEP_ASM_AA(dn, a[su][0], qf[tt % QT], c[su]);
+                    KEEP_A(d[t % NACC]);
+                } else if constexpr (TREE == 23) {   // literal-zero C + the full tree
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %7, %8, 0\n\t" TREE8
+                                 : "=&v"(dn), "+v"(tmp[t & 1][0]), "+v"(tmp[t & 1][1]), "+v"(tmp[t & 1][2]), "+v"(tmp[t & 1][3]),
+                                   "+v"(tmp[t & 1][4]), "+v"(run[t])
+                                 : "v"(a[su][0]), "a"(qf[tt % QT]), "v"(c[su]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
+                                   "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]),
+                                   "v"(x[13]), "v"(x[14]), "v"(x[15]));
+                } else if constexpr (TREE == 4) {
+                    STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE4);
+                } else if constexpr (!QAGPR) {
+                    if (NACC == 2)
+                        STEP_ASM("v", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "s_nop 1\n\t", TREE8);
+                    else
+                        STEP_ASM("v", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE8);
+                } else {
+                    if (NACC == 2)
+                        STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "s_nop 1\n\t", TREE8);
+                    else
+                        STEP_ASM("a", "v", dn, a[su][0], qf[tt % QT], c[su], x, run[t], tmp[t & 1], "", TREE8);
+                }
+                if (t == QT - NACC + 1)   // every MFMA reading set s has been issued: refill it
+                    load_ref_tile<1>(rf, rn, min(tile + s + NSET, t1 - 1), lane, a[s], c[s]);
+            }
+        }
+        if (TREE == 10) {
+            run[QT - 1] = min3f(tmp[(QT - 1) & 1][0], tmp[(QT - 1) & 1][3], run[QT - 1]);
+            tmp[(QT - 1) & 1][0] = INFINITY;
+            tmp[(QT - 1) & 1][3] = INFINITY;
+        }
+        u64 any = 0ull;
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            any |= __ballot(run[t] < (THRREG ? thv[t] : s_thr[t * 32 + (lane & 31)]));
+        if (__builtin_expect(any != 0ull, 0))
+            ++hits;
+    }
+    float um = run[0];
+#pragma unroll
+    for (int t = 1; t < QT; ++t)
+        um = fminf(um, run[t]);
+    sink[1024 + (size_t)wave * 64 + lane] = um;   // checked on the host: global minimum equal across variants
+    if (hits == 0xFFFFFFFFu)
+        sink[threadIdx.x] = um + hits;
+    if (lane == 0) {
+        stamps[2 * wave] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[2 * wave + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 static unsigned long long *g_stamps;
+typedef void (*probe_fn)(const h8 *, const float *, const h8 *, const float *, long long, float *, unsigned long long *);
+template <int VAR>
+static int run_k(const char *name, probe_fn fn, unsigned blocks, const h8 *rf, const float *rn, const h8 *qf, const float *thr, long long ntiles, float *sink);
 template <int VAR>
 static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, const float *thr, long long ntiles, float *sink)
+{
+    return run_k<VAR>(name, probe_kernel<VAR>, 512u, rf, rn, qf, thr, ntiles, sink);
+}
+template <int VAR>
+static int run_k(const char *name, probe_fn fn, unsigned blocks, const h8 *rf, const float *rn, const h8 *qf, const float *thr, long long ntiles, float *sink)
 {
     hipEvent_t a, b;
     CHK(hipEventCreate(&a));
@@ -239,7 +448,11 @@ static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, co
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         CHK(hipEventRecord(a));
-        hipLaunchKernelGGL(probe_kernel<VAR>, dim3(512), dim3(FILTER_BLOCK), 0, 0, rf, rn, qf, thr, ntiles, sink, g_stamps);
+        if (rep == 0) {
+            CHK(hipMemset(g_stamps, 0, 3 * 4096 * 8));
+            CHK(hipMemset(sink + 1024, 0x7f, 2048 * 64 * 4));   // 0x7f7f7f7f = 3.4e38
+        }
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(FILTER_BLOCK), 0, 0, rf, rn, qf, thr, ntiles, sink, g_stamps);
         CHK(hipEventRecord(b));
         CHK(hipEventSynchronize(b));
         float ms;
@@ -312,12 +525,19 @@ static int run(const char *name, const h8 *rf, const float *rn, const h8 *qf, co
             printf("    per-wave us: min %.0f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f  (%zu waves)\n", dur.front(),
                    dur[dur.size() / 10], dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(), dur.size());
     }
-    printf("%-44s %8.3f ms  %7.1f TFLOP/s  %6.1f ns = %5.1f cycles per tile per SIMD at the in-kernel clock %.2f GHz\n", name, best,
-           tiles * 32768 / (best * 1e-3) / 1e12, best * 1e6 / (tiles / 1024.0), best * 1e6 / (tiles / 1024.0) * ghz, ghz);
+    float gmin = 3.4e38f;
+    {
+        std::vector<float> hm(2048 * 64);
+        CHK(hipMemcpy(hm.data(), sink + 1024, hm.size() * 4, hipMemcpyDeviceToHost));
+        for (float v : hm)
+            gmin = std::min(gmin, v);
+    }
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s  %6.1f ns = %5.1f cycles per tile per SIMD at the in-kernel clock %.2f GHz  (global min score %.6g)\n", name, best,
+           tiles * 32768 / (best * 1e-3) / 1e12, best * 1e6 / (tiles / 1024.0), best * 1e6 / (tiles / 1024.0) * ghz, ghz, gmin);
     return 0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     const long long n = 1ll << 24, ntiles = n / 32;
     float *refs, *rn, *thr, *sink, *q;
@@ -328,7 +548,7 @@ int main()
     CHK(hipMalloc(&qf, 32 * 1024));
     CHK(hipMalloc(&rn, n * 4));
     CHK(hipMalloc(&thr, 1024 * 4));
-    CHK(hipMalloc(&sink, 4096));
+    CHK(hipMalloc(&sink, (1024 + 2048 * 64) * 4));
     CHK(hipMalloc(&g_stamps, 3 * 4096 * 8));
     CHK(hipMemset(g_stamps, 0, 3 * 4096 * 8));
     CHK(knn_synth_fill_launch(refs, n * 16, 1001, 0, 0));
@@ -344,7 +564,25 @@ int main()
     hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (const f4v *)refs, n, n, center, 2.0f, rf, rn, out, (unsigned *)sink, 0u);
     hipLaunchKernelGGL(knn_frag_kernel, dim3(4), dim3(256), 0, 0, q, 1024ll, 1024ll, 16, 1, center, 2.0f, -2.0f, 0.0f, qf, sink + 0, out, 0, (unsigned *)nullptr, (float *)nullptr, (unsigned *)nullptr, 0u);
     CHK(hipDeviceSynchronize());
-    for (int round = 0; round < 2; ++round) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const bool r2 = argc > 1 && !strcmp(argv[1], "r2");
+    const int only = argc > 2 ? atoi(argv[2]) : -1;   // run a single variant
+    for (int round = 0; r2 && round < 3; ++round) {
+        if (only < 0 || only == 0) if (run<0>("0 production (8 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 1) if (run<1>("1 running min (8 min3)", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 5) if (run<5>("5 MFMA stream only", rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 21) if (run_k<21>("21 run[t] NACC 3, 1 wave/SIMD, 3 sets", probe_run_kernel<3, 1, 3, true, true>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 25) if (run_k<25>("25 as 21, no tree (MFMA only)", probe_run_kernel<3, 1, 3, true, true, 0>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 26) if (run_k<26>("26 as 21, 4-op tree", probe_run_kernel<3, 1, 3, true, true, 4>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 31) if (run_k<31>("31 as 21, 6-op tree", probe_run_kernel<3, 1, 3, true, true, 6>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 32) if (run_k<32>("32 as 21, 12-op tree", probe_run_kernel<3, 1, 3, true, true, 12>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 35) if (run_k<35>("35 MFMA only, srcC = literal 0", probe_run_kernel<3, 1, 3, true, true, 20>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 36) if (run_k<36>("36 MFMA only, chain srcC = vdst", probe_run_kernel<3, 1, 3, true, true, 21>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 37) if (run_k<37>("37 MFMA only, C and D in AGPRs, B VGPR", probe_run_kernel<3, 1, 3, true, false, 22>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 38) if (run_k<38>("38 MFMA only (as 25), 2 waves/SIMD NACC 2", probe_run_kernel<2, 2, 2, false, true, 0>, 512u, rf, rn, qf, thr, ntiles, sink)) return 1;
+        if (only < 0 || only == 39) if (run_k<39>("39 as 21, srcC = literal 0 + full tree", probe_run_kernel<3, 1, 3, true, true, 23>, 256u, rf, rn, qf, thr, ntiles, sink)) return 1;
+    }
+    for (int round = 0; !r2 && round < 2; ++round) {
         if (run<0>("0 production (8 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<1>("1 running min (8 min3)", rf, rn, qf, thr, ntiles, sink)) return 1;
         if (run<2>("2 half tree (4 min3 + cmp + branch)", rf, rn, qf, thr, ntiles, sink)) return 1;
