@@ -54,11 +54,74 @@ def parse_args():
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="launcher rehearsal without GPUs: the ranks only form a gloo group, min-reduce packed keys "
+                         "and rank 0 prints one JSON line (tests/test_host_logic.py)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: start one rank per GPU with
+    torch.distributed.run as a CHILD process (the parent never touches a GPU and never execs after
+    one has been initialised), relay rank 0's single JSON line, return the launcher's exit code."""
+    import socket
+    import subprocess
+    import torch
+    if not args.selftest_launcher:
+        have = torch.cuda.device_count()      # counting devices does not initialise the GPU
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node: nothing was run\n"
+                             % (args.gpus, have))
+            return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{"):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank failed (torch.distributed.run exit code %d)\n" % rc)
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        return 4
+    print(line, flush=True)
+    return 0
+
+
+def selftest_launcher():
+    """What the N > 1 path does around its kernels, on the CPU: gloo group, MIN all-reduce of packed
+    (distance bits << 32 | index) keys viewed as int64, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("KNN_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(7)
+    # rank r holds distance r + 1 for query 0 and distance world - r for query 1
+    keys = torch.tensor([((rank + 1) << 32) | (100 + rank), ((world - rank) << 32) | (200 + rank)], dtype=torch.int64)
+    dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "keys": keys.tolist()}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.selftest_launcher:
+        return selftest_launcher()
     import numpy as np
     import torch
     import multicore_hw2_amd as pkg
@@ -67,9 +130,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world     # launched by torchrun: the world size is the number of GPUs
     if args.workload in WORKLOADS:
         k, m, n = WORKLOADS[args.workload]
         wname = args.workload.upper()
@@ -244,18 +305,43 @@ def main():
                     "valu_lane_ops_per_s": lane_ops / (kern_avg_ms * 1e-3),
                     "valu_frac": lane_ops / (kern_avg_ms * 1e-3) / VALU_LANE_OPS_PEAK}
         # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json); only quoted for the
-        # workload/kernel it was measured on.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_c3_pmc_traffic.json")
+        # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json).  Quoted only when the profile
+        # was taken on the kernel source that is running now (the profile records the sha256 of
+        # knn_filter.hip + knn_exact.hip); a stale profile is named, not used.
+        pmc_path = os.path.join(ROOT, "profiles", "r02_c3_pmc_traffic.json")
         if wname == "C3" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                pmc = json.load(f)["kernels"]
-            kname = "_Z17knn_filter_kernelILi1ELi32EE" if path_taken == 2 else "void knn_exact_qreg<16, 2>"
-            for name, ent in pmc.items():
-                if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
-                    roof["traffic"] = ent["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r01_c3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
-                                             "separate passes; read bytes = 2 x FETCH_SIZE KiB, gfx950)"
+                pmc_doc = json.load(f)
+            if pmc_doc.get("kernel_source_sha256") == kernel_source_sha():
+                kname = "_Z17knn_filter" if path_taken == 2 else "void knn_exact_qreg<16, 2>"
+                best = None
+                for name, ent in pmc_doc["kernels"].items():
+                    if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
+                        if best is None or ent["hbm_bytes_per_launch"] > best["hbm_bytes_per_launch"]:
+                            best = ent
+                if best is not None:
+                    roof["traffic"] = best["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r02_c3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
+                                             "separate passes; read bytes = 2 x FETCH_SIZE KiB, gfx950); same kernel source"
+                    roof["hbm_frac_physical"] = best["hbm_bytes_per_launch"] / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            else:
+                roof["traffic_source"] = "profiles/r02_c3_pmc_traffic.json is from another build of the kernels: not quoted"
+        if path_taken == 2 and k <= 16:
+            # Where this kernel's ceiling is (profiles/r02_filter_probe.txt, r02_cvt_probe.txt): one MFMA
+            # 32x32x16 per (32 refs x 32 queries) tile pair leaves 16 fp32 scores per lane whose reduction
+            # takes 8 v_min3_f32; hand-scheduled, one wave per SIMD, that stream runs at 50-54 shader
+            # cycles per tile pair (the min3 issue at ~5 cycles each, the MFMA's issue + C-tile fetch
+            # ~10-14; the matrix pipe itself needs 32) and the chip holds ~1.8 GHz under it.
+            pairs_per_simd = (n_local / 32.0) * ((m + 31) // 32) / (256 * 4)
+            roof["ceiling"] = {
+                "what": "vector-issue floor of 'score every pair' at k <= 16: 1 MFMA + 8 v_min3_f32 per 32x32 tile pair",
+                "cycles_per_tile_pair": 50.0, "tile_pairs_per_simd": pairs_per_simd,
+                "ms_at_2.4GHz": pairs_per_simd * 50.0 / 2.4e9 * 1e3,
+                "ms_at_measured_clock_1.8GHz": pairs_per_simd * 50.0 / 1.8e9 * 1e3,
+                "matrix_pipe_ms_at_2.4GHz": pairs_per_simd * 32.0 / 2.4e9 * 1e3,
+                "source": "profiles/r02_filter_probe.txt (variants 21-39), profiles/r02_cvt_probe.txt",
+                "note": "the north_star's 0.70 of HBM roofline (0.19 ms) is below this floor: not reachable by a "
+                        "kernel that scores every (query, reference) pair at m = 1024, k = 16"}
         if alone_n:
             roof["kernel_alone_ms"] = alone_ms / alone_n      # same kernel, nothing else on the GPU
             roof["frac_alone"] = roof["frac"] * kern_avg_ms / (alone_ms / alone_n)
@@ -271,9 +357,11 @@ def main():
         roof["algorithmic_bytes_per_launch"] = alg_bytes
 
         cpu = None
+        cpu_all = None
         parity = None
         if world == 1 and args.cpu_queries != 0:
             cpu = cpu_baseline(k, m, n, args.cpu_queries, result_idx)
+            cpu_all = cpu_baseline_all_cores(k, m, n, cpu["value"], result_idx)
         elif world > 1 and args.cpu_queries != 0:
             # no CPU baseline at N > 1, but never report a number for wrong answers: the reduced
             # result of the last step must match the oracle on a few queries of the full set
@@ -283,7 +371,7 @@ def main():
             "metric": "queries/sec (brute-force 1-NN, bit-exact vs v0), m=%d n=%d k=%d" % (m, n, k),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 results (f16 MFMA filter + f32 exact re-rank)" if path_taken == 2 else "f32", "data": "synthetic",
             "config": {"workload": "%s: k=%d m=%d n=%d uniform[0,1) fp32, refs resident in HBM, sharded over n" %
                                    (wname, k, m, n),
                        "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank"}.get(path_taken),
@@ -293,6 +381,8 @@ def main():
                        if world > 1 else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if cpu_all is not None:
+            line["cpu_baseline_all_cores"] = cpu_all
         if parity:
             line["parity_spot_check"] = parity
         sys.stdout.flush()
@@ -303,6 +393,15 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("knn_filter.hip", "knn_exact.hip"):
+        with open(os.path.join(ROOT, "multicore_hw2_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def parity_spot_check(k, m, n, nq, gpu_idx):
@@ -344,6 +443,28 @@ def cpu_baseline(k, m, n, cpu_queries, gpu_idx):
             "sample": "first %d of %d queries against all %d refs, serial oracle (v0 restatement), %.1f s; "
                       "GPU indices identical on the sample" % (cpu_queries, m, n, dt),
             "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_all_cores(k, m, n, serial_qps, gpu_idx):
+    """'v0 x P cores' (BASELINE.md §3): the same oracle with OpenMP over queries (the per-query
+    loop is untouched, so results are bit-identical) on all host cores, on a sample sized for ~10 s from
+    the serial rate; also a parity check of that many more queries."""
+    from tests.oracle_lib import Oracle
+    o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))      # a one-GPU box's CPU share is 16 threads, whatever the host has
+    q = int(max(cores, min(m, 10.0 * serial_qps * cores)))
+    q = min(m, q)
+    Q = o.synth(m * k, 1000)
+    R = o.synth(n * k, 1001)
+    t0 = time.perf_counter()
+    want = o.v0(k, Q[:q * k], R, threads=cores)
+    dt = time.perf_counter() - t0
+    if not (want == gpu_idx[:q]).all():
+        raise SystemExit("PARITY FAILURE: GPU indices differ from the CPU oracle on the all-cores sample")
+    return {"value": q / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "first %d of %d queries against all %d refs, oracle with OpenMP over queries on %d threads, %.1f s; "
+                      "GPU indices identical on the sample" % (q, m, n, cores, dt)}
 
 
 if __name__ == "__main__":

@@ -101,9 +101,11 @@ int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream)
 int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
                          unsigned long long *keys_dev, void *stream);
 
-/* Same, using query workspace `slot` (0 or 1) of the index.  The index owns two independent
- * workspaces, so two batches may be in flight at once on two streams (e.g. batch i+1's small
- * preparation kernels beside batch i's scan); calls that share a slot must be stream-ordered.
+/* Same, using query workspace `slot` (0 .. 3) of the index.  The index owns four independent
+ * workspaces, so up to four batches may be in flight at once on their own streams (e.g. batch
+ * i+1's small preparation kernels beside batch i's scan); calls that share a slot must be
+ * stream-ordered, and one index must not be driven from two host threads at once (its event and
+ * statistics bookkeeping is not locked).  A slot outside 0 .. 3 is KNN_EINVAL.
  * knn_index_query_keys == slot 0. */
 int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
                               unsigned long long *keys_dev, void *stream);

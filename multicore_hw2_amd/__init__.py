@@ -166,7 +166,7 @@ class KnnIndex:
 
     def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0):
         """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m].
-        slot 0/1 picks one of the index's two independent query workspaces."""
+        slot 0..3 picks one of the index's four independent query workspaces."""
         _check(lib().knn_index_query_keys_slot(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
                                                ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream)))
 

@@ -205,3 +205,97 @@ def test_two_rank_gloo_minloc_allreduce_matches_v0(tmp_path, oracle):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launches_its_own_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus N` outside torchrun starts N ranks itself (child process, nothing
+    GPU-related in the parent), relays rank 0's single JSON line and passes a rank's failure on.
+    Rehearsed on the CPU with the gloo self-test mode: same launcher, same rendezvous."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--selftest-launcher"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    doc = json.loads(lines[0])
+    # MIN over ranks of (distance << 32 | index): query 0 -> rank 0's key, query 1 -> rank 1's key
+    assert doc == {"launcher_selftest": True, "n_gpus": 2, "keys": [(1 << 32) | 100, (1 << 32) | 201]}
+    # a failing rank makes the launcher fail, with no result line
+    env["KNN_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--selftest-launcher"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    # more GPUs asked for than the node has: a clear message and a non-zero exit, not a usage error
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("KNN_BENCH_SELFTEST_FAIL_RANK")
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 3 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+
+
+def test_error_returns_of_the_index_api_without_a_gpu():
+    """KNN_EINVAL / KNN_ENODEV come back as codes with a message (no GPU needed to see them)."""
+    _built_lib()
+    import multicore_hw2_amd as pkg
+    L = pkg.lib()
+    h = ctypes.c_void_p()
+    refs = np.zeros(16, dtype=np.float32)
+    rp = refs.ctypes.data_as(ctypes.c_void_p)
+    KNN_EINVAL, KNN_ENODEV = -1, -2
+    assert L.knn_index_create(None, 0, 4, 4, rp, 0, 0, None) == KNN_EINVAL
+    assert b"null out" in L.knn_last_error()
+    assert L.knn_index_create(ctypes.byref(h), 0, 0, 4, rp, 0, 0, None) == KNN_EINVAL        # k < 1
+    assert L.knn_index_create(ctypes.byref(h), 0, 4, -1, rp, 0, 0, None) == KNN_EINVAL       # n < 0
+    assert L.knn_index_create(ctypes.byref(h), 0, 4, 4, None, 0, 0, None) == KNN_EINVAL      # no rows
+    assert L.knn_index_create(ctypes.byref(h), 0, 4, 4, rp, 0, 2**31, None) == KNN_EINVAL    # index beyond int32
+    assert b"int32" in L.knn_last_error()
+    assert L.knn_index_query_host(None, 1, rp, rp) == KNN_EINVAL
+    assert L.knn_index_query_keys_slot(None, 0, 1, rp, rp, None) == KNN_EINVAL
+    assert L.knn_keys_init(0, None, 5, None) == KNN_EINVAL
+    assert L.knn_index_timing(None, 1) == KNN_EINVAL
+    if pkg.device_count() == 0:
+        assert L.knn_index_create(ctypes.byref(h), 0, 4, 4, rp, 0, 0, None) == KNN_ENODEV
+        assert b"no HIP device" in L.knn_last_error()
+    else:
+        assert L.knn_index_create(ctypes.byref(h), 10**6, 4, 4, rp, 0, 0, None) == KNN_EINVAL  # device out of range
+
+
+def test_drop_in_entry_prints_the_reference_error_line_and_exits_1():
+    """The void entry has no error channel: like the reference's CHECK macro (core.h:77-87) it prints
+    `Error: <file>:<line>, code:<c>, reason: <text>` and exit(1)s.  Run in a child process: bad
+    arguments anywhere, and 'no GPU' where there is none (the reference would compute on the CPU there,
+    core.cu:869-870; this library deliberately does not)."""
+    _built_lib()
+    child = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import multicore_hw2_amd as pkg\n"
+        "L = pkg.lib()\n"
+        "res = ctypes.POINTER(ctypes.c_int)()\n"
+        "buf = (ctypes.c_float * 16)()\n"
+        "mode = sys.argv[1]\n"
+        "if mode == 'badk':\n"
+        "    L.cudaCallback(0, 1, 1, buf, buf, ctypes.byref(res))\n"
+        "elif mode == 'null':\n"
+        "    L.cudaCallback(4, 1, 1, None, buf, ctypes.byref(res))\n"
+        "else:\n"
+        "    L.cudaCallback(4, 1, 4, buf, buf, ctypes.byref(res))\n"
+        "print('returned')\n" % ROOT)
+    pat = re.compile(r"^Error: \S*knn_api\.cpp:\d+, code:-?\d+, reason: .+$", re.M)
+    for mode in ("badk", "null"):
+        r = subprocess.run([sys.executable, "-c", child, mode], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, KNN_MI355X_NO_TORCH="1"))
+        assert r.returncode == 1 and "returned" not in r.stdout, (mode, r.returncode, r.stdout, r.stderr[-500:])
+        m = pat.search(r.stdout)
+        assert m and "code:-1" in m.group(0), r.stdout
+    import multicore_hw2_amd as pkg
+    if pkg.device_count() == 0:
+        r = subprocess.run([sys.executable, "-c", child, "nogpu"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, KNN_MI355X_NO_TORCH="1"))
+        assert r.returncode == 1 and "returned" not in r.stdout
+        m = pat.search(r.stdout)
+        assert m and "code:-2" in m.group(0) and "no CPU fallback" in m.group(0), r.stdout
