@@ -359,10 +359,10 @@ def main():
         cpu = None
         cpu_all = None
         parity = None
-        if world == 1 and args.cpu_queries != 0:
+        if dist is None and args.cpu_queries != 0:
             cpu = cpu_baseline(k, m, n, args.cpu_queries, result_idx)
             cpu_all = cpu_baseline_all_cores(k, m, n, cpu["value"], result_idx)
-        elif world > 1 and args.cpu_queries != 0:
+        elif dist is not None and args.cpu_queries != 0:
             # no CPU baseline at N > 1, but never report a number for wrong answers: the reduced
             # result of the last step must match the oracle on a few queries of the full set
             parity = parity_spot_check(k, m, n, 8, result_idx)
@@ -378,7 +378,7 @@ def main():
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "batches_in_flight": nstreams, "setup_steps": SETUP_STEPS,
                        "collective": ("rccl all_reduce(min) of %d x %d packed keys per %d batches" % (nbuf, m, nbuf))
-                       if world > 1 else None},
+                       if dist is not None else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu_all is not None:
@@ -412,7 +412,7 @@ def parity_spot_check(k, m, n, nq, gpu_idx):
     o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
     Q = o.synth(nq * k, 1000)
     R = o.synth(n * k, 1001)
-    want = o.v0(k, Q, R)
+    want = o.v0(k, Q, R, threads=16)
     if not (want == gpu_idx[:nq]).all():
         raise SystemExit("PARITY FAILURE: reduced multi-GPU indices differ from the CPU oracle")
     return "%d/%d sampled queries identical to the CPU oracle over all %d refs" % (nq, nq, n)
