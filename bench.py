@@ -174,7 +174,10 @@ def main():
     # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
     # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
-    inflight = args.inflight if args.inflight > 0 else (2 if n_local >= (1 << 24) else 3)
+    # (the library chains the scans of different slots when one scan is long: two in flight are enough then)
+    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8
+    long_scan = n_local >= (1 << 24) or (kt >= 4 and m >= 512 and (n_local / 32.0) * ((m + 31) // 32) * kt >= (1 << 24))
+    inflight = args.inflight if args.inflight > 0 else (2 if long_scan else 3)
     nbuf = 1 if args.serial else max(1, min(4, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.
     keys_all = torch.empty((2, nbuf, m), dtype=torch.int64, device=dev)
@@ -348,8 +351,7 @@ def main():
         roof["kernel_avg_ms"] = kern_avg_ms
         roof["kernel_launches_timed"] = launches
         chain = pkg.get_option("filter_chain") if hasattr(pkg, "get_option") else 0
-        roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or
-                                                          (chain == 0 and n_local < (1 << 24))))
+        roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or (chain == 0 and not long_scan)))
         if roof["launches_overlap"]:
             roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
                            "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restr
         bidx[2 * p + 1] = 0u;
     }
 
-    const long long i0 = (long long)blockIdx.x * refs_per_block;
+    // Slices are strided over: an ordinary launch has one block per slice; the GATED launch (the filter's
+    // device-side fallback, almost always a no-op) has at most ~5 resident blocks per CU, so looking at
+    // the flag costs a few hundred blocks instead of a full grid queued on every query.
+    for (long long i0 = (long long)blockIdx.x * refs_per_block; i0 < n; i0 += (long long)gridDim.x * refs_per_block) {
     const long long i1 = min(n, i0 + refs_per_block);
     unsigned gidx = (unsigned)(base + i0);  // global index of the current reference (low 32 bits)
     const float *__restrict__ r = R + (size_t)i0 * K;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restr
             }
         }
     }
+    }  // slices
 
 #pragma unroll
     for (int p = 0; p < QP; ++p) {
@@ -177,9 +181,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qregn(const float *__rest
     float best0 = INFINITY, best1 = INFINITY;
     unsigned bidx0 = 0u, bidx1 = 0u;
 
-    const long long i0 = (long long)blockIdx.x * refs_per_block;
+    // Slices are strided over: an ordinary launch has one block per slice; the GATED launch (the filter's
+    // device-side fallback, almost always a no-op) has at most ~5 resident blocks per CU, so looking at
+    // the flag costs a few hundred blocks instead of a full grid queued on every query.
+    for (long long i0 = (long long)blockIdx.x * refs_per_block; i0 < n; i0 += (long long)gridDim.x * refs_per_block) {
     const long long i1 = min(n, i0 + refs_per_block);
-    unsigned gidx = (unsigned)(base + i0);
+    unsigned gidx = (unsigned)(base + i0);  // global index of the current reference (low 32 bits)
     const float *__restrict__ r = R + (size_t)i0 * k;
     for (long long i = i0; i < i1; ++i, ++gidx, r += k) {
         T acc = L::make(0.0f, 0.0f);
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qregn(const float *__rest
             bidx1 = gidx;
         }
     }
+    }  // slices
     if (q0 + lane < m && best0 < INFINITY) {
         const u64 key = pack_key(best0, bidx0);
         if (key < keys[q0 + lane])
@@ -255,9 +263,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__rest
     float best = INFINITY;
     unsigned bidx = 0u;
 
-    const long long i0 = (long long)blockIdx.x * refs_per_block;
+    // Slices are strided over: an ordinary launch has one block per slice; the GATED launch (the filter's
+    // device-side fallback, almost always a no-op) has at most ~5 resident blocks per CU, so looking at
+    // the flag costs a few hundred blocks instead of a full grid queued on every query.
+    for (long long i0 = (long long)blockIdx.x * refs_per_block; i0 < n; i0 += (long long)gridDim.x * refs_per_block) {
     const long long i1 = min(n, i0 + refs_per_block);
-    unsigned gidx = (unsigned)(base + i0);
+    unsigned gidx = (unsigned)(base + i0);  // global index of the current reference (low 32 bits)
     const float *__restrict__ r = R + (size_t)i0 * K;
 #pragma unroll 4
     for (long long i = i0; i < i1; ++i, ++gidx, r += K) {
@@ -273,6 +284,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__rest
             bidx = gidx;
         }
     }
+    }  // slices
     if (qi < m && best < INFINITY) {
         const u64 key = pack_key(best, bidx);
         if (key < keys[qi])
@@ -720,6 +732,18 @@ SliceGeom slice_refs(long long n, unsigned qgroups, int num_cu, long long min_re
     return g;
 }
 
+// Blocks along the slice axis: one per slice, except for a gated (almost always no-op) launch, which
+// gets what is resident at once (5 blocks per CU at these kernels' register counts) and strides.
+unsigned slice_grid(const SliceGeom &g, unsigned qgroups, int num_cu, const unsigned *gate)
+{
+    if (!gate)
+        return g.nslices;
+    unsigned cap = (unsigned)num_cu * 5u / (qgroups ? qgroups : 1u);
+    if (cap < 1u)
+        cap = 1u;
+    return g.nslices < cap ? g.nslices : cap;
+}
+
 template <int K>
 hipError_t launch_qreg_k(int m, long long n, long long base, const float *q, const float *r,
                          u64 *keys, int num_cu, const unsigned *gate, hipStream_t s)
@@ -728,17 +752,17 @@ hipError_t launch_qreg_k(int m, long long n, long long base, const float *q, con
     if (m > 3 * KNN_WAVE * KNN_WAVES) {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 4 * KNN_WAVE);
         const SliceGeom g = slice_refs(n, qg, num_cu, 32);
-        hipLaunchKernelGGL((knn_exact_qreg<K, 2>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
+        hipLaunchKernelGGL((knn_exact_qreg<K, 2>), dim3(slice_grid(g, qg, num_cu, gate), qg), dim3(KNN_BLOCK), 0, s, q, r,
                            m, n, base, keys, g.refs_per_block, gate);
     } else if (m > KNN_WAVE * KNN_WAVES) {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * 2 * KNN_WAVE);
         const SliceGeom g = slice_refs(n, qg, num_cu, 32);
-        hipLaunchKernelGGL((knn_exact_qreg<K, 1>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r,
+        hipLaunchKernelGGL((knn_exact_qreg<K, 1>), dim3(slice_grid(g, qg, num_cu, gate), qg), dim3(KNN_BLOCK), 0, s, q, r,
                            m, n, base, keys, g.refs_per_block, gate);
     } else {
         const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * KNN_WAVE);
         const SliceGeom g = slice_refs(n, qg, num_cu, 32);
-        hipLaunchKernelGGL((knn_exact_qreg1<K>), dim3(g.nslices, qg), dim3(KNN_BLOCK), 0, s, q, r, m,
+        hipLaunchKernelGGL((knn_exact_qreg1<K>), dim3(slice_grid(g, qg, num_cu, gate), qg), dim3(KNN_BLOCK), 0, s, q, r, m,
                            n, base, keys, g.refs_per_block, gate);
     }
     return hipGetLastError();
@@ -811,7 +835,7 @@ hipError_t knn_exact_launch(int k, int m, long long n, long long base, const flo
             const bool pack = kc <= 4;
             const unsigned qg = (unsigned)knn_divup(m, KNN_WAVES * (pack ? 2 : 1) * KNN_WAVE);
             const SliceGeom g = slice_refs(n, qg, num_cu, 32);
-            const dim3 grid(g.nslices, qg), block(KNN_BLOCK);
+            const dim3 grid(slice_grid(g, qg, num_cu, gate), qg), block(KNN_BLOCK);
 #define KNN_QREGN(KCV, PK)                                                                                  \
     hipLaunchKernelGGL((knn_exact_qregn<KCV, PK>), grid, block, 0, s, q, r, k, m, n, base, keys, g.refs_per_block, gate)
             switch (kc) {

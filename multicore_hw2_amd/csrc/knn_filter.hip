@@ -1502,11 +1502,12 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     FTRY(hipGetLastError());
     if (!st.scan_done)
         FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
-    // Scans of different slots: free to overlap (heads fill the other's tail, no event round trip:
-    // -17 % per step at n = 2M, -5 % at 8M, -2.5 % at 16M with three batches in flight) unless the
-    // shard is >= 16M rows, where they are chained so that a launch's duration stays that of the kernel
-    // itself (the roofline is quoted from it; two 256-VGPR scans sharing the SIMDs take ~1.7x as long each).
-    const bool no_chain = st.chain_policy == 2 || (st.chain_policy == 0 && st.ntiles < (1ll << 19));
+    // Scans of different slots: chained (one after the other) when a scan is long — >= 2^24 MFMAs per launch,
+    // ~0.4 ms — free to overlap when it is short.  Three overlapping deep-K scans stretched each launch from
+    // 0.83 to 1.45-1.64 ms at C5 (k 128, m = n = 65536: 2^25 MFMAs) for a 1.04 ms step; chained, a launch's
+    // duration is the kernel's own and the small kernels of the next batch still run beside it.
+    const bool no_chain = st.chain_policy == 2 ||
+                          (st.chain_policy == 0 && (double)st.ntiles * (double)qtiles * (double)KT < (double)(1ll << 24));
     if (st.scan_recorded && !no_chain)
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
