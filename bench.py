@@ -174,9 +174,8 @@ def main():
     # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
     # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
-    # (the library chains the scans of different slots when one scan is long: two in flight are enough then)
-    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8
-    long_scan = n_local >= (1 << 24) or (kt >= 4 and m >= 512 and (n_local / 32.0) * ((m + 31) // 32) * kt >= (1 << 24))
+    # (the library chains the scans of different slots for shards of >= 16M rows: two in flight are enough then)
+    long_scan = n_local >= (1 << 24)
     inflight = args.inflight if args.inflight > 0 else (2 if long_scan else 3)
     nbuf = 1 if args.serial else max(1, min(4, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.

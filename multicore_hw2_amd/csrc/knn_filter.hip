@@ -1502,12 +1502,12 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     FTRY(hipGetLastError());
     if (!st.scan_done)
         FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
-    // Scans of different slots: chained (one after the other) when a scan is long — >= 2^24 MFMAs per launch,
-    // ~0.4 ms — free to overlap when it is short.  Three overlapping deep-K scans stretched each launch from
-    // 0.83 to 1.45-1.64 ms at C5 (k 128, m = n = 65536: 2^25 MFMAs) for a 1.04 ms step; chained, a launch's
-    // duration is the kernel's own and the small kernels of the next batch still run beside it.
-    const bool no_chain = st.chain_policy == 2 ||
-                          (st.chain_policy == 0 && (double)st.ntiles * (double)qtiles * (double)KT < (double)(1ll << 24));
+    // Scans of different slots: free to overlap unless the shard is >= 16M rows (as in launch_filter).
+    // Chaining the deep-K scans was measured at C5 (k 128, m = n = 65536; profiles/r02_c5_chain_ab.txt): a
+    // launch's duration drops from 1.64 to 1.00 ms (0.84 with the GPU to itself) but the step goes UP, 1.043 ->
+    // 1.081 ms: the other batch's sample pass, re-rank (640k records) and fragment kernels are ~0.25 ms of real
+    // work that overlapping scans were absorbing in each other's tails.
+    const bool no_chain = st.chain_policy == 2 || (st.chain_policy == 0 && st.ntiles < (1ll << 19));
     if (st.scan_recorded && !no_chain)
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
