@@ -110,6 +110,20 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
 int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
                               unsigned long long *keys_dev, void *stream);
 
+/* The path's one exchange step, for callers that keep one index per GPU in ONE process: min-reduce the
+ * GPUs' key arrays with RCCL — ncclAllReduce(ncclUint64, ncclMin) per device inside
+ * ncclGroupStart/End over xGMI, communicators from ncclCommInitAll created once per device set.
+ * Replaces the reference's host gather + CPU re-rank (core.cu:925-957).
+ *   devices[g]    HIP device of key array g (each device at most once)
+ *   keys_dev[g]   m packed keys on devices[g]; on completion every array holds the elementwise
+ *                 unsigned minimum (= lexicographic (distance, index) minimum) of all of them
+ *   streams[g]    hipStream_t as void* the reduction of array g is enqueued on (NULL array or NULL
+ *                 entries = default stream); stream-ordered after the queries that wrote the keys
+ * One process per GPU (bench.py) uses torch.distributed's all_reduce(MIN) on the same keys instead.
+ * librccl is opened at first use; KNN_EHIP with the reason if it cannot be. */
+int knn_keys_allreduce_min(int ndev, const int *devices, unsigned long long *const *keys_dev, int m,
+                           void *const *streams);
+
 /* out_dev[j] = (int)(keys_dev[j] & 0xFFFFFFFF) (async on stream). */
 int knn_keys_to_indices(int device, const unsigned long long *keys_dev, int m, int *out_dev,
                         void *stream);
@@ -129,6 +143,11 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
  *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
  *             (shards of at least 32 MiB)
+ *   "rccl"    cudaCallback only: how the shards' keys are merged: 0 = RCCL all-reduce when the set
+ *             is split over several GPUs (one shard each), host merge otherwise; 1 = RCCL always
+ *             (also with one GPU: a 1-rank communicator); 2 = host merge always.
+ *             knn_get_option("rccl_reductions") counts the merges RCCL has done,
+ *             knn_get_option("rccl_version") is the loaded library's NCCL_VERSION_CODE (0: none)
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_destroy", "knn_keys_init", "knn_index_query_keys", "knn_keys_to_indices",
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
-    "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim",
+    "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim", "knn_keys_allreduce_min",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -221,6 +221,18 @@ def keys_init(keys_dev, m, device=0, stream=0):
 def keys_to_indices(keys_dev, m, out_dev, device=0, stream=0):
     _check(lib().knn_keys_to_indices(int(device), ctypes.c_void_p(int(keys_dev)), int(m),
                                      ctypes.c_void_p(int(out_dev)), ctypes.c_void_p(stream)))
+
+
+def keys_allreduce_min(devices, keys_dev, m, streams=None):
+    """RCCL min-reduction of one key array per GPU of this process (knn_keys_allreduce_min)."""
+    n = len(devices)
+    devs = (ctypes.c_int * n)(*[int(d) for d in devices])
+    ptrs = (ctypes.c_void_p * n)(*[int(p) for p in keys_dev])
+    strs = (ctypes.c_void_p * n)(*[int(s) for s in streams]) if streams is not None else None
+    f = lib().knn_keys_allreduce_min
+    f.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                  ctypes.POINTER(ctypes.c_void_p)]
+    _check(f(n, devs, ptrs, int(m), strs))
 
 
 def synth_fill_device(dst_dev, count, seed, first=0, device=0, stream=0):

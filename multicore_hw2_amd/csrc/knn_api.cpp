@@ -68,6 +68,8 @@ std::atomic<long long> g_opt_filter_qt{0};
 std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
+std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
+std::atomic<long long> g_rccl_reductions{0}; // cudaCallback merges done by the RCCL all-reduce
 
 struct DeviceGuard {
     int prev = -1;
@@ -311,6 +313,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_stream = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "rccl")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: rccl must be 0 (auto), 1 (always) or 2 (never: host merge)");
+        g_opt_rccl = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "filter_rounds")) {
         if (value < 0 || value > 64)
             return fail(KNN_EINVAL, "knn_set_option: filter_rounds must be in [0, 64]");
@@ -334,6 +342,12 @@ long long knn_get_option(const char *name)
         return g_opt_filter_chain;
     if (name && !strcmp(name, "stream"))
         return g_opt_stream;
+    if (name && !strcmp(name, "rccl"))
+        return g_opt_rccl;
+    if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
+        return g_rccl_reductions;
+    if (name && !strcmp(name, "rccl_version"))      // read-only: NCCL_VERSION_CODE of the loaded RCCL, 0 if none
+        return knn_rccl_version();
     return -1;
 }
 
@@ -599,6 +613,28 @@ int knn_keys_to_indices(int device, const unsigned long long *keys_dev, int m, i
     return KNN_OK;
 }
 
+int knn_keys_allreduce_min(int ndev, const int *devices, unsigned long long *const *keys_dev, int m,
+                           void *const *streams)
+{
+    if (ndev < 1 || !devices || !keys_dev || m < 0)
+        return fail(KNN_EINVAL, "knn_keys_allreduce_min: bad arguments");
+    const int have = knn_device_count();
+    for (int g = 0; g < ndev; ++g) {
+        if (devices[g] < 0 || devices[g] >= have || (m > 0 && !keys_dev[g]))
+            return fail(KNN_EINVAL, "knn_keys_allreduce_min: bad device or null key array");
+        for (int h = 0; h < g; ++h)
+            if (devices[h] == devices[g])
+                return fail(KNN_EINVAL, "knn_keys_allreduce_min: a device appears twice (one key array per GPU)");
+    }
+    if (have < 1)
+        return fail(KNN_ENODEV, "knn_keys_allreduce_min: no HIP device visible");
+    std::string err;
+    static_assert(sizeof(unsigned long long) == sizeof(u64), "key type");
+    if (knn_rccl_allreduce_min(ndev, devices, (u64 *const *)keys_dev, m, (const hipStream_t *)streams, err) != 0)
+        return fail(KNN_EHIP, "knn_keys_allreduce_min", err.c_str());
+    return KNN_OK;
+}
+
 int knn_synth_fill_device(int device, float *dst_dev, long long count, unsigned long long seed,
                           long long first, void *stream)
 {
@@ -616,7 +652,9 @@ int knn_synth_fill_device(int device, float *dst_dev, long long count, unsigned 
 namespace {
 
 // Queries on the host, packed keys back on the host; everything else stays on `idx->device`.
-int query_keys_host(knn_index *idx, int m, const float *queries_host, u64 *keys_host)
+// keep_dev != nullptr: the keys stay on the device instead (*keep_dev = pooled buffer of m keys, complete
+// on return; the caller gives it back with pool_put) — the RCCL merge of cudaCallback reads them there.
+int query_keys_host(knn_index *idx, int m, const float *queries_host, u64 *keys_host, u64 **keep_dev = nullptr)
 {
     DeviceGuard guard(idx->device);
     if (!guard.ok)
@@ -638,14 +676,17 @@ int query_keys_host(knn_index *idx, int m, const float *queries_host, u64 *keys_
     if (rc == KNN_OK)
         rc = knn_index_query_keys(idx, m, q_dev, keys_dev, nullptr);
     if (rc == KNN_OK) {
-        e = hipMemcpy(keys_host, keys_dev, kbytes, hipMemcpyDeviceToHost);
+        e = keep_dev ? hipStreamSynchronize(nullptr) : hipMemcpy(keys_host, keys_dev, kbytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
             rc = fail(KNN_EHIP, "query: D2H keys", hipGetErrorString(e));
     }
     if (rc != KNN_OK)
         (void)hipDeviceSynchronize();  // nothing in flight may still use the buffers going back to the pool
     pool_put(idx->device, q_dev, qbytes);
-    pool_put(idx->device, keys_dev, kbytes);
+    if (keep_dev && rc == KNN_OK)
+        *keep_dev = keys_dev;
+    else
+        pool_put(idx->device, keys_dev, kbytes);
     return rc;
 }
 
@@ -677,7 +718,7 @@ namespace {
 // k = 16, m <= ~1300 the exact scan of a chunk takes less than its PCIe transfer, so the call
 // costs the transfer plus one chunk's scan.
 int run_shard_streamed(int device, int k, int m, long long rows, long long base, const float *queries_host,
-                       const float *refs_host, u64 *keys_host)
+                       const float *refs_host, u64 *keys_host, u64 **keep_dev = nullptr)
 {
     DeviceGuard guard(device);
     if (!guard.ok)
@@ -729,7 +770,7 @@ int run_shard_streamed(int device, int k, int m, long long rows, long long base,
             e = knn_exact_launch(k, m, r1 - r0, base + r0, q_dev, r_dev + (size_t)r0 * k, keys_dev, num_cu, nullptr,
                                  st.compute);
     }
-    if (e == hipSuccess)
+    if (e == hipSuccess && !keep_dev)
         e = hipMemcpyAsync(keys_host, keys_dev, kbytes, hipMemcpyDeviceToHost, st.compute);
     const hipError_t e_sync1 = hipStreamSynchronize(st.copy);
     const hipError_t e_sync2 = hipStreamSynchronize(st.compute);
@@ -741,7 +782,10 @@ int run_shard_streamed(int device, int k, int m, long long rows, long long base,
         (void)hipDeviceSynchronize();  // nothing in flight may still use the buffers going back to the pool
     pool_put(device, r_dev, rbytes);
     pool_put(device, q_dev, qbytes);
-    pool_put(device, keys_dev, kbytes);
+    if (keep_dev && e == hipSuccess)
+        *keep_dev = keys_dev;
+    else
+        pool_put(device, keys_dev, kbytes);
     if (e != hipSuccess)
         return fail(KNN_EHIP, "cudaCallback: streamed shard", hipGetErrorString(e));
     return KNN_OK;
@@ -777,14 +821,46 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
     std::vector<std::vector<u64>> shard_keys((size_t)shards);
     std::vector<int> shard_rc((size_t)shards, KNN_OK);
     std::vector<std::string> shard_err((size_t)shards);
+    // The exchange step.  Several GPUs with one shard each (the reference's configuration, core.cu:873):
+    // every shard leaves its m packed keys ON ITS DEVICE and one RCCL all-reduce(uint64, min) merges them
+    // (knn_rccl.cpp); device 0's copy comes back to the host.  More shards than devices (the single-GPU
+    // test hook), a single device, `rccl` = 2, or no usable librccl: the keys come back per shard and are
+    // min-merged on the host — the same unsigned minimum.
+    std::string rccl_why;
+    const bool rccl_wanted = g_opt_rccl != 2 && shards <= ndev && (g_opt_rccl == 1 || shards > 1);
+    const bool use_rccl = rccl_wanted && knn_rccl_available(&rccl_why) != 0;
+    if (rccl_wanted && !use_rccl && g_opt_rccl == 1) {
+        fail(KNN_EHIP, "cudaCallback: option rccl = 1 but RCCL cannot be used", rccl_why.c_str());
+        die(__FILE__, __LINE__, KNN_EHIP, g_err.c_str());
+    }
+    std::vector<u64 *> shard_dev_keys((size_t)shards, nullptr);   // use_rccl: pooled, on device g % ndev
 
     auto run_shard = [&](long long g) {
         const long long lo = std::min<long long>(g * per, n);
         const long long hi = std::min<long long>(lo + per, n);
         std::vector<u64> &keys = shard_keys[(size_t)g];
-        keys.assign((size_t)m, kKeyInit);
-        if (hi <= lo)
+        u64 **keep_dev = use_rccl ? &shard_dev_keys[(size_t)g] : nullptr;
+        if (!use_rccl)
+            keys.assign((size_t)m, kKeyInit);
+        if (hi <= lo) {
+            if (use_rccl) {   // an empty shard still takes part in the all-reduce: m keys of (+INF, 0)
+                DeviceGuard guard((int)(g % ndev));
+                u64 *kd = nullptr;
+                hipError_t e = guard.ok ? pool_get((int)(g % ndev), (size_t)m * sizeof(u64), (void **)&kd) : hipErrorInvalidDevice;
+                if (e == hipSuccess)
+                    e = knn_keys_fill_launch(kd, m, nullptr);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(nullptr);
+                if (e != hipSuccess) {
+                    shard_rc[(size_t)g] = fail(KNN_EHIP, "cudaCallback: empty shard keys", hipGetErrorString(e));
+                    shard_err[(size_t)g] = g_err;
+                    pool_put((int)(g % ndev), kd, (size_t)m * sizeof(u64));
+                } else {
+                    *keep_dev = kd;
+                }
+            }
             return;
+        }
         knn_index *idx = nullptr;
         // One-shot call: the filter layouts cost two extra passes over the shard plus a few
         // allocations, so build them only where that is cheaper than the exact VALU scan
@@ -813,7 +889,7 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
                               (g_opt_stream == 2 || t_streamed < t_staged);
         if (streamed) {
             const int rc = run_shard_streamed((int)(g % ndev), k, m, hi - lo, lo, searchPoints,
-                                              referencePoints + (size_t)lo * (size_t)k, keys.data());
+                                              referencePoints + (size_t)lo * (size_t)k, keys.data(), keep_dev);
             shard_rc[(size_t)g] = rc;
             if (rc != KNN_OK)
                 shard_err[(size_t)g] = g_err;
@@ -827,7 +903,7 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
                                    referencePoints + (size_t)lo * (size_t)k, 0, lo, nullptr, want_filter);
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == KNN_OK)
-            rc = query_keys_host(idx, m, searchPoints, keys.data());
+            rc = query_keys_host(idx, m, searchPoints, keys.data(), keep_dev);
         const auto t2 = std::chrono::steady_clock::now();
         knn_index_destroy(idx);
         if (trace) {
@@ -859,19 +935,62 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         for (auto &th : pool)
             th.join();
     }
-    for (long long g = 0; g < shards; ++g)
-        if (shard_rc[(size_t)g] != KNN_OK)
-            die(__FILE__, __LINE__, shard_rc[(size_t)g], shard_err[(size_t)g].c_str());
-
-    // Final reduce: unsigned min of packed keys == lexicographic (distance, global index).
-    int *out = (int *)malloc(sizeof(int) * (size_t)m);  // caller free()s (main.cu:98,175)
-    if (!out)
-        die(__FILE__, __LINE__, KNN_ENOMEM, "malloc(results)");
-    for (int j = 0; j < m; ++j) {
-        u64 best = kKeyInit;
+    auto release_dev_keys = [&]() {
         for (long long g = 0; g < shards; ++g)
-            best = std::min(best, shard_keys[(size_t)g][(size_t)j]);
-        out[j] = (int)(unsigned)(best & 0xFFFFFFFFull);
+            if (shard_dev_keys[(size_t)g]) {
+                DeviceGuard guard((int)(g % ndev));
+                pool_put((int)(g % ndev), shard_dev_keys[(size_t)g], (size_t)m * sizeof(u64));
+                shard_dev_keys[(size_t)g] = nullptr;
+            }
+    };
+    for (long long g = 0; g < shards; ++g)
+        if (shard_rc[(size_t)g] != KNN_OK) {
+            release_dev_keys();
+            die(__FILE__, __LINE__, shard_rc[(size_t)g], shard_err[(size_t)g].c_str());
+        }
+
+    int *out = (int *)malloc(sizeof(int) * (size_t)m);  // caller free()s (main.cu:98,175)
+    if (!out) {
+        release_dev_keys();
+        die(__FILE__, __LINE__, KNN_ENOMEM, "malloc(results)");
+    }
+    if (use_rccl) {
+        // Final reduce on the GPUs: ncclAllReduce(uint64, min) over the shards' keys, one D2H from shard 0's device.
+        std::vector<int> devs((size_t)shards);
+        for (long long g = 0; g < shards; ++g)
+            devs[(size_t)g] = (int)(g % ndev);
+        std::string err;
+        std::vector<u64> merged((size_t)m);
+        int rc = knn_rccl_allreduce_min((int)shards, devs.data(), shard_dev_keys.data(), m, nullptr, err);
+        if (rc == 0) {
+            DeviceGuard guard(devs[0]);
+            const hipError_t e = hipMemcpy(merged.data(), shard_dev_keys[0], (size_t)m * sizeof(u64), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                err = std::string("D2H of the reduced keys: ") + hipGetErrorString(e);
+                rc = -1;
+            }
+        }
+        for (long long g = 0; g < shards; ++g) {   // nothing may still be reading the buffers going back to the pool
+            DeviceGuard guard(devs[(size_t)g]);
+            (void)hipStreamSynchronize(nullptr);
+        }
+        release_dev_keys();
+        if (rc != 0) {
+            free(out);
+            fail(KNN_EHIP, "cudaCallback: RCCL key reduction", err.c_str());
+            die(__FILE__, __LINE__, KNN_EHIP, g_err.c_str());
+        }
+        ++g_rccl_reductions;
+        for (int j = 0; j < m; ++j)
+            out[j] = (int)(unsigned)(merged[(size_t)j] & 0xFFFFFFFFull);
+    } else {
+        // Host merge: unsigned min of packed keys == lexicographic (distance, global index).
+        for (int j = 0; j < m; ++j) {
+            u64 best = kKeyInit;
+            for (long long g = 0; g < shards; ++g)
+                best = std::min(best, shard_keys[(size_t)g][(size_t)j]);
+            out[j] = (int)(unsigned)(best & 0xFFFFFFFFull);
+        }
     }
     *results = out;
 }

@@ -108,6 +108,15 @@ struct FilterState {
 hipError_t knn_dev_alloc(void **p, size_t bytes);
 hipError_t knn_dev_free(void *p);
 
+// ---- RCCL exchange step (knn_rccl.cpp; librccl is dlopen'ed at first use) -------------------
+#ifdef __cplusplus
+#include <string>
+int knn_rccl_available(std::string *why);
+int knn_rccl_version();
+int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m, const hipStream_t *streams,
+                           std::string &err);
+#endif
+
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.

@@ -607,3 +607,42 @@ def test_index_policy_builds_the_filter_early_for_dimensions_without_a_compiled_
     ix.close()
     np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R))
     assert (path_taken == 2) == expect_filter, path_taken
+
+
+def test_rccl_exchange_step_with_a_one_device_communicator(oracle):
+    """The library's own collective (knn_rccl.cpp): ncclCommInitAll + ncclAllReduce(uint64, min) in a
+    group, here with the one GPU a test box has.  (a) the exported knn_keys_allreduce_min leaves a
+    1-rank reduction unchanged and rejects a device list with repeats; (b) cudaCallback with option
+    rccl = 1 merges through RCCL (counted) and stays bit-exact, for the staged and the streamed
+    one-shot paths; (c) rccl = 2 and more shards than devices take the host merge."""
+    dev = torch.device("cuda:0")
+    assert pkg.get_option("rccl_version") >= 20000           # librccl could be opened
+    m = 1000
+    keys = torch.randint(0, 2**62, (m,), dtype=torch.int64, device=dev)
+    before = keys.clone()
+    pkg.keys_allreduce_min([0], [keys.data_ptr()], m, streams=[torch.cuda.current_stream().cuda_stream])
+    torch.cuda.synchronize()
+    assert torch.equal(keys, before)
+    with pytest.raises(pkg.KnnError):
+        pkg.keys_allreduce_min([0, 0], [keys.data_ptr(), keys.data_ptr()], m)
+    with pytest.raises(pkg.KnnError):
+        pkg.keys_allreduce_min([7], [keys.data_ptr()], m)     # no such device here
+    try:
+        for (k, mm, n, stream) in [(16, 300, 70001, 0), (3, 1024, 1 << 20, 0), (16, 64, 1200001, 2), (5, 1, 7, 0)]:
+            Q, R = oracle.synth(mm * k, 51), oracle.synth(n * k, 52)
+            want = oracle.v0(k, Q, R)
+            pkg.set_option("stream", stream)
+            pkg.set_option("rccl", 1)
+            done = pkg.get_option("rccl_reductions")
+            np.testing.assert_array_equal(pkg.cudaCallback(k, mm, n, Q, R), want, err_msg=f"rccl {(k, mm, n)}")
+            assert pkg.get_option("rccl_reductions") == done + 1
+            pkg.set_option("rccl", 2)
+            np.testing.assert_array_equal(pkg.cudaCallback(k, mm, n, Q, R), want)
+            pkg.set_option("rccl", 0)
+            pkg.set_option("shards", 3)                       # more shards than GPUs: host merge
+            np.testing.assert_array_equal(pkg.cudaCallback(k, mm, n, Q, R), want)
+            pkg.set_option("shards", 0)
+            assert pkg.get_option("rccl_reductions") == done + 1
+    finally:
+        for name in ("rccl", "shards", "stream"):
+            pkg.set_option(name, 0)
