@@ -142,7 +142,11 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             (0 = chosen from m)
  *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
  *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
- *             (shards of at least 32 MiB)
+ *             (shards of at least 64 MiB)
+ *   "ingest"  indexes created from HOST rows (knn_index_create with refs_on_device = 0, and the
+ *             staged-filter case of cudaCallback): 0 = the rows go over in chunks and every chunk's
+ *             MFMA layouts are built as soon as it has landed (robust box from a strided host
+ *             sample), 1 = copy everything, then build (the box from full-range statistics)
  *   "rccl"    cudaCallback only: how the shards' keys are merged: 0 = RCCL all-reduce when the set
  *             is split over several GPUs (one shard each), host merge otherwise; 1 = RCCL always
  *             (also with one GPU: a 1-rank communicator); 2 = host merge always.

@@ -9,6 +9,7 @@
 #include "../../include/knn_mi355x.h"
 #include "knn_common.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -68,6 +69,7 @@ std::atomic<long long> g_opt_filter_qt{0};
 std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
+std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
 std::atomic<long long> g_rccl_reductions{0}; // cudaCallback merges done by the RCCL all-reduce
 
@@ -313,6 +315,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_stream = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "ingest")) {
+        if (value < 0 || value > 1)
+            return fail(KNN_EINVAL, "knn_set_option: ingest must be 0 (layouts built under the copy) or 1 (copy, then build)");
+        g_opt_ingest = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "rccl")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: rccl must be 0 (auto), 1 (always) or 2 (never: host merge)");
@@ -344,6 +352,8 @@ long long knn_get_option(const char *name)
         return g_opt_stream;
     if (name && !strcmp(name, "rccl"))
         return g_opt_rccl;
+    if (name && !strcmp(name, "ingest"))
+        return g_opt_ingest;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
         return g_rccl_reductions;
     if (name && !strcmp(name, "rccl_version"))      // read-only: NCCL_VERSION_CODE of the loaded RCCL, 0 if none
@@ -401,6 +411,16 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
         idx->num_cu = prop.multiProcessorCount;
 
     hipStream_t s = (hipStream_t)stream;
+    // MFMA filter layouts (skipped for small shards and when the exact path is forced)
+    idx->filter_wanted = build_filter > 0;
+    if (build_filter < 0) {
+        // library policy: shards of >= 65536 rows; for 32 < k <= 128 (3k+3 exact lane-ops per pair,
+        // one query per lane above k = 64) the MFMA filter pays off from 4096 rows already
+        build_filter = g_opt_path == 2 || n_local >= 65536 || (k > 32 && k <= 128 && n_local >= 4096);
+        idx->filter_wanted = build_filter && n_local < 65536 && g_opt_path != 2;
+    }
+    const bool want_layouts = n_local > 0 && g_opt_path != 1 && build_filter;
+    bool layouts_done = false;
     if (n_local > 0) {
         if (refs_on_device) {
             idx->refs = refs;
@@ -412,11 +432,21 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
                 delete idx;
                 return fail(KNN_ENOMEM, "knn_index_create: hipMalloc(refs)", hipGetErrorString(e));
             }
-            e = hipMemcpyAsync(idx->owned_refs, refs, bytes, hipMemcpyHostToDevice, s);
-            if (e == hipSuccess)
-                e = hipStreamSynchronize(s);  // the host buffer may be freed right after return
+            DeviceStreams ds;
+            if (want_layouts && g_opt_ingest != 1 && streams_get(device, &ds) == hipSuccess) {
+                // ingest: rows and filter layouts in one pass over PCIe (knn_filter_build_from_host)
+                e = hipStreamSynchronize(s);   // work the caller queued ahead of this call
+                if (e == hipSuccess)
+                    e = knn_filter_build_from_host(idx->filter, k, n_local, idx->owned_refs, refs, ds.copy, ds.compute);
+                layouts_done = e == hipSuccess;
+            } else {
+                e = hipMemcpyAsync(idx->owned_refs, refs, bytes, hipMemcpyHostToDevice, s);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(s);  // the host buffer may be freed right after return
+            }
             if (e != hipSuccess) {
-                (void)hipStreamSynchronize(s);
+                (void)hipDeviceSynchronize();
+                knn_filter_free(idx->filter);
                 pool_put(device, idx->owned_refs, bytes);
                 delete idx;
                 return fail(KNN_EHIP, "knn_index_create: H2D copy of refs", hipGetErrorString(e));
@@ -424,15 +454,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
             idx->refs = idx->owned_refs;
         }
     }
-    // MFMA filter layouts (skipped for small shards and when the exact path is forced)
-    idx->filter_wanted = build_filter > 0;
-    if (build_filter < 0) {
-        // library policy: shards of >= 65536 rows; for 32 < k <= 128 (3k+3 exact lane-ops per pair,
-        // one query per lane above k = 64) the MFMA filter pays off from 4096 rows already
-        build_filter = g_opt_path == 2 || n_local >= 65536 || (k > 32 && k <= 128 && n_local >= 4096);
-        idx->filter_wanted = build_filter && n_local < 65536 && g_opt_path != 2;
-    }
-    if (n_local > 0 && g_opt_path != 1 && build_filter) {
+    if (want_layouts && !layouts_done) {
         hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s);
         if (e == hipErrorOutOfMemory) {
             // no room for the fp16 layouts beside the rows: the index still works, exact kernels only
@@ -718,7 +740,7 @@ namespace {
 // k = 16, m <= ~1300 the exact scan of a chunk takes less than its PCIe transfer, so the call
 // costs the transfer plus one chunk's scan.
 int run_shard_streamed(int device, int k, int m, long long rows, long long base, const float *queries_host,
-                       const float *refs_host, u64 *keys_host, u64 **keep_dev = nullptr)
+                       const float *refs_host, u64 *keys_host, u64 **keep_dev = nullptr, int nchunks_hint = 8)
 {
     DeviceGuard guard(device);
     if (!guard.ok)
@@ -731,11 +753,14 @@ int run_shard_streamed(int device, int k, int m, long long rows, long long base,
     HIP_TRY(streams_get(device, &st));
     const size_t row_bytes = (size_t)k * sizeof(float);
     const size_t rbytes = (size_t)rows * row_bytes, qbytes = (size_t)m * row_bytes, kbytes = (size_t)m * sizeof(u64);
-    // up to 16 chunks, each 32..128 MiB (pageable copies have a fixed cost of ~0.1 ms each: sixteen
-    // 4 MiB chunks took 6-20 ms where one 64 MiB copy takes 1.3) and a multiple of 1024 rows
-    long long chunk_rows = (rows + 15) / 16;
-    const long long lo_rows = (long long)((32u << 20) / row_bytes) + 1, hi_rows = (long long)((128u << 20) / row_bytes);
-    chunk_rows = std::max(lo_rows, std::min(hi_rows, chunk_rows));
+    // Chunks of at least 32 MiB, multiples of 1024 rows.  Every pageable copy call costs ~0.25 ms of
+    // pipeline fill on top of its bytes (profiles/r02_ingest_timing.txt) and the call ends one chunk's
+    // scan after the last byte, so the count that minimises  0.25 ms * c + t_scan / c  is sqrt(t_scan / 0.25 ms)
+    // (`nchunks_hint`, from the caller's cost model), kept within 2 .. 16.
+    long long want_chunks = nchunks_hint < 2 ? 2 : nchunks_hint > 16 ? 16 : nchunks_hint;
+    long long chunk_rows = (rows + want_chunks - 1) / want_chunks;
+    const long long lo_rows = (long long)((32u << 20) / row_bytes) + 1;
+    chunk_rows = std::max(lo_rows, chunk_rows);
     chunk_rows = (chunk_rows + 1023) / 1024 * 1024;
     const long long nchunks = (rows + chunk_rows - 1) / chunk_rows;
 
@@ -875,21 +900,28 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
         const double t_filter = k > 128 ? 1e30
                                         : 1.0e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * kt * pairs + 1e-4;
-        int want_filter = g_opt_path == 2 || (g_opt_path == 0 && m >= 5 && t_filter < t_exact);
+        const double t_filter_under_copy = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // host rows: layouts built under the copy
+        int want_filter = g_opt_path == 2 ||
+                          (g_opt_path == 0 && m >= 5 && k <= 128 && (g_opt_ingest == 1 ? t_filter : t_filter_under_copy) < t_exact);
         static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        // Third option: the exact scan chunk by chunk under the copy (pageable H2D measured at
-        // ~50 GB/s): costs the longer of the two plus one chunk's scan.
+        // Third option: the exact scan chunk by chunk under the copy (pageable H2D measured at 50-55 GB/s,
+        // ~0.25 ms of fixed cost per copy call): costs the longer of the two plus one chunk's scan.  The
+        // staged alternatives pay the copy in one piece; the filter layouts are then built under the copy's
+        // tail (knn_filter_build_from_host), leaving the query itself.
         const double bytes = 4.0 * k * (double)(hi - lo);
-        const double t_h2d = bytes / 50e9;
-        const double nchunks = std::max(std::min(16.0, bytes / (double)(32u << 20)), bytes / (double)(128u << 20));
-        const double t_streamed = std::max(t_h2d, t_exact) + t_exact / nchunks + 1e-4 * nchunks + 1e-4;
-        const double t_staged = t_h2d + (want_filter ? t_filter : t_exact);
-        const bool streamed = g_opt_path != 2 && g_opt_stream != 1 && bytes >= (double)(32u << 20) &&
+        const double t_h2d = bytes / 52e9;
+        const double kCopyCall = 2.5e-4;
+        double nchunks = floor(sqrt(t_exact / kCopyCall) + 0.5);
+        nchunks = std::max(2.0, std::min(16.0, std::min(nchunks, floor(bytes / (double)(32u << 20)))));
+        const double t_streamed = std::max(t_h2d, t_exact) + t_exact / nchunks + kCopyCall * nchunks + 1e-4;
+        const double t_filter_query = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // layouts under the copy + query
+        const double t_staged = t_h2d + kCopyCall + (want_filter ? (g_opt_ingest == 1 ? t_filter : t_filter_query) : t_exact);
+        const bool streamed = g_opt_path != 2 && g_opt_stream != 1 && bytes >= (double)(64u << 20) &&
                               (g_opt_stream == 2 || t_streamed < t_staged);
         if (streamed) {
             const int rc = run_shard_streamed((int)(g % ndev), k, m, hi - lo, lo, searchPoints,
-                                              referencePoints + (size_t)lo * (size_t)k, keys.data(), keep_dev);
+                                              referencePoints + (size_t)lo * (size_t)k, keys.data(), keep_dev, (int)nchunks);
             shard_rc[(size_t)g] = rc;
             if (rc != KNN_OK)
                 shard_err[(size_t)g] = g_err;

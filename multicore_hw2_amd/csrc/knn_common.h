@@ -118,6 +118,9 @@ int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m
 #endif
 
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
+// Host rows -> device rows (r_dev, n x k floats) + filter layouts, chunk by chunk under the copy.  Synchronous.
+hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
+                                      hipStream_t copy, hipStream_t compute);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q_dev, const float *r_dev,

@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
                                                        h8 *__restrict__ frag, float *__restrict__ norms,
                                                        unsigned *__restrict__ out, int out_is_partials,
                                                        unsigned *__restrict__ ctl, float *__restrict__ rowmax,
-                                                       unsigned *__restrict__ olist, unsigned ocap)
+                                                       unsigned *__restrict__ olist, unsigned ocap,
+                                                       unsigned row_base = 0u)
 {
+    // (row_base: first row of this launch inside the shard when the layouts are built chunk by chunk;
+    // X / frag / norms arrive already offset to that row, only the outlier list needs the number)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float vmax = 0.0f, nrm = 0.0f;
     unsigned bad = 0;
@@ -228,12 +231,12 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
             bool outside = false;
             for (int d = 0; d < k; ++d) {
                 const float back = (float)(_Float16)((x[d] - center[d]) * sigma);
-                outside = outside || !(fabsf(back) <= 1.0f);
+                outside = outside || !(fabsf(back) <= 1.0f);   // NaN included
             }
             if (outside) {
                 const unsigned pos = atomicAdd(&out[3], 1u);
                 if (pos < ocap)
-                    olist[pos] = (unsigned)i;
+                    olist[pos] = row_base + (unsigned)i;
                 real = false;
             }
         }
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
                                                          const float *__restrict__ center, float sigma,
                                                          h8 *__restrict__ frag, float *__restrict__ norms,
                                                          unsigned *__restrict__ out,
-                                                         unsigned *__restrict__ olist, unsigned ocap)
+                                                         unsigned *__restrict__ olist, unsigned ocap,
+                                                         unsigned row_base = 0u)
 {
     __shared__ f4v s_x[256 * 4];
     const long long row0 = (long long)blockIdx.x * 256;
@@ -353,11 +357,12 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
                 }
             }
         }
-        if (real && !(rowmax <= 1.0f)) {
-            // outside the robust box: out of the filter (zero fragment, +INF norm), into the exact list
+        if (real && (!(rowmax <= 1.0f) || !(nrm < INFINITY))) {
+            // outside the robust box (or a NaN coordinate, which fmaxf above skips): out of the filter
+            // (zero fragment, +INF norm), into the exact list
             const unsigned pos = atomicAdd(&out[3], 1u);
             if (pos < ocap)
-                olist[pos] = (unsigned)i;
+                olist[pos] = row_base + (unsigned)i;
             real = false;
             v[0] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
             v[1] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -1006,6 +1011,70 @@ void knn_filter_free(FilterState &st)
     st = FilterState();
 }
 
+// Robust box of a sample (samples x k, row-major): per dimension [median - w s, median + w s] clipped to
+// [lo_d, hi_d], s = 1.4826 * MAD (median/MAD do not move when a few rows sit 300 sigma out; mean/std do).
+// A few far-out rows would otherwise stretch the box, and with it the fp16 step, for everybody.  ANY
+// box is correct: rows outside it leave the filter and are scanned exactly on every query, so the box
+// is only worth it if it leaves out a handful of rows — w doubles from 12 until at most 1 % of the
+// sample falls outside (heavy tails), and a second mode further out than 96 s (more than 1 % of the
+// rows) keeps the plain [lo, hi].  Returns the half-width of the widest dimension; center[16 kt].
+static double robust_box(const std::vector<float> &samp, long long samples, int k, int kp, const std::vector<float> &lo_d,
+                         const std::vector<float> &hi_d, std::vector<float> &center)
+{
+    center.assign((size_t)kp, 0.0f);
+    std::vector<float> col((size_t)samples), blo((size_t)k), bhi((size_t)k);
+    std::vector<double> med((size_t)k), mad((size_t)k);
+    for (int d = 0; d < k; ++d) {
+        for (long long i = 0; i < samples; ++i)
+            col[(size_t)i] = samp[(size_t)i * k + d];
+        std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
+        med[(size_t)d] = col[(size_t)(samples / 2)];
+        for (long long i = 0; i < samples; ++i)
+            col[(size_t)i] = fabsf(col[(size_t)i] - (float)med[(size_t)d]);
+        std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
+        mad[(size_t)d] = 1.4826 * (double)col[(size_t)(samples / 2)];
+    }
+    bool clipped = false;
+    for (double w = 12.0; w <= 96.0 && !clipped; w *= 2.0) {
+        for (int d = 0; d < k; ++d) {
+            float lo = lo_d[(size_t)d], hi = hi_d[(size_t)d];
+            const double sr = mad[(size_t)d];
+            if (sr > 0.0 && sr < 1e30) {
+                const double rlo = med[(size_t)d] - w * sr, rhi = med[(size_t)d] + w * sr;
+                if (rlo > (double)lo && rlo < (double)hi)
+                    lo = (float)rlo;
+                if (rhi < (double)hi && rhi > (double)lo)
+                    hi = (float)rhi;
+            }
+            blo[(size_t)d] = lo;
+            bhi[(size_t)d] = hi;
+        }
+        long long outside = 0;
+        for (long long i = 0; i < samples; ++i) {
+            bool out = false;
+            for (int d = 0; d < k && !out; ++d) {
+                const float x = samp[(size_t)i * k + d];
+                out = x < blo[(size_t)d] || x > bhi[(size_t)d];
+            }
+            outside += out;
+        }
+        clipped = outside * 100 <= samples;
+    }
+    if (!clipped)
+        for (int d = 0; d < k; ++d) {
+            blo[(size_t)d] = lo_d[(size_t)d];
+            bhi[(size_t)d] = hi_d[(size_t)d];
+        }
+    double h = 0.0;
+    for (int d = 0; d < k; ++d) {
+        const float lo = blo[(size_t)d], hi = bhi[(size_t)d];
+        const float c = 0.5f * lo + 0.5f * hi;
+        center[(size_t)d] = c;
+        h = fmax(h, fmax((double)hi - (double)c, (double)c - (double)lo));
+    }
+    return h;
+}
+
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s)
 {
     st = FilterState();
@@ -1078,56 +1147,12 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         FTRY(e);
         lap("sample rows + copy");
     }
-    std::vector<float> center((size_t)kp, 0.0f), col((size_t)samples), blo((size_t)k), bhi((size_t)k);
-    std::vector<double> med((size_t)k), mad((size_t)k);
+    std::vector<float> center, dlo((size_t)k), dhi((size_t)k);
     for (int d = 0; d < k; ++d) {
-        for (long long i = 0; i < samples; ++i)
-            col[(size_t)i] = samp[(size_t)i * k + d];
-        std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
-        med[(size_t)d] = col[(size_t)(samples / 2)];
-        for (long long i = 0; i < samples; ++i)
-            col[(size_t)i] = fabsf(col[(size_t)i] - (float)med[(size_t)d]);
-        std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
-        mad[(size_t)d] = 1.4826 * (double)col[(size_t)(samples / 2)];
+        dlo[(size_t)d] = ord2f_host(hstats[(size_t)d]);
+        dhi[(size_t)d] = ord2f_host(hstats[(size_t)k + d]);
     }
-    bool clipped = false;
-    for (double w = 12.0; w <= 96.0 && !clipped; w *= 2.0) {
-        for (int d = 0; d < k; ++d) {
-            float lo = ord2f_host(hstats[(size_t)d]), hi = ord2f_host(hstats[(size_t)k + d]);
-            const double sr = mad[(size_t)d];
-            if (sr > 0.0 && sr < 1e30) {
-                const double rlo = med[(size_t)d] - w * sr, rhi = med[(size_t)d] + w * sr;
-                if (rlo > (double)lo && rlo < (double)hi)
-                    lo = (float)rlo;
-                if (rhi < (double)hi && rhi > (double)lo)
-                    hi = (float)rhi;
-            }
-            blo[(size_t)d] = lo;
-            bhi[(size_t)d] = hi;
-        }
-        long long outside = 0;
-        for (long long i = 0; i < samples; ++i) {
-            bool out = false;
-            for (int d = 0; d < k && !out; ++d) {
-                const float x = samp[(size_t)i * k + d];
-                out = x < blo[(size_t)d] || x > bhi[(size_t)d];
-            }
-            outside += out;
-        }
-        clipped = outside * 100 <= samples;
-    }
-    if (!clipped)
-        for (int d = 0; d < k; ++d) {
-            blo[(size_t)d] = ord2f_host(hstats[(size_t)d]);
-            bhi[(size_t)d] = ord2f_host(hstats[(size_t)k + d]);
-        }
-    double h = 0.0;
-    for (int d = 0; d < k; ++d) {
-        const float lo = blo[(size_t)d], hi = bhi[(size_t)d];
-        const float c = 0.5f * lo + 0.5f * hi;
-        center[(size_t)d] = c;
-        h = fmax(h, fmax((double)hi - (double)c, (double)c - (double)lo));
-    }
+    const double h = robust_box(samp, samples, k, kp, dlo, dhi, center);
     lap("median / MAD box (host)");
     if (!(h <= 1e15) || (h != 0.0 && h < 1e-15))
         return hipSuccess;
@@ -1192,6 +1217,196 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     memcpy(&st.nmax, &hout[1], 4);
     st.usable = true;
     return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------
+// Ingest: host rows -> device rows + filter layouts in ONE pass over PCIe.
+// The reference copies the whole shard with a pageable cudaMemcpy and only then starts working on it
+// (core.cu:885-891); its own whole-callback timings are that copy (README.md:291-292).  Here the
+// rows go over in chunks on `copy` and every chunk is turned into fragments + norms on `compute` as
+// soon as it has landed, so the index is resident — rows AND MFMA layouts — one fragment kernel
+// (~20 us per 64 MiB chunk) after the last byte arrives.
+// What made the layouts need the whole shard was the robust box (range + median/MAD).  With the rows
+// still on the host the box comes from a strided HOST sample of up to 4096 rows taken before the
+// first byte moves (~0.5 ms): median/MAD as before, clipped to the sample's min/max widened by 1/32
+// of its width.  Any box is correct — rows outside it (a far-out row in a
+// late chunk, a NaN, an Inf) go to the exact list as always; only if more than n/32 rows end up
+// there (the sample was not representative) are the layouts rebuilt from the resident rows with the
+// full-range statistics of knn_filter_build.
+// r_dev: destination, n x k floats on the current device.  Synchronous.
+// ------------------------------------------------------------------------------------------
+hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
+                                      hipStream_t copy, hipStream_t compute)
+{
+    st = FilterState();
+    const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[knn ingest] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    const size_t row_bytes = (size_t)k * sizeof(float);
+    const bool layouts = n > 0 && k >= 1 && k <= 128;
+    const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+    const int kp = 16 * kt;
+    const long long ntiles = (n + 31) / 32;
+
+    // 1. box from a host sample
+    bool usable = layouts;
+    std::vector<float> center;
+    float sigma = 1.0f;
+    if (usable) {
+        // 4096 strided rows give the range (every read is a cache + TLB miss: 16384 rows cost 3.6 ms, more than
+        // the layouts), every 4th of them — 1024 rows, as in knn_filter_build — the median / MAD
+        const long long samples = n < 4096 ? n : 4096;
+        const long long row_stride = n / samples;
+        const long long sub = samples >= 4096 ? 4 : 1, nsub = samples / sub;
+        std::vector<float> samp((size_t)nsub * k), dlo((size_t)k, INFINITY), dhi((size_t)k, -INFINITY);
+        for (long long i = 0; i < samples && usable; ++i) {
+            const float *x = r_host + (size_t)(i * row_stride) * k;
+            for (int d = 0; d < k; ++d) {
+                const float v = x[d];
+                if (!(fabsf(v) < INFINITY))
+                    usable = false;   // non-finite rows in the sample: leave it to the classic build
+                if (i % sub == 0 && i / sub < nsub)
+                    samp[(size_t)(i / sub) * k + d] = v;
+                dlo[(size_t)d] = fminf(dlo[(size_t)d], v);
+                dhi[(size_t)d] = fmaxf(dhi[(size_t)d], v);
+            }
+        }
+        if (usable) {
+            for (int d = 0; d < k; ++d) {
+                const float pad = (dhi[(size_t)d] - dlo[(size_t)d]) * (1.0f / 32.0f);
+                dlo[(size_t)d] -= pad;
+                dhi[(size_t)d] += pad;
+            }
+            const double h = robust_box(samp, nsub, k, kp, dlo, dhi, center);
+            if (!(h <= 1e15) || (h != 0.0 && h < 1e-15))
+                usable = false;
+            else if (h > 0.0) {
+                int ex;
+                (void)frexp(h, &ex);
+                sigma = (float)ldexp(1.0, -ex);
+            }
+        }
+    }
+
+    lap("host sample + box");
+    // 2. buffers
+    unsigned *dout = nullptr;
+    const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);
+    hipError_t e = hipSuccess;
+    if (usable) {
+        st.k = k;
+        st.kt = kt;
+        st.n = n;
+        st.ntiles = ntiles;
+        st.sigma = sigma;
+        e = KNN_DEV_ALLOC((void **)&st.center, (size_t)kp * sizeof(float));
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&dout, 4 * sizeof(unsigned));
+        if (e == hipSuccess)
+            e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), compute);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(st.center, center.data(), (size_t)kp * sizeof(float), hipMemcpyHostToDevice, compute);
+        if (e == hipErrorOutOfMemory) {   // no room for the layouts beside the rows: rows only
+            (void)hipGetLastError();
+            (void)KNN_DEV_FREE(dout);
+            dout = nullptr;
+            knn_filter_free(st);
+            usable = false;
+            e = hipSuccess;
+        }
+        if (e != hipSuccess) {
+            (void)KNN_DEV_FREE(dout);
+            knn_filter_free(st);
+            return e;
+        }
+    }
+
+    lap("allocations");
+    // 3. Two chunks: everything but the last 64 MiB in ONE pageable copy, then the tail.  A pageable
+    // hipMemcpy runs at the link rate (55 GB/s: the runtime pins the caller's pages as it goes) but every
+    // call costs ~0.25 ms of pipeline fill, so sixteen 64 MiB chunks lost 4 ms against one 1 GiB copy
+    // (profiles/r02_ingest_timing.txt) where the whole layout build is 0.8 ms.  The big chunk's fragment
+    // kernels (0.8 ms for 960 MiB) run under the tail's copy (1.2 ms); what is left after the last byte is
+    // the tail's own fragment kernel (~0.05 ms).  Shards up to 128 MiB go over in one piece.
+    const long long tail_rows = ((long long)((64u << 20) / row_bytes) + 1023) / 1024 * 1024;
+    const long long head_rows = (size_t)n * row_bytes > ((size_t)128u << 20) ? (n - tail_rows) / 1024 * 1024 : n;
+    std::vector<hipEvent_t> events;
+    for (long long r0 = 0; r0 < n && e == hipSuccess;) {
+        const long long chunk_rows = r0 == 0 ? head_rows : n - r0;
+        const long long r1 = std::min(n, r0 + chunk_rows);
+        e = hipMemcpyAsync(r_dev + (size_t)r0 * k, r_host + (size_t)r0 * k, (size_t)(r1 - r0) * row_bytes,
+                           hipMemcpyHostToDevice, copy);
+        const long long r0_this = r0;
+        r0 = r1;
+        lap("copy call returned");
+        if (!usable || e != hipSuccess)
+            continue;
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess)
+            break;
+        events.push_back(ev);
+        e = hipEventRecord(ev, copy);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(compute, ev, 0);
+        if (e != hipSuccess)
+            break;
+        // rows c0 .. r1 (c0 is a multiple of 1024): tiles c0/32 .., the last chunk pads its last tile
+        const long long c0 = r0_this;
+        const long long rows = r1 - c0;
+        const long long rows_padded = r1 == n ? ntiles * 32 - c0 : rows;
+        const float *x = r_dev + (size_t)c0 * k;
+        h8 *frag = (h8 *)st.ref_frags + (size_t)(c0 / 32) * kt * 64;
+        float *norms = st.ref_norms + c0;
+        const unsigned blocks = (unsigned)((rows_padded + 255) / 256);
+        if (k == 16 && ((uintptr_t)x & 15u) == 0)
+            hipLaunchKernelGGL(knn_frag16_kernel, dim3(blocks), dim3(256), 0, compute, (const f4v *)x, rows, rows_padded,
+                               st.center, sigma, frag, norms, dout, st.outliers, ocap, (unsigned)c0);
+        else
+            hipLaunchKernelGGL(knn_frag_kernel, dim3(blocks), dim3(256), 0, compute, x, rows, rows_padded, k, kt, st.center,
+                               sigma, 1.0f, INFINITY, frag, norms, dout, 0, nullptr, nullptr, st.outliers, ocap, (unsigned)c0);
+        e = hipGetLastError();
+    }
+    unsigned hout[4] = {0, 0, 0, 0};
+    if (usable && e == hipSuccess)
+        e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, compute);
+    const hipError_t e1 = hipStreamSynchronize(copy), e2 = hipStreamSynchronize(compute);
+    lap("streams drained");
+    if (e == hipSuccess)
+        e = e1 != hipSuccess ? e1 : e2;
+    for (hipEvent_t ev : events)
+        (void)hipEventDestroy(ev);
+    (void)KNN_DEV_FREE(dout);
+    lap("events + scratch released");
+    if (e != hipSuccess) {
+        knn_filter_free(st);
+        return e;
+    }
+    if (!layouts)
+        return hipSuccess;
+    if (usable && hout[2] == 0u && hout[3] <= ocap) {
+        st.n_outliers = hout[3];
+        memcpy(&st.bmax, &hout[0], 4);
+        memcpy(&st.nmax, &hout[1], 4);
+        st.usable = true;
+        return hipSuccess;
+    }
+    // the sampled box did not fit the data (or the sample held non-finite values): classic build from
+    // the rows that are now resident
+    knn_filter_free(st);
+    return knn_filter_build(st, k, n, r_dev, compute);
 }
 
 static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)

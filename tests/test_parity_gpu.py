@@ -646,3 +646,69 @@ def test_rccl_exchange_step_with_a_one_device_communicator(oracle):
     finally:
         for name in ("rccl", "shards", "stream"):
             pkg.set_option(name, 0)
+
+
+@pytest.mark.parametrize("k,m,n", [(16, 1024, 3_300_001), (3, 700, 6 << 20), (40, 600, 900_000)])
+def test_ingest_builds_the_layouts_chunk_by_chunk_under_the_copy(oracle, k, m, n):
+    """an index created from HOST rows ships them in chunks and builds every chunk's MFMA
+    layouts as it lands, with the robust box taken from a strided host sample.  Checked against the oracle
+    and against the copy-then-build path, with the cases a sampled box must survive: far-out rows, NaN and
+    Inf rows that only show up in LATE chunks (one of them the nearest neighbour of a query), duplicates
+    across chunks (lowest index wins)."""
+    rng = np.random.default_rng(n + k)
+    R = oracle.synth(n * k, 61).reshape(n, k).copy()
+    Q = oracle.synth(m * k, 62).reshape(m, k).copy()
+    late = n - 1 - rng.choice(n // 8, 40, replace=False)          # rows of the last chunk
+    R[late[:10]] *= np.float32(500.0)                              # far outside the sampled box
+    R[late[10:14], 0] = np.nan
+    R[late[14:18], k - 1] = np.inf
+    R[late[18]] = np.float32(1e30)
+    Q[:5] = R[late[:5]] + np.float32(0.5)                          # nearest neighbour = a far-out late row
+    R[late[20]] = R[3]                                             # duplicate of an early row: index 3 must win
+    Q[5] = R[3]
+    want = oracle.v0(k, Q, R)
+    assert np.isin(want[:5], late[:10]).all() and want[5] == 3
+    got = {}
+    try:
+        for ingest in (0, 1):
+            pkg.set_option("ingest", ingest)
+            pkg.set_option("path", 2)
+            ix = pkg.KnnIndex(k, R)                                 # host rows
+            pkg.set_option("path", 0)
+            got[ingest] = ix.query(Q)
+            st = ix.last_stats()
+            ix.close()
+            np.testing.assert_array_equal(got[ingest], want, err_msg=f"ingest={ingest}")
+            if ingest == 0:
+                assert st[0] == 2 and st[2] == 0, st                # the filter ran, no device fallback
+                assert 10 <= st[3] <= 4096, st                      # the planted rows are on the exact list
+            else:
+                assert st[0] == 1, st   # copy-then-build sees the NaN / Inf rows in its range pass: exact kernels only
+    finally:
+        pkg.set_option("ingest", 0)
+        pkg.set_option("path", 0)
+
+
+def test_ingest_stays_exact_when_the_sample_misses_the_data(oracle):
+    """A reference set whose rows sit far outside what a strided sample sees (every row NOT on the sample
+    stride is scaled by 50): the sampled box would send almost everything to the exact list.  The build
+    notices (more than n/32 outliers), redoes the layouts from the resident rows with full-range
+    statistics, and — this data defeats that box too — ends on the exact kernels.  Never a wrong index."""
+    k, m, n = 16, 300, 1 << 20
+    R = oracle.synth(n * k, 71).reshape(n, k).copy()
+    Q = oracle.synth(m * k, 72).reshape(m, k).copy()
+    stride = n // 16384
+    mask = np.ones(n, dtype=bool)
+    mask[::stride] = False
+    R[mask] *= np.float32(50.0)
+    Q *= np.float32(50.0)
+    pkg.set_option("path", 2)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got = ix.query(Q)
+        st = ix.last_stats()
+        ix.close()
+    finally:
+        pkg.set_option("path", 0)
+    np.testing.assert_array_equal(got, oracle.v0(k, Q, R))
+    assert st[0] in (1, 2) and st[3] <= n // 32, st
