@@ -303,7 +303,9 @@ def main():
             lane_ops = (3.0 * k + 3.0) * m * n_local
             roof = {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": hbm_gbps / HBM_PEAK_GBPS, "traffic": None,
-                    "kernel": "knn_exact (VALU-bound at this m: see valu_frac)",
+                    "kernel": "knn_grid_query (uniform-grid ring search, one wave per query: latency-bound, touches a few "
+                              "hundred rows per query instead of n)" if path_taken == 3 else
+                              "knn_exact (VALU-bound at this m: see valu_frac)",
                     "valu_lane_ops_per_s": lane_ops / (kern_avg_ms * 1e-3),
                     "valu_frac": lane_ops / (kern_avg_ms * 1e-3) / VALU_LANE_OPS_PEAK}
         # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
@@ -375,7 +377,7 @@ def main():
             "dtype": "f32 results (f16 MFMA filter + f32 exact re-rank)" if path_taken == 2 else "f32", "data": "synthetic",
             "config": {"workload": "%s: k=%d m=%d n=%d uniform[0,1) fp32, refs resident in HBM, sharded over n" %
                                    (wname, k, m, n),
-                       "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank"}.get(path_taken),
+                       "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank", 3: "grid_index"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "batches_in_flight": nstreams, "setup_steps": SETUP_STEPS,
                        "collective": ("rccl all_reduce(min) of %d x %d packed keys per %d batches" % (nbuf, m, nbuf))

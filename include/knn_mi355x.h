@@ -133,7 +133,9 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
 
 /* Tuning / test hooks.  Known names:
  *   "path"    0 = auto, 1 = exact VALU kernels only, 2 = force the MFMA filter
- *             (+ exact re-rank) where its preconditions hold
+ *             (+ exact re-rank) where its preconditions hold, 3 = the uniform-grid spatial index
+ *             where k <= 4 and the data allows it (else the exact kernels).  Auto: resident shards
+ *             with k <= 4 and >= 16384 rows get the grid index at creation and are served by it
  *   "shards"  cudaCallback only: split the reference set into this many
  *             shards (0 = one per visible GPU).  Shards beyond the GPU count
  *             wrap around the devices — exercises the partition + merge logic
@@ -162,7 +164,7 @@ long long knn_get_option(const char *name);
 
 /* Statistics of the most recent knn_index_query_keys on this index (filled
  * when the stream has completed; call after synchronising):
- *   [0] path taken (1 exact, 2 filter)   [1] candidates re-ranked exactly
+ *   [0] path taken (1 exact, 2 filter, 3 grid index)   [1] candidates re-ranked exactly
  *   [2] != 0: the device fell back to the exact scan   [3] reference rows outside the filter's
  *   robust box (scanned exactly on every query) */
 int knn_index_last_stats(knn_index *idx, long long stats[4]);

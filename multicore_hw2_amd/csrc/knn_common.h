@@ -108,6 +108,17 @@ struct FilterState {
 hipError_t knn_dev_alloc(void **p, size_t bytes);
 hipError_t knn_dev_free(void *p);
 
+// ---- uniform-grid index for k <= 4 (knn_grid.hip) -------------------------------------------
+struct GridState;
+// *out stays null (hipSuccess) when the data rules the grid out.  Synchronous.
+hipError_t knn_grid_build(GridState **out, int k, long long n, const float *r_dev, hipStream_t stream);
+void knn_grid_free(GridState *&gs);
+// Asynchronous; *gate_out = device word that is != 0 afterwards iff some query left the grid search
+// unfinished (the caller queues the gated brute-force scan behind it).
+hipError_t knn_grid_query(const GridState *gs, int slot, int m, const float *q_dev, long long base, u64 *keys_dev,
+                          const unsigned **gate_out, hipStream_t stream);
+void knn_grid_info(const GridState *gs, long long info[4]);
+
 // ---- RCCL exchange step (knn_rccl.cpp; librccl is dlopen'ed at first use) -------------------
 #ifdef __cplusplus
 #include <string>

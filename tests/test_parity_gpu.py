@@ -712,3 +712,102 @@ def test_ingest_stays_exact_when_the_sample_misses_the_data(oracle):
         pkg.set_option("path", 0)
     np.testing.assert_array_equal(got, oracle.v0(k, Q, R))
     assert st[0] in (1, 2) and st[3] <= n // 32, st
+
+
+def _grid_cases(rng, name, m, n, k):
+    if name == "uniform":
+        return rng.random((m, k), dtype=np.float32), rng.random((n, k), dtype=np.float32)
+    if name == "offset":        # far from the origin: fp32 spacing is a visible fraction of a cell
+        return ((rng.random((m, k)) + 4096).astype(np.float32), (rng.random((n, k)) + 4096).astype(np.float32))
+    if name == "clustered":     # most cells empty, a few crowded: long ring walks and big cells
+        c = rng.random((6, k))
+        return ((c[rng.integers(0, 6, m)] + rng.normal(0, 2e-3, (m, k))).astype(np.float32),
+                (c[rng.integers(0, 6, n)] + rng.normal(0, 2e-3, (n, k))).astype(np.float32))
+    if name == "lattice":       # integer coordinates: massive exact ties, the lowest index must win
+        return rng.integers(0, 12, (m, k)).astype(np.float32), rng.integers(0, 12, (n, k)).astype(np.float32)
+    if name == "queries_outside":   # far outside the box (the ring search gives up: gated brute force) and just outside
+        q = rng.random((m, k)) * 3 - 1
+        q[: m // 4] = rng.random((m // 4, k)) * 2000 - 1000
+        return q.astype(np.float32), rng.random((n, k)).astype(np.float32)
+    if name == "skewed":        # one axis 1e4 times longer than the others, heavy-tailed
+        sc = np.ones(k)
+        sc[0] = 1e4
+        return ((rng.standard_cauchy((m, k)) * sc).astype(np.float32), (rng.standard_cauchy((n, k)) * sc).astype(np.float32))
+    raise ValueError(name)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+@pytest.mark.parametrize("dist", ["uniform", "offset", "clustered", "lattice", "queries_outside", "skewed"])
+def test_grid_index_for_low_k_is_bit_exact(oracle, k, dist):
+    """the uniform-grid index (k <= 4) against the oracle — ring search with the stop rule
+    `best < LB^2 (1 - 1e-6)`, ties by lowest index, queries outside the box, crowded and empty cells,
+    NaN / Inf queries, several shards folding into one key array with global indices."""
+    rng = np.random.default_rng(1000 * k + len(dist))
+    m, n = 700, 150_000
+    Q, R = _grid_cases(rng, dist, m, n, k)
+    Q[3, 0] = np.nan
+    Q[5, k - 1] = np.inf
+    R[n // 2] = R[7]                    # duplicate row: index 7 must win over n // 2
+    Q[9] = R[7]
+    want = oracle.v0(k, Q, R)
+    assert want[9] <= 7 and want[3] == 0 and want[5] == 0
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    pkg.set_option("path", 3)
+    try:
+        for shards in (1, 3):
+            pkg.keys_init(keys.data_ptr(), m)
+            paths = []
+            for lo, hi in pkg.shard_bounds(n, shards):
+                ix = pkg.KnnIndex(k, r_d.data_ptr() + lo * k * 4, n_local=hi - lo, base_index=lo, refs_on_device=True)
+                ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+                torch.cuda.synchronize()
+                paths.append(ix.last_stats()[0])
+                ix.close()
+            pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"{dist} k={k} shards={shards}")
+            if dist in ("uniform", "offset", "queries_outside"):
+                assert paths == [3] * shards, paths          # the grid really was the path taken
+    finally:
+        pkg.set_option("path", 0)
+
+
+def test_grid_index_is_the_resident_path_at_c2_scale_and_steps_aside_for_bad_data(oracle):
+    """Policy: a resident shard with k <= 4 and >= 16384 rows is served by the grid (C2: k 3, n 2^20); rows
+    with NaN / Inf, identical rows and tiny shards are not — the brute-force kernels take those."""
+    k, m, n = 3, 1024, 1 << 20
+    Q, R = oracle.synth(m * k, 1000), oracle.synth(n * k, 1001)
+    dev = torch.device("cuda:0")
+    q_d = torch.from_numpy(Q).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+
+    def run(Rh, nn):
+        r_d = torch.from_numpy(np.ascontiguousarray(Rh)).to(dev)
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=nn, refs_on_device=True)
+        pkg.keys_init(keys.data_ptr(), m)
+        ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+        torch.cuda.synchronize()
+        st = ix.last_stats()
+        ix.close()
+        return out.cpu().numpy().copy(), st[0]
+
+    got, path = run(R, n)
+    np.testing.assert_array_equal(got, oracle.v0(k, Q, R, threads=16))
+    assert path == 3
+    Rb = R.reshape(n, k).copy()
+    Rb[12345, 1] = np.nan
+    got, path = run(Rb, n)
+    np.testing.assert_array_equal(got, oracle.v0(k, Q, Rb, threads=16))
+    assert path != 3
+    Rc = np.tile(R[:k], (70000, 1))                      # every row identical: no box to grid
+    got, path = run(Rc, 70000)
+    np.testing.assert_array_equal(got, np.zeros(m, dtype=np.int32))
+    assert path != 3
+    got, path = run(R[:5000 * k], 5000)
+    np.testing.assert_array_equal(got, oracle.v0(k, Q, R[:5000 * k]))
+    assert path != 3

@@ -41,7 +41,7 @@ def one_case(o, rng, case):
     if k * n > 40_000_000 or k * m * n > 3e11:
         n = max(1, min(n, 40_000_000 // k, int(3e11 // (k * m))))
     kind = str(rng.choice(["uniform", "gauss", "offset", "grid", "clusters", "heavy"]))
-    path = int(rng.choice([0, 0, 1, 2]))
+    path = int(rng.choice([0, 0, 1, 2, 3]))     # 3: the grid index where k <= 4, else the exact kernels
     shards = int(rng.choice([0, 0, 2, 5]))
     stream = int(rng.choice([0, 1, 2]))
     R = make_data(rng, kind, n, k)
