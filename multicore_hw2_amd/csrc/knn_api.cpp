@@ -69,6 +69,7 @@ std::atomic<long long> g_opt_filter_qt{0};
 std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
+std::atomic<long long> g_opt_deepk{0};
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
 std::atomic<long long> g_rccl_reductions{0}; // cudaCallback merges done by the RCCL all-reduce
@@ -316,6 +317,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_stream = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "deepk")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: deepk must be 0 (LDS-tiled, 4 waves), 1 (register-resident) or 2 (LDS-tiled, 8 waves)");
+        g_opt_deepk = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "ingest")) {
         if (value < 0 || value > 1)
             return fail(KNN_EINVAL, "knn_set_option: ingest must be 0 (layouts built under the copy) or 1 (copy, then build)");
@@ -355,6 +362,8 @@ long long knn_get_option(const char *name)
         return g_opt_rccl;
     if (name && !strcmp(name, "ingest"))
         return g_opt_ingest;
+    if (name && !strcmp(name, "deepk"))
+        return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
         return g_rccl_reductions;
     if (name && !strcmp(name, "rccl_version"))      // read-only: NCCL_VERSION_CODE of the loaded RCCL, 0 if none
@@ -573,6 +582,7 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         idx->filter.force_qt = (int)g_opt_filter_qt;
         idx->filter.force_rounds = (int)g_opt_filter_rounds;
         idx->filter.chain_policy = (int)g_opt_filter_chain;
+        idx->filter.deepk_variant = (int)g_opt_deepk;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));

@@ -811,3 +811,31 @@ def test_grid_index_is_the_resident_path_at_c2_scale_and_steps_aside_for_bad_dat
     got, path = run(R[:5000 * k], 5000)
     np.testing.assert_array_equal(got, oracle.v0(k, Q, R[:5000 * k]))
     assert path != 3
+
+
+@pytest.mark.parametrize("deepk", [1, 2], ids=["register_resident", "tiled_8_waves"])
+def test_deep_k_scan_variants_behind_the_deepk_option_stay_bit_exact(oracle, deepk):
+    """The A/B arms of the 64 < k <= 128 scan (profiles/r02_c5_variants.txt: both lose to the default
+    LDS-tiled 4-wave kernel) are kept selectable; they must give the same indices, row masks included."""
+    pkg.set_option("deepk", deepk)
+    try:
+        for (k, m, n) in [(128, 2048, 40000), (100, 1000, 70001), (65, 600, 9000)]:
+            Q, R = oracle.synth(m * k, 81), oracle.synth(n * k, 82)
+            dev = torch.device("cuda:0")
+            q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+            keys = torch.empty(m, dtype=torch.int64, device=dev)
+            out = torch.empty(m, dtype=torch.int32, device=dev)
+            pkg.set_option("path", 2)
+            ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+            pkg.set_option("path", 0)
+            pkg.keys_init(keys.data_ptr(), m)
+            ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+            pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+            torch.cuda.synchronize()
+            st = ix.last_stats()
+            ix.close()
+            np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R), err_msg=str((k, m, n)))
+            assert st[0] == 2 and st[2] == 0, st
+    finally:
+        pkg.set_option("deepk", 0)
+        pkg.set_option("path", 0)
