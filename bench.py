@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--filter-chain", type=int, default=0, help="0 auto, 1 scans of different slots chained, 2 free")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every N-th launch of the dominant kernel with HIP events (roofline.kernel_avg_ms)")
-    ap.add_argument("--deepk", type=int, default=0, help="A/B: 64 < k <= 128 scan, 0 register-resident, 1 LDS-tiled")
+    ap.add_argument("--deepk", type=int, default=0, help="A/B: deep-K LDS-tiled scan, 0 = 4 waves per block, 1 = 8 waves per block")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")

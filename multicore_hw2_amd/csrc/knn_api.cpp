@@ -318,8 +318,8 @@ int knn_set_option(const char *name, long long value)
         return KNN_OK;
     }
     if (!strcmp(name, "deepk")) {
-        if (value < 0 || value > 2)
-            return fail(KNN_EINVAL, "knn_set_option: deepk must be 0 (LDS-tiled, 4 waves), 1 (register-resident) or 2 (LDS-tiled, 8 waves)");
+        if (value < 0 || value > 1)
+            return fail(KNN_EINVAL, "knn_set_option: deepk must be 0 (LDS-tiled scan, 4 waves per block) or 1 (8 waves per block)");
         g_opt_deepk = value;
         return KNN_OK;
     }

@@ -93,7 +93,7 @@ struct FilterState {
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
     int force_rounds = 0;      // tuning hook: filter blocks per resident slot (0 = default)
     int chain_policy = 0;      // scans of different slots: 0 auto (chained when long), 1 always chained, 2 never
-    int deepk_variant = 0;     // k > 64 scans: 0 register-resident, one wave per SIMD; 1 LDS-tiled (A/B hook)
+    int deepk_variant = 0;     // k > 32 tiled scans: 0 = 4 waves per block, 1 = 8 waves per block (A/B hook)
     unsigned *outliers = nullptr; // device: rows outside the robust box (excluded from the filter, scanned exactly)
     unsigned n_outliers = 0;
     FilterWorkspace ws[KNN_SLOTS];

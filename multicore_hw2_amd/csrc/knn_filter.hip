@@ -538,70 +538,13 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 // query tile is issued first (into the other accumulator buffer), then the min3 tree of the
 // current one runs in its shadow.  Query tiles past the end of the batch hold a copy of the last
 // real tile with threshold -INF: wasted MFMAs, never a record (the host picks QT to fit m).
-// ROWS: every record also gets a 16-bit mask of WHICH of the lane's 16 rows are under the threshold
-// (my_rows[pos]); the deep-K re-rank reads only those rows.  The scores of a hit step are recomputed in the
-// rare block (its accumulator has been overwritten two steps later): KT more MFMAs per record-bearing step.
-template <int KT, int QT, bool ROWS = false>
+template <int KT, int QT>
 __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c, const h8 (&qf)[QT][KT],
                                                 const float *__restrict__ s_thr, int lane, int qt0,
                                                 long long tile, u64 *__restrict__ my_rec,
-                                                unsigned &cnt, unsigned slice,
-                                                unsigned short *__restrict__ my_rows = nullptr)
+                                                unsigned &cnt, unsigned slice)
 {
     f16v d[2];
-    u64 masks[QT];
-    u64 any = 0ull;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (KT * QT > 32) {
-        // One wave per SIMD (the B operands alone are 256 registers): the MFMAs are inline asm so that the query
-        // fragments sit in AGPRs for good ("a") and the accumulators in arch VGPRs where the min3 tree reads them —
-        // left alone, hipcc parks a third of the fragments in AGPRs and copies each back with 4 v_accvgpr_read +
-        // s_nop in front of its MFMA (+25 issue cycles per MFMA).  hipcc does not see an asm MFMA's latency, so the
-        // two places where a result could be read early are pinned by hand:
-        //  * tree(t) reads chain(t)'s accumulator only after chain(t+1)'s KT MFMAs have been issued (>= 2 KT wait
-        //    states, 12 needed): the last statement of chain(t+1) names that accumulator as a dummy in/out operand,
-        //    so the scheduler cannot lift the tree above it;
-        //  * the last step of a tile has no next chain: two s_nop 7 stand in for it.
-        // tools/mfma_hazard_audit.py checks the resulting ISA like every other filter kernel.
-#define KNN_MFMA_FIRST(D, A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "a"(B), "v"(C))
-#define KNN_MFMA_CHAIN(D, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "a"(B))
-#define KNN_MFMA_CHAIN_TIE(D, A, B, X) asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0" : "+v"(D), "+v"(X) : "v"(A), "a"(B))
-        static_assert(KT >= 2, "the tie goes on a chained MFMA");
-        KNN_MFMA_FIRST(d[0], a[0], qf[0][0], c);
-#pragma unroll
-        for (int kk = 1; kk < KT; ++kk)
-            KNN_MFMA_CHAIN(d[0], a[kk], qf[0][kk]);
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const float th = s_thr[t * 32 + (lane & 31)];
-            f16v &x = d[t & 1];
-            if (t + 1 < QT) {
-                f16v &dn = d[(t + 1) & 1];
-                KNN_MFMA_FIRST(dn, a[0], qf[t + 1][0], c);
-#pragma unroll
-                for (int kk = 1; kk + 1 < KT; ++kk)
-                    KNN_MFMA_CHAIN(dn, a[kk], qf[t + 1][kk]);
-                KNN_MFMA_CHAIN_TIE(dn, a[KT - 1], qf[t + 1][KT - 1], x);
-            } else {
-                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x));
-            }
-            const float m0 = min3f(x[0], x[1], x[2]);
-            const float m1 = min3f(x[3], x[4], x[5]);
-            const float m2 = min3f(x[6], x[7], x[8]);
-            const float m3 = min3f(x[9], x[10], x[11]);
-            const float m4 = min3f(x[12], x[13], x[14]);
-            const float m5 = min3f(m0, m1, m2);
-            const float m6 = min3f(m3, m4, x[15]);
-            const float mn = min3f(m5, m6, th);
-            masks[t] = __ballot(mn < th);
-            any |= masks[t];
-        }
-#undef KNN_MFMA_FIRST
-#undef KNN_MFMA_CHAIN
-#undef KNN_MFMA_CHAIN_TIE
-    } else
-#endif
-    {
     d[0] = c;
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
@@ -610,6 +553,8 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
     // after the last step.  (With a branch per step the accumulator written by an MFMA was read
     // in a later block, and the compiler's cross-block MFMA->VALU wait-state count came out short
     // of the 12 the in-block rule gives: stale accumulator reads, i.e. missed survivors.)
+    u64 masks[QT];
+    u64 any = 0ull;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float th = s_thr[t * 32 + (lane & 31)];
@@ -632,34 +577,18 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
         masks[t] = __ballot(mn < th);  // rare: one of this lane's 16 rows may beat the bound
         any |= masks[t];
     }
-    }
     if (__builtin_expect(any != 0ull, 0)) {  // wave-uniform
         const u64 me = 1ull << lane;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u64 mask = masks[t];
             if (mask != 0ull) {
-                unsigned rm = 0xFFFFu;
-                if (ROWS) {   // wave-uniform block: the whole wave recomputes this step's scores
-                    f16v e = c;
-#pragma unroll
-                    for (int kk = 0; kk < KT; ++kk)
-                        e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qf[t][kk], e, 0, 0, 0);
-                    const float th = s_thr[t * 32 + (lane & 31)];
-                    rm = 0u;
-#pragma unroll
-                    for (int r16 = 0; r16 < 16; ++r16)
-                        rm |= e[r16] < th ? (1u << r16) : 0u;
-                }
                 if (mask & me) {
                     const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (pos < slice) {
+                    if (pos < slice)
                         my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) | ((u64)tile << 1) |
                                       (u64)(lane >> 5);
-                        if (ROWS)
-                            my_rows[pos] = (unsigned short)rm;
-                    }
                 }
                 cnt += (unsigned)__popcll(mask);
             }
@@ -667,12 +596,11 @@ __device__ __forceinline__ void filter_ref_tile(const h8 (&a)[KT], const f16v &c
     }
 }
 
-template <int KT, int QT, bool ROWS = false>
-__global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : KT * QT > 32 ? 1 : 2)) void knn_filter_kernel(
+template <int KT, int QT>
+__global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : 2)) void knn_filter_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, u64 *__restrict__ rec,
-    unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice,
-    unsigned short *__restrict__ rec_rows = nullptr)
+    unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
 {
     // One launch covers a PIECE of the batch: `qtiles` query tiles in groups of QT; qfg / thrg / rec /
     // counts arrive already offset to the piece and records carry piece-relative query numbers (the
@@ -697,7 +625,6 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : KT * QT > 
     const long long t1 = ntiles * (wave + 1) / nwaves;
     const size_t list = (size_t)blockIdx.y * (size_t)nwaves + (size_t)wave;
     u64 *__restrict__ my_rec = rec + list * slice;
-    unsigned short *__restrict__ my_rows = ROWS ? rec_rows + list * slice : nullptr;
     unsigned cnt = 0u;
 
     h8 qf[QT][KT];
@@ -768,10 +695,10 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : KT * QT > 
         load_ref_tile<KT>(rf, rn, t0, lane, aA, cA);
         for (long long tile = t0; tile < t1; tile += 2) {
             load_ref_tile<KT>(rf, rn, min(tile + 1, t1 - 1), lane, aB, cB);  // prefetch
-            filter_ref_tile<KT, QT, ROWS>(aA, cA, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice, my_rows);
+            filter_ref_tile<KT, QT>(aA, cA, qf, s_thr, lane, qt0, tile, my_rec, cnt, slice);
             if (tile + 1 < t1) {  // wave-uniform
                 load_ref_tile<KT>(rf, rn, min(tile + 2, t1 - 1), lane, aA, cA);
-                filter_ref_tile<KT, QT, ROWS>(aB, cB, qf, s_thr, lane, qt0, tile + 1, my_rec, cnt, slice, my_rows);
+                filter_ref_tile<KT, QT>(aB, cB, qf, s_thr, lane, qt0, tile + 1, my_rec, cnt, slice);
             }
         }
     }
@@ -1757,16 +1684,12 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         gx = (gx + 1) / 2;
     if ((size_t)gx * 4 * gy > kMaxLists)
         return hipErrorInvalidValue;
-    // KT = 8 (64 < k <= 128), the scan proper: register-resident form, ONE wave per SIMD with 8 query tiles
-    // (256 registers of B operands) and the accumulators in the other half of the 512-register file — 64
-    // MFMAs per KiB-tile of A straight from L2, trees behind the next chain, no LDS and no barrier on the
-    // data path (the LDS-tiled kernel stays as the sample pass and as the `deepk` = 1 A/B arm).
-    const bool reg_scan = KT == 8 && st.deepk_variant == 1;
-    // `deepk` = 2: the LDS-tiled scan with 8 waves per block (each staged reference tile feeds 32 query tiles)
-    const bool wide_scan = st.deepk_variant == 2;
+    // `deepk` = 1 (A/B arm): the same kernel with 8 waves per block — each staged reference tile feeds 32 query
+    // tiles, half the L2 -> LDS traffic.  Measured equal to the 4-wave form (profiles/r02_c5_variants.txt).
+    const bool wide_scan = st.deepk_variant == 1;
     unsigned wgy = (unsigned)((qtiles + 8 * QT - 1) / (8 * QT)), wgx = 1;
     if (wide_scan) {
-        wgx = ((unsigned)num_cu * 4 + wgy - 1) / wgy;    // ~4 rounds of one-block-per-CU
+        wgx = ((unsigned)num_cu * 4 + wgy - 1) / wgy;    // ~4 rounds of one block per CU
         if ((long long)wgx > st.ntiles)
             wgx = (unsigned)st.ntiles;
         if (wgx < 1)
@@ -1774,17 +1697,7 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         while ((size_t)wgx * 8 * wgy > kMaxLists && wgx > 1)
             wgx = (wgx + 1) / 2;
     }
-    unsigned rgy = (unsigned)((qtiles + 7) / 8), rgx = 1;
-    if (reg_scan) {
-        rgx = ((unsigned)num_cu + rgy - 1) / rgy;
-        if ((long long)rgx * 4 > st.ntiles)
-            rgx = (unsigned)((st.ntiles + 3) / 4);
-        if (rgx < 1)
-            rgx = 1;
-        if ((size_t)rgx * 4 * rgy > kMaxLists)
-            return hipErrorInvalidValue;
-    }
-    w.nlists = reg_scan ? rgx * 4 * rgy : wide_scan ? wgx * 8 * wgy : gx * 4 * gy;
+    w.nlists = wide_scan ? wgx * 8 * wgy : gx * 4 * gy;
     w.slice = w.rec_cap / w.nlists;
 
     long long stride = st.ntiles / 256;
@@ -1827,18 +1740,12 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    if constexpr (KT == 8) {
-        if (reg_scan)
-            hipLaunchKernelGGL((knn_filter_kernel<8, 8, true>), dim3(rgx, rgy), dim3(FILTER_BLOCK), 0, s,
-                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                               w.records, w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap));
-    }
-    if (wide_scan && !reg_scan)
+    if (wide_scan)
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, 512>), dim3(wgx, wgy), dim3(512), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
                            (unsigned short *)(w.records + w.rec_cap));
-    else if (!reg_scan)
+    else
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
