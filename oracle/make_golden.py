@@ -52,6 +52,7 @@ def main():
     # 2-3. oracle vs results.csv
     lib.ta_srand(SEED)
     out_lines = []
+    dist_lines = []
     for i, (k, m, n) in enumerate(SAMPLES):
         Q = np.empty(k * m, dtype=np.float32)
         R = np.empty(k * n, dtype=np.float32)
@@ -64,6 +65,22 @@ def main():
         assert gold == out.tolist(), f"sample {i} {(k, m, n)}: oracle differs from results.csv line {2 * i + 1}"
         out_lines.append(" ".join(str(v) for v in gold))
         print(f"sample {i} (k={k}, m={m}, n={n}): {m} indices match results.csv:{2 * i + 1}")
+        # the distance line under it ("%.3f," per query, main.cu:16-25: sqrtf of the fp32 squared distance).  Samples
+        # 0 and 1 are NOT reproducible: the reference harness frees its inputs before it measures (main.cu:76-77 vs
+        # 88-91) and the tiny allocations have been reused by then; samples 2-7 must match to the printed digit.
+        dist_ref = [t for t in ref_lines[2 * i + 1].split(",") if t.strip() != ""]
+        assert len(dist_ref) == m
+        Qm, Rm = Q.reshape(m, k), R.reshape(n, k)
+        mine = []
+        for j in range(m):
+            acc = np.float32(0.0)
+            for d in range(k):
+                diff = np.float32(Qm[j, d] - Rm[out[j], d])
+                acc = np.float32(acc + np.float32(diff * diff))
+            mine.append("%.3f" % float(np.sqrt(acc, dtype=np.float32)))
+        if i >= 2:
+            assert mine == dist_ref, f"sample {i}: distance line differs from results.csv:{2 * i + 2}"
+        dist_lines.append(" ".join(dist_ref))
 
     # 4. fixtures
     gdir = os.path.join(ROOT, "tests", "golden")
@@ -73,10 +90,15 @@ def main():
         f.write("# seed 1000; = odd lines of the reference's results.csv (sha256 3b19edfb...0ded9); made by oracle/make_golden.py\n")
         for line in out_lines:
             f.write(line + "\n")
+    with open(os.path.join(gdir, "ta_distances.txt"), "w") as f:
+        f.write("# distance lines (even lines) of the reference's results.csv, '%.3f' per query; samples 0-1 are the\n")
+        f.write("# reference harness' use-after-free values (not reproducible), samples 2-7 equal sqrtf(v0 distance); made by oracle/make_golden.py\n")
+        for line in dist_lines:
+            f.write(line + "\n")
     with open(os.path.join(gdir, "ta_first_draws.txt"), "w") as f:
         f.write("# first 16 outputs of glibc rand() after srand(1000); made by oracle/make_golden.py\n")
         f.write(" ".join(str(v) for v in first) + "\n")
-    print("wrote tests/golden/ta_indices.txt, ta_first_draws.txt")
+    print("wrote tests/golden/ta_indices.txt, ta_distances.txt, ta_first_draws.txt")
 
 
 if __name__ == "__main__":

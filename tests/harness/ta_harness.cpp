@@ -4,8 +4,8 @@
 // malloc'd inputs freed by the caller, results malloc'd by the callee and freed by the caller —
 // over the same eight sample shapes and seed, and prints the same two kinds of line
 // ("CallbackN, k, m, n, ms" and "errors/total w.r.t. baseline: e/m") so logs are comparable with
-// the reference's screen.log.  It also writes the nearest indices in the layout of the
-// reference's results.csv index lines.
+// the reference's screen.log.  It also writes a file in the layout of the reference's results.csv:
+// per sample one line of nearest indices and one line of "%.3f" distances.
 //
 // v0 (CALLBACK1, the CPU baseline) comes from the CPU oracle: test infrastructure, never the product.
 #include <math.h>
@@ -79,9 +79,12 @@ static int run_all(int slot, callback_t fn, FILE *csv)
             }
             printf("errors/total w.r.t. baseline: %d/%d\n\n", errors, m);
             total_errors += errors;
-            if (csv) {
+            if (csv) {   // results.csv layout: one line of indices, one line of "%.3f" distances per sample
                 for (int j = 0; j < m; ++j)
                     fprintf(csv, "%d,", res[j]);
+                fprintf(csv, "\n");
+                for (int j = 0; j < m; ++j)
+                    fprintf(csv, "%.3f,", euclid(k, q + (size_t)j * k, r + (size_t)res[j] * k));
                 fprintf(csv, "\n");
             }
             free(res);

@@ -110,3 +110,19 @@ def test_synth_fill_is_uniform_unit_interval_and_counter_based(oracle):
     assert abs(float(a.mean()) - 0.5) < 0.01
     b = oracle.synth(1000, 1001, first=5000)
     np.testing.assert_array_equal(b, a[5000:6000])
+
+
+def test_oracle_reproduces_the_reference_distance_lines(oracle):
+    """results.csv's even lines ('%.3f' of sqrtf(v0 distance), main.cu:16-25) for TA samples 2-7, from the
+    oracle's inputs, indices and fp32 arithmetic (samples 0-1 in the reference file are use-after-free
+    values: SURVEY §4)."""
+    with open(os.path.join(GOLDEN, "ta_distances.txt")) as f:
+        gold = [ln.split() for ln in f.read().splitlines() if ln and not ln.startswith("#")]
+    assert len(gold) == len(TA_SAMPLES)
+    for i, (k, m, n, Q, R) in enumerate(oracle.ta_samples()):
+        if i < 2:
+            continue
+        idx = oracle.v0_serial(k, Q, R)
+        Qm, Rm = Q.reshape(m, k), R.reshape(n, k)
+        mine = ["%.3f" % float(np.sqrt(np.float32(oracle.dist2(Qm[j], Rm[idx[j]])), dtype=np.float32)) for j in range(m)]
+        assert mine == gold[i], f"sample {i}"

@@ -342,9 +342,17 @@ def test_ta_style_harness_through_the_cpp_function_pointer_boundary(tmp_path, or
     assert "Callback10, 16, 1024, 65536," in r.stdout
     gold = read_golden_indices()
     lines = csv.read_text().splitlines()
-    assert len(lines) == len(gold)
-    for line, g in zip(lines, gold):
+    assert len(lines) == 2 * len(gold)                 # results.csv layout: index line, distance line
+    for line, g in zip(lines[0::2], gold):
         assert [int(t) for t in line.split(",") if t] == g.tolist()
+    # distance lines: the reference's own for samples 2-7 (its samples 0-1 are use-after-free values)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ta_distances.txt")) as f:
+        gdist = [ln.split() for ln in f.read().splitlines() if ln and not ln.startswith("#")]
+    for i, line in enumerate(lines[1::2]):
+        mine = [t for t in line.split(",") if t]
+        assert len(mine) == len(gdist[i])
+        if i >= 2:
+            assert mine == gdist[i], f"sample {i}"
 
 
 @pytest.mark.parametrize("chain", [0, 1, 2], ids=["auto", "chained", "free"])
