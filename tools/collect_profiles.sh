@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box (everything lands under gpurun_out/r02_final/; tools/pmc_traffic.py and the
+# copy into profiles/ happen afterwards in the build container).  usage: gpurun -- 'bash tools/collect_profiles.sh'
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02_final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+step() { echo "== $1"; }
+step "bench lines"
+timeout -k 10 300 python3 $R/bench.py > $O/c3_bench.json 2> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload c2 > $O/c2_bench.json 2>> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload c5 --cpu-queries 2048 > $O/c5_bench.json 2>> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload c4 --cpu-queries 0 > $O/c4_1gpu_bench.json 2>> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload 16,1,16777216 --cpu-queries 0 > $O/16_1_16777216_bench.json 2>> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload 16,64,16777216 --cpu-queries 0 > $O/16_64_16777216_bench.json 2>> $O/c3_bench.err || exit 1
+step "kernel traces"
+for w in c3 c2 c5; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -- python3 $R/bench.py --workload $w --cpu-queries 0 > /dev/null 2>&1 || exit 1
+done
+step "pmc passes (C3)"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
+step "drop-in timing"
+cd $R
+timeout -k 10 300 python3 tools/dropin_timing.py > $O/dropin_timing.txt 2>&1 || exit 1
+timeout -k 10 300 python3 tools/ingest_timing.py > $O/ingest_timing.txt 2>&1 || exit 1
+echo done

@@ -48,9 +48,16 @@ def main():
         out[name] = ent
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", f"{tag}_pmc_traffic.json")
+    # bench.py quotes roofline.traffic from this file only while the kernels it was measured on are the ones running
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("knn_filter.hip", "knn_exact.hip"):
+        with open(os.path.join(root, "multicore_hw2_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
     with open(path, "w") as fo:
         json.dump({"note": "rocprofv3 --pmc, separate passes; read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 correction, "
                            "MI355X_MICROARCH.md HBM section); command: bench.py --steps 5 --warmup 1 --cpu-queries 0",
+                   "kernel_source_sha256": h.hexdigest(),
                    "kernels": out}, fo, indent=1)
     for k, v in out.items():
         print(f"{k[:60]:60s} n={v['launches']:3d} read {v['hbm_read_bytes_per_launch']/1e6:10.2f} MB write {v['hbm_write_bytes_per_launch']/1e6:9.2f} MB"
