@@ -174,6 +174,16 @@ hipError_t knn_dev_alloc(void **p, size_t bytes)
     return e;
 }
 
+// One device-wide wait covers any number of frees that follow it on this thread (knn_index_destroy gives ~15
+// buffers back; a wait per buffer was 15 device-wide syncs).
+static thread_local bool g_free_synced = false;
+void knn_dev_free_begin_synced()
+{
+    (void)hipDeviceSynchronize();
+    g_free_synced = true;
+}
+void knn_dev_free_end_synced() { g_free_synced = false; }
+
 hipError_t knn_dev_free(void *p)
 {
     if (!p)
@@ -189,7 +199,8 @@ hipError_t knn_dev_free(void *p)
     }
     if (info.first < 0)
         return hipFree(p);
-    (void)hipDeviceSynchronize();  // hipFree's implicit wait: nothing may still be using the buffer
+    if (!g_free_synced)
+        (void)hipDeviceSynchronize();  // hipFree's implicit wait: nothing may still be using the buffer
     pool_put(info.first, p, info.second);
     return hipSuccess;
 }
@@ -503,13 +514,14 @@ void knn_index_destroy(knn_index *idx)
         return;
     {
         DeviceGuard guard(idx->device);
-        if (idx->owned_refs) {
-            // the pool must never hand out memory a kernel may still be reading
-            (void)hipDeviceSynchronize();
+        // the pool must never hand out memory a kernel may still be reading: ONE device-wide wait, then
+        // every buffer of the index goes back
+        knn_dev_free_begin_synced();
+        if (idx->owned_refs)
             pool_put(idx->device, idx->owned_refs, idx->owned_bytes);
-        }
         knn_filter_free(idx->filter);
         knn_grid_free(idx->grid);
+        knn_dev_free_end_synced();
         for (auto &ev : idx->events) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);

@@ -108,6 +108,9 @@ struct FilterState {
 // pooled device memory for the CURRENT device (knn_api.cpp); knn_dev_free waits for the device first
 hipError_t knn_dev_alloc(void **p, size_t bytes);
 hipError_t knn_dev_free(void *p);
+// bracket a run of knn_dev_free calls on this thread with ONE device-wide wait (current device)
+void knn_dev_free_begin_synced();
+void knn_dev_free_end_synced();
 
 // ---- uniform-grid index for k <= 4 (knn_grid.hip) -------------------------------------------
 struct GridState;
