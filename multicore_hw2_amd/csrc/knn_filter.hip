@@ -15,9 +15,13 @@
 //     D* <= sigma^2 (E0 (1+g2) + tau)                       [v0's own rounding: g2 = (k+3) 2^-24]
 //   * fp16 rounding of centred coordinates moves each coordinate difference by at most
 //     e = theta'(Amax + Bmax) + 2 nu0, so |D~ - D| <= 2 eta sqrt(D) + eta^2, eta = sqrt(k) e
-//   * norm sums and the MFMA's internal fp32 accumulation add at most rho (assumed <= 2^-18
-//     relative to the sum of magnitudes — 16x the single-rounding bound; tests/ check the
-//     scores against a float64 evaluation).
+//   * norm sums and the MFMA's internal fp32 accumulation add at most rho.  The accumulation term is the ONE
+//     constant of this bound that is ASSUMED, not proven: omega = kt * 2^-18 relative to the sum of term
+//     magnitudes (16x a single fp32 rounding per 16-wide K-step; the matrix core's internal summation order is
+//     not documented).  It is measured on every GPU test run: test_mfma_accumulation_error_is_far_inside_the_
+//     assumed_allowance rebuilds the fp16 operands on the host, evaluates N - 2 a.b in float64 and asserts the
+//     device scores are within 2^-20 (a 4x margin to the allowance) for k = 16, 40, 128; test_filter_scores_stay_
+//     inside_the_proven_error_bound checks the whole bound against float64 distances on 20 data sets.
 //   => S_j* <= Dup + 2 eta sqrt(Dup) + eta^2 + rho - M_q(1-g) =: thr_q.
 //
 // Survivors are written as records (query, reference tile, lane half) and re-evaluated with the
