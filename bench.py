@@ -68,7 +68,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     import torch
-    if not args.selftest_launcher:
+    if not args.selftest_launcher and not os.environ.get("KNN_BENCH_REHEARSE_ON_ONE_GPU"):
         have = torch.cuda.device_count()      # counting devices does not initialise the GPU
         if have < args.gpus:
             sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node: nothing was run\n"
@@ -141,6 +141,12 @@ def main():
 
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # KNN_BENCH_REHEARSE_ON_ONE_GPU=1 (tests): every rank uses GPU 0 and the collective goes through gloo — RCCL
+    # refuses two ranks on one device.  Everything else of the N > 1 flow (shard bounds and base indices per rank,
+    # grouped all-reduce of the batches' keys, unpack, parity check of the reduced result) is the real code.
+    rehearse = os.environ.get("KNN_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # Native libraries (RCCL prints a version banner at communicator creation) write to fd 1:
@@ -153,7 +159,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg.set_option("path", args.path)
     if args.filter_qt:
         pkg.set_option("filter_qt", args.filter_qt)
@@ -383,7 +392,8 @@ def main():
                        "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank", 3: "grid_index"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "batches_in_flight": nstreams, "setup_steps": SETUP_STEPS,
-                       "collective": ("rccl all_reduce(min) of %d x %d packed keys per %d batches" % (nbuf, m, nbuf))
+                       "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %
+                                      ("gloo (one-GPU rehearsal)" if rehearse else "rccl", nbuf, m, nbuf))
                        if dist is not None else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
