@@ -223,9 +223,14 @@ __global__ __launch_bounds__(GRID_BLOCK) void knn_grid_query_kernel(const float 
                                                                     const f4g *__restrict__ pts,
                                                                     const unsigned *__restrict__ orig, long long base,
                                                                     u64 *__restrict__ keys, int rmax,
-                                                                    unsigned *__restrict__ giveup)
+                                                                    unsigned *__restrict__ giveup,
+                                                                    unsigned *__restrict__ giveup_next)
 {
 #pragma clang fp contract(off)
+    // (the flag word of the NEXT batch on this workspace slot is cleared here: the two words of a slot alternate,
+    // calls on a slot are stream-ordered, so no memset launch is needed between batches)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *giveup_next = 0u;
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * (GRID_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (qi >= m)
@@ -250,7 +255,10 @@ __global__ __launch_bounds__(GRID_BLOCK) void knn_grid_query_kernel(const float 
     bool done = false;
     // (a query far outside the box, or in an empty region, would walk O(r^K) cells per ring: past rmax rings
     // it gives up and raises the flag that un-gates the brute-force scan queued behind this kernel)
-    for (int r = 0; r < gmax && r <= rmax; ++r) {
+    // The first pass takes rings 0 and 1 together (the whole 3^K block): with ~3 rows per cell the own cell alone
+    // almost never satisfies the stop rule, and every ring is a chain of dependent loads (cell bounds -> rows).
+    bool first = true;
+    for (int r = gmax > 1 ? 1 : 0; r < gmax && r <= rmax; ++r) {
         // the cells of ring r: positions of the (2r+1)^K block whose largest |offset| is exactly r
         const int side = 2 * r + 1;
         int total = 1;
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void knn_grid_query_kernel(const float 
                 inside = inside && cd >= 0 && cd < gg.g[d];
                 cell += (unsigned)(inside ? cd : 0) * gg.stride[d];
             }
-            if (!inside || far != r)
+            if (!inside || (first ? far > r : far != r))
                 continue;
             const unsigned p0 = start[cell], p1 = start[cell + 1];
             for (unsigned p = p0; p < p1; ++p) {
@@ -289,6 +297,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void knn_grid_query_kernel(const float 
                 }
             }
         }
+        first = false;
         mine = grid_wave_min(mine);
         best = mine < best ? mine : best;
         // stop rule: rows not yet seen are outside the block of rings 0..r; along the axis where they leave
@@ -345,7 +354,8 @@ struct GridState {
     f4g *pts = nullptr;          // device [n]: rows in cell order, padded to 4 floats
     unsigned *orig = nullptr;    // device [n]: shard-local row number of pts[i]
     unsigned max_cell = 0;
-    unsigned *giveup = nullptr;  // device [KNN_SLOTS]: != 0 after a query batch = some query left the grid search
+    unsigned *giveup = nullptr;  // device [KNN_SLOTS][2]: != 0 after a query batch = some query left the grid search
+    mutable unsigned calls[KNN_SLOTS] = {0, 0, 0, 0};   // batches issued per slot (picks the slot's flag word)
 };
 
 void knn_grid_free(GridState *&gs)
@@ -439,7 +449,9 @@ hipError_t knn_grid_build(GridState **out, int k, long long n, const float *r, h
     if (e == hipSuccess)
         e = knn_dev_alloc((void **)&gs->orig, (size_t)n * sizeof(unsigned));
     if (e == hipSuccess)
-        e = knn_dev_alloc((void **)&gs->giveup, KNN_SLOTS * sizeof(unsigned));
+        e = knn_dev_alloc((void **)&gs->giveup, 2 * KNN_SLOTS * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemsetAsync(gs->giveup, 0, 2 * KNN_SLOTS * sizeof(unsigned), s);
     if (e == hipSuccess)
         e = knn_dev_alloc((void **)&cell_of_row, (size_t)n * sizeof(unsigned));
     if (e == hipSuccess)
@@ -496,16 +508,17 @@ hipError_t knn_grid_query(const GridState *gs, int slot, int m, const float *q, 
     *gate_out = nullptr;
     if (!gs || !gs->usable || m <= 0)
         return hipSuccess;
-    unsigned *giveup = gs->giveup + slot;
-    GTRY(hipMemsetAsync(giveup, 0, sizeof(unsigned), s));
+    const unsigned call = gs->calls[slot]++;
+    unsigned *giveup = gs->giveup + 2 * slot + (call & 1u);
+    unsigned *giveup_next = gs->giveup + 2 * slot + ((call + 1u) & 1u);
     const int k = gs->geom.k;
     const int rmax = k == 1 ? 64 : k == 2 ? 16 : k == 3 ? 6 : 4;
     const dim3 grid((unsigned)((m + GRID_BLOCK / 64 - 1) / (GRID_BLOCK / 64))), block(GRID_BLOCK);
     switch (k) {
-    case 1: hipLaunchKernelGGL(knn_grid_query_kernel<1>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup); break;
-    case 2: hipLaunchKernelGGL(knn_grid_query_kernel<2>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup); break;
-    case 3: hipLaunchKernelGGL(knn_grid_query_kernel<3>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup); break;
-    default: hipLaunchKernelGGL(knn_grid_query_kernel<4>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup); break;
+    case 1: hipLaunchKernelGGL(knn_grid_query_kernel<1>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup, giveup_next); break;
+    case 2: hipLaunchKernelGGL(knn_grid_query_kernel<2>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup, giveup_next); break;
+    case 3: hipLaunchKernelGGL(knn_grid_query_kernel<3>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup, giveup_next); break;
+    default: hipLaunchKernelGGL(knn_grid_query_kernel<4>, grid, block, 0, s, q, m, gs->geom, gs->start, gs->pts, gs->orig, base, keys, rmax, giveup, giveup_next); break;
     }
     *gate_out = giveup;
     return hipGetLastError();

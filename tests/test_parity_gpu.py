@@ -847,3 +847,36 @@ def test_deep_k_scan_variants_behind_the_deepk_option_stay_bit_exact(oracle, dee
     finally:
         pkg.set_option("deepk", 0)
         pkg.set_option("path", 0)
+
+
+def test_grid_index_give_up_flag_is_reset_between_batches_on_a_slot(oracle):
+    """The flag that un-gates the brute-force scan behind the grid query lives in two alternating words per
+    workspace slot (no memset between batches): batches with far-outside queries (flag raised) and batches without
+    alternate on one index and one slot, and on two slots in flight; every answer stays bit-exact."""
+    k, m, n = 3, 256, 200_000
+    rng = np.random.default_rng(123)
+    R = rng.random((n, k), dtype=np.float32)
+    near = [rng.random((m, k), dtype=np.float32) for _ in range(3)]
+    far = [(rng.random((m, k)) * 4000 - 2000).astype(np.float32) for _ in range(3)]
+    batches = [near[0], far[0], far[1], near[1], far[2], near[2], near[0]]
+    dev = torch.device("cuda:0")
+    r_d = torch.from_numpy(R).to(dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = []
+    for j, Q in enumerate(batches):
+        slot = j % 2 if j >= 3 else 0
+        st = streams[slot]
+        q_d = torch.from_numpy(Q).to(dev)
+        keys = torch.empty(m, dtype=torch.int64, device=dev)
+        out = torch.empty(m, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        pkg.keys_init(keys.data_ptr(), m, stream=st.cuda_stream)
+        ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=st.cuda_stream, slot=slot)
+        pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), stream=st.cuda_stream)
+        outs.append((out, q_d, keys))
+    torch.cuda.synchronize()
+    assert ix.last_stats()[0] == 3
+    ix.close()
+    for j, Q in enumerate(batches):
+        np.testing.assert_array_equal(outs[j][0].cpu().numpy(), oracle.v0(k, Q, R), err_msg=f"batch {j}")
