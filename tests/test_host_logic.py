@@ -299,3 +299,29 @@ def test_drop_in_entry_prints_the_reference_error_line_and_exits_1():
         assert r.returncode == 1 and "returned" not in r.stdout
         m = pat.search(r.stdout)
         assert m and "code:-2" in m.group(0) and "no CPU fallback" in m.group(0), r.stdout
+
+
+def test_rccl_entry_point_validates_its_arguments_without_a_gpu():
+    """knn_keys_allreduce_min: argument errors come back as KNN_EINVAL before RCCL is touched; librccl itself
+    is opened lazily (the version query either finds it or returns 0, never raises)."""
+    _built_lib()
+    import multicore_hw2_amd as pkg
+    L = pkg.lib()
+    f = L.knn_keys_allreduce_min
+    f.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                  ctypes.POINTER(ctypes.c_void_p)]
+    devs = (ctypes.c_int * 2)(0, 0)
+    ptrs = (ctypes.c_void_p * 2)(1, 1)
+    assert f(0, devs, ptrs, 4, None) == -1                       # no devices
+    assert f(1, None, ptrs, 4, None) == -1
+    assert f(1, devs, None, 4, None) == -1
+    assert f(1, devs, ptrs, -1, None) == -1
+    rc = f(2, devs, ptrs, 4, None)                               # the same device twice (or no such device here)
+    assert rc == -1, rc
+    assert b"knn_keys_allreduce_min" in L.knn_last_error()
+    assert pkg.get_option("rccl_version") >= 0
+    assert pkg.get_option("rccl_reductions") >= 0
+    with pytest.raises(pkg.KnnError):
+        pkg.set_option("rccl", 3)
+    with pytest.raises(pkg.KnnError):
+        pkg.set_option("ingest", 2)
