@@ -70,6 +70,7 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_deepk{0};
+std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes of >= 2^17 rows, 1 every index, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
 std::atomic<long long> g_rccl_reductions{0}; // cudaCallback merges done by the RCCL all-reduce
@@ -334,6 +335,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_deepk = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "cells")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: cells must be 0 (library policy), 1 (always) or 2 (never)");
+        g_opt_cells = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "ingest")) {
         if (value < 0 || value > 1)
             return fail(KNN_EINVAL, "knn_set_option: ingest must be 0 (layouts built under the copy) or 1 (copy, then build)");
@@ -373,6 +380,8 @@ long long knn_get_option(const char *name)
         return g_opt_rccl;
     if (name && !strcmp(name, "ingest"))
         return g_opt_ingest;
+    if (name && !strcmp(name, "cells"))
+        return g_opt_cells;
     if (name && !strcmp(name, "deepk"))
         return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -435,6 +444,10 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     hipStream_t s = (hipStream_t)stream;
     // MFMA filter layouts (skipped for small shards and when the exact path is forced)
     idx->filter_wanted = build_filter > 0;
+    // cell-sorted layout for the pruned scan: indexes the caller keeps (library policy) or on request; the
+    // one-shot cudaCallback asks for explicit layouts and answers one batch, which does not repay the sort
+    const bool want_cells = k <= 16 && n_local >= (1ll << 17) &&
+                            (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0));
     if (build_filter < 0) {
         // library policy: shards of >= 65536 rows; for 32 < k <= 128 (3k+3 exact lane-ops per pair,
         // one query per lane above k = 64) the MFMA filter pays off from 4096 rows already
@@ -457,7 +470,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
                 return fail(KNN_ENOMEM, "knn_index_create: hipMalloc(refs)", hipGetErrorString(e));
             }
             DeviceStreams ds;
-            if (want_layouts && !grid_planned && g_opt_ingest != 1 && streams_get(device, &ds) == hipSuccess) {
+            if (want_layouts && !grid_planned && !want_cells && g_opt_ingest != 1 && streams_get(device, &ds) == hipSuccess) {
                 // ingest: rows and filter layouts in one pass over PCIe (knn_filter_build_from_host)
                 e = hipStreamSynchronize(s);   // work the caller queued ahead of this call
                 if (e == hipSuccess)
@@ -489,7 +502,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
             want_layouts = false;
     }
     if (want_layouts && !layouts_done) {
-        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s);
+        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s, want_cells ? 1 : 0);
         if (e == hipErrorOutOfMemory) {
             // no room for the fp16 layouts beside the rows: the index still works, exact kernels only
             (void)hipGetLastError();
@@ -586,8 +599,10 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         HIP_TRY(knn_exact_launch(idx->k, m, idx->n, idx->base, queries_dev, idx->refs, (u64 *)keys_dev, idx->num_cu, gate, s));
         return KNN_OK;
     }
+    // (with a cell-sorted layout even one query is served faster by the pruned scan than by reading the shard)
+    const bool cells_live = idx->filter.cells && !idx->filter.cells->off && g_opt_cells != 2;
     const bool use_filter = idx->filter.usable &&
-                            (path == 2 || (path == 0 && m >= 5 && (idx->n >= 65536 || idx->filter_wanted)));
+                            (path == 2 || (path == 0 && (m >= 5 || cells_live) && (idx->n >= 65536 || idx->filter_wanted)));
     if (use_filter) {
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;
@@ -595,9 +610,12 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         idx->filter.force_rounds = (int)g_opt_filter_rounds;
         idx->filter.chain_policy = (int)g_opt_filter_chain;
         idx->filter.deepk_variant = (int)g_opt_deepk;
+        idx->filter.cells_policy = (int)g_opt_cells;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));
+        if (idx->filter.ws[slot].last_used_cells)
+            idx->stats[0] = 4;
         return KNN_OK;
     }
     if (ev)
@@ -655,7 +673,7 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
     if (!idx || !stats)
         return fail(KNN_EINVAL, "knn_index_last_stats: bad arguments");
     const FilterWorkspace &w = idx->filter.ws[idx->last_slot];
-    if (idx->stats[0] == 2 && w.ctl) {
+    if ((idx->stats[0] == 2 || idx->stats[0] == 4) && w.ctl) {
         DeviceGuard guard(idx->device);
         unsigned ctl[KNN_CTL_WORDS];
         HIP_TRY(hipMemcpy(ctl, w.ctl, sizeof ctl, hipMemcpyDeviceToHost));

@@ -35,10 +35,12 @@ struct RerankPieces {
     int n = 1;
 };
 
+// perm (nullable): records name positions of a permuted layout; perm[position] = row (~0u = padding), and n
+// is then the number of positions.
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
                              const u64 *records, const unsigned short *record_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
-                             hipStream_t stream);
+                             hipStream_t stream, const unsigned *perm = nullptr);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
@@ -54,6 +56,7 @@ enum {
     KNN_CTL_AMAX = 2,      // float bits: max |scaled query coordinate| in fp16
     KNN_CTL_QNMAX = 3,     // float bits: max fp32 squared norm of the fp16 query rows
     KNN_CTL_QBAD = 4,      // != 0: a query coordinate is non-finite or out of fp16 range
+    KNN_CTL_CELLS = 5,     // != 0: this batch went through the cell-pruned scan
     KNN_CTL_WORDS = 8
 };
 
@@ -77,6 +80,26 @@ struct FilterWorkspace {
     size_t umin_cap = 0;       // floats allocated in umin
     unsigned *qpart = nullptr; // device [3 * query blocks]: {max |coord|, max norm, #bad} per block
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // optional: bracket the filter kernel
+    // cell-pruned scan (CellIndex): per-cell query lists and the per-query pruning tables of the batch
+    unsigned *cell_counts = nullptr;       // device [ncells]
+    unsigned short *cell_lists = nullptr;  // device [ncells][cap]
+    float *dup = nullptr;                  // device [m_cap]: largest scaled squared distance a candidate can have
+    float *lo_tab = nullptr, *hi_tab = nullptr;  // device [m_cap][2^sa], [2^(bits-sa)][m_cap]
+    int cell_m_cap = 0;
+    unsigned *cells_off = nullptr;         // pinned host word the kernels set when the cells did not fit the batch
+    bool last_used_cells = false;
+};
+
+// Cell-sorted layout of the references (k <= 16): see "Cell-pruned scan" in knn_filter.hip.
+struct CellIndex {
+    int bits = 0, sa = 0;            // cells = 2^bits; low pruning table = 2^sa entries
+    unsigned char nb[16] = {0}, shift[16] = {0};
+    unsigned ncells = 0, cap = 0;    // cap: queries a cell's list can hold per batch
+    float *bounds = nullptr;         // device [16][15]: ascending cuts of every dimension
+    unsigned *tile_start = nullptr;  // device [ncells + 1]: first 32-row tile of each cell in the layout
+    unsigned *perm = nullptr;        // device [ntiles * 32]: row held by each layout position (~0u = padding)
+    unsigned max_cell_rows = 0;
+    bool off = false;                // a batch did not fit (list overflow, empty seed cells): full scans from now on
 };
 
 struct FilterState {
@@ -96,6 +119,8 @@ struct FilterState {
     int deepk_variant = 0;     // k > 32 tiled scans: 0 = 4 waves per block, 1 = 8 waves per block (A/B hook)
     unsigned *outliers = nullptr; // device: rows outside the robust box (excluded from the filter, scanned exactly)
     unsigned n_outliers = 0;
+    CellIndex *cells = nullptr;   // non-null: the layout is cell-sorted (ntiles counts its padded tiles)
+    int cells_policy = 0;         // per call: 0 use the cells when present, 2 full scan
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
     // 15 % slower than back to back; only the small preparation kernels are meant to overlap.
@@ -132,7 +157,9 @@ int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m
                            std::string &err);
 #endif
 
-hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream);
+// want_cells != 0: also sort the layout into cells (k <= 16, large shards; see CellIndex).
+hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream,
+                            int want_cells = 0);
 // Host rows -> device rows (r_dev, n x k floats) + filter layouts, chunk by chunk under the copy.  Synchronous.
 hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
                                       hipStream_t copy, hipStream_t compute);

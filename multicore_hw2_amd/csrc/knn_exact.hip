@@ -509,7 +509,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                                                                const unsigned short *__restrict__ rec_rows,
                                                                const unsigned *__restrict__ counts,
                                                                unsigned slice, unsigned *__restrict__ ctl,
-                                                               u64 *__restrict__ keys, RerankPieces pieces)
+                                                               u64 *__restrict__ keys, RerankPieces pieces,
+                                                               const unsigned *__restrict__ perm)
 {
 #pragma clang fp contract(off)
     // one block per record list (= per filter wave); the list's piece gives its first query
@@ -540,10 +541,16 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
             const unsigned reg = c & 15u;
             qi = (unsigned)(e >> 32) + qrow_base;
             const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
-            const long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+            long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
             // rows the filter already proved to be above the threshold are not the answer: skip them
             const unsigned rmask = rec_rows ? rec_rows[(size_t)blockIdx.x * slice + (c >> 4)] : 0xFFFFu;
-            if (ri < n && ((rmask >> reg) & 1u)) {
+            bool live = ri < n && ((rmask >> reg) & 1u);
+            if (perm && live) {  // cell-sorted layout: position -> row, padding positions hold ~0u
+                const unsigned row = perm[ri];
+                live = row != 0xFFFFFFFFu;
+                ri = (long long)row;
+            }
+            if (live) {
                 const float *__restrict__ q = Q + (size_t)qi * k;
                 const float *__restrict__ r = R + (size_t)ri * k;
                 float acc = 0.0f;
@@ -892,10 +899,12 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
                              const u64 *rec, const unsigned short *rec_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
-                             hipStream_t s)
+                             hipStream_t s, const unsigned *perm)
 {
     if (nlists == 0)
         return hipSuccess;
+    if (rec_rows && perm)
+        return hipErrorInvalidValue;  // row masks belong to the deep-K scan, cell-sorted layouts to k <= 16
     if (rec_rows) {  // deep-K scans are never cut into pieces
         hipLaunchKernelGGL(knn_rerank_rows_kernel, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows,
                            counts, slice, ctl, keys);
@@ -903,7 +912,7 @@ hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r,
     }
 #define KNN_RERANK(KK)                                                                                     \
     hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows, \
-                       counts, slice, ctl, keys, pieces)
+                       counts, slice, ctl, keys, pieces, perm)
     switch (k) {
     case 3: KNN_RERANK(3); break;
     case 4: KNN_RERANK(4); break;

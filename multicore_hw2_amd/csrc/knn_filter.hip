@@ -217,10 +217,12 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
                                                        unsigned *__restrict__ out, int out_is_partials,
                                                        unsigned *__restrict__ ctl, float *__restrict__ rowmax,
                                                        unsigned *__restrict__ olist, unsigned ocap,
-                                                       unsigned row_base = 0u)
+                                                       unsigned row_base = 0u,
+                                                       const unsigned *__restrict__ gather = nullptr)
 {
     // (row_base: first row of this launch inside the shard when the layouts are built chunk by chunk;
     // X / frag / norms arrive already offset to that row, only the outlier list needs the number)
+    // (gather: position i of the layout holds row gather[i] of X, ~0u = padding — the cell-sorted layout)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float vmax = 0.0f, nrm = 0.0f;
     unsigned bad = 0;
@@ -228,7 +230,13 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
         const long long tile = i >> 5;
         const int r = (int)(i & 31);
         bool real = i < rows;
-        const float *__restrict__ x = X + (size_t)(real ? i : 0) * k;
+        long long src = i;
+        if (gather) {
+            const unsigned gs = gather[i];
+            real = gs != 0xFFFFFFFFu;
+            src = (long long)gs;
+        }
+        const float *__restrict__ x = X + (size_t)(real ? src : 0) * k;
         if (olist && real) {
             // reference rows outside the robust box (|scaled coordinate| > 1) leave the filter: zero
             // fragment, +INF norm (never a survivor), listed for the exact gather scan
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
             if (outside) {
                 const unsigned pos = atomicAdd(&out[3], 1u);
                 if (pos < ocap)
-                    olist[pos] = row_base + (unsigned)i;
+                    olist[pos] = gather ? (unsigned)src : row_base + (unsigned)i;
                 real = false;
             }
         }
@@ -430,13 +438,15 @@ __host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double si
 //   the winner j* has E_j* <= E_j0 (v0 values), hence D_j* <= D0up (1+g2)^2 + sigma^2 tau =: Dup
 //   and its own score obeys S_j* <= Dup + 2 eta sqrt(Dup) + eta^2 + rho - mq(1-g).
 // Monotone in u, so any upper bound of the true sample minimum is safe too.
-__host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, double mq)
+__host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, double mq, double *dup_out = nullptr)
 {
     double dt = u + mq * (1.0 + 1.01 * c.gam) + c.rho;
     if (dt < 0.0)
         dt = 0.0;
     const double sq0 = c.eta + sqrt(dt + 2.0 * c.eta2);
     const double dup = sq0 * sq0 * (1.0 + c.g2) * (1.0 + c.g2) + c.sigma2 * c.tau;
+    if (dup_out)
+        *dup_out = dup;  // real scaled squared distance no candidate for the answer can exceed (cell pruning)
     double thr = dup + 2.0 * c.eta * sqrt(dup) + c.eta2 + c.rho - mq * (1.0 - c.gam);
     thr += fabs(thr) * 1e-6 + 1e-30;                  // slack for the double arithmetic above
     float tf = (float)thr;
@@ -457,7 +467,9 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
                                                       float *__restrict__ thr,
                                                       unsigned *__restrict__ ctl,
                                                       const unsigned *__restrict__ qpart, int qblocks,
-                                                      unsigned *__restrict__ counts, unsigned nlists)
+                                                      unsigned *__restrict__ counts, unsigned nlists,
+                                                      float *__restrict__ dup_out = nullptr,
+                                                      unsigned *__restrict__ cells_off = nullptr)
 {
     __shared__ float s_part[THR_PARTS][32];
     // housekeeping folded in here to save launches: zero the record counters of the filter pass
@@ -488,18 +500,31 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
     }
     bool bad = qbad != 0u || !(amax <= amax_limit);
     float t = -INFINITY;  // padding queries never pass
+    float dupf = -INFINITY;
     if (i < m) {
-        if (!(u < INFINITY))
+        if (!(u < INFINITY)) {
             bad = true;  // no finite sample score: cannot bound
+            if (cells_off && qbad == 0u && amax <= amax_limit)
+                *cells_off = 1u;  // the query's seed cells were empty: the strided sample will serve the next batches
+        }
         if (!bad) {
             // the error bound of THIS query: its own coordinate magnitude, not the batch maximum
             // (one far-away query must not loosen everybody's threshold)
             const BoundConsts c = knn_bound_consts(k, kt, sigma, qamax[i], bmax, nmax);
-            t = knn_threshold(c, u, qnorm[i]);
+            double dup = 0.0;
+            t = knn_threshold(c, u, qnorm[i], &dup);
             if (!(t < INFINITY))
                 bad = true;
+            else {
+                dup *= 1.0 + 1e-6;
+                dupf = (float)dup;
+                if ((double)dupf < dup)
+                    dupf = nextafterf(dupf, INFINITY);
+            }
         }
     }
+    if (dup_out)
+        dup_out[i] = dupf;
     thr[i] = t;
     if (bad)
         ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
@@ -953,6 +978,407 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_sample_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Cell-pruned scan (k <= 16, resident index).  Scoring every (query, reference) pair costs ~50 issue
+// cycles per 32x32 tile pair whatever the schedule, so the only way under it is not to
+// score most pairs.  The index sorts the rows into 2^B cells — every dimension cut into 2^nb[d] bins at
+// sample quantiles, cell = the tuple of bin numbers — and lays the fp16 fragments out cell by cell (each
+// cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch:
+//   seed    : every query scores its own cell and the 3 cells next to it (MFMA, same scores as the scan):
+//             the minimum is a score of a real reference, which is all knn_threshold needs.  The same
+//             kernel tabulates the query's squared gap to every bin of every dimension.
+//   thr     : threshold thr_q for the scores, and Dup_q = the largest real (scaled) squared distance any
+//             candidate for the answer can have (see knn_threshold).
+//   match   : a row of cell c differs from the query by at least gap_d(bin_d(c)) in every dimension, so
+//             LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of the cell, and LB > Dup_q rules the whole
+//             cell out (ties included: a row that ties with the answer obeys the Dup bound too).  LB is separable:
+//             lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  Cell-major, no atomics: a wave owns 64
+//             consecutive cells and appends the surviving queries to its lanes' lists.
+//   scan    : a wave walks its cells; per cell it gathers the listed queries' B operands from LDS (32 per
+//             block of columns) and runs the usual MFMA + min3 tree + threshold test over the cell's tiles.
+// Uniform data in 16 dimensions, n = 2^24: ~2400 of 65536 cells survive per query, ~36 queries per cell —
+// 1/20 of the MFMA work of the full scan, and the fragments are read once: the scan is HBM-bound.
+// Anything that does not fit (a list overflows, a query's seed cells are empty) raises the FALLBACK
+// flag for this batch — the gated exact scan answers it — and the host-visible `cells_off` word, after
+// which the index goes back to the full scan with the strided sample.
+// ------------------------------------------------------------------------------------------
+#define CELL_MAX_BINS 16
+#define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts
+#define CELL_SEEDS (1 << CELL_SEED_DIMS)
+#define CELL_TILES_PER_PASS 10                // reference tiles a wave holds in registers at a time
+
+struct CellGeom {
+    int k, bits, sa;                 // dimensions, total bits, bits of the low table
+    unsigned char nb[16], shift[16]; // bits of dimension d (0 = not cut), position of its bin number in the cell code
+};
+
+__device__ __forceinline__ unsigned cell_bin(const float *__restrict__ bnd, int nbins, float x)
+{
+    unsigned b = 0u;
+    for (int j = 0; j < nbins - 1; ++j)   // ascending cuts: bin b <=> bnd[b-1] <= x < bnd[b]; NaN -> bin 0
+        b += x >= bnd[j] ? 1u : 0u;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__restrict__ R, long long n, CellGeom g,
+                                                             const float *__restrict__ bounds,
+                                                             unsigned *__restrict__ code, unsigned *__restrict__ counts)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *__restrict__ x = R + (size_t)i * g.k;
+    unsigned c = 0u;
+    for (int d = 0; d < g.k; ++d)
+        if (g.nb[d])
+            c |= cell_bin(bounds + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], x[d]) << g.shift[d];
+    code[i] = c;
+    atomicAdd(&counts[c], 1u);
+}
+
+__global__ __launch_bounds__(256) void knn_cells_scatter_kernel(const unsigned *__restrict__ code, long long n,
+                                                                const unsigned *__restrict__ tile_start,
+                                                                unsigned *__restrict__ fill, unsigned *__restrict__ perm)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const unsigned c = code[i];
+    perm[(size_t)tile_start[c] * 32 + atomicAdd(&fill[c], 1u)] = (unsigned)i;
+}
+
+__device__ __forceinline__ float min_tree16(const f16v &x, float seed)
+{
+    const float m0 = min3f(x[0], x[1], x[2]);
+    const float m1 = min3f(x[3], x[4], x[5]);
+    const float m2 = min3f(x[6], x[7], x[8]);
+    const float m3 = min3f(x[9], x[10], x[11]);
+    const float m4 = min3f(x[12], x[13], x[14]);
+    const float m5 = min3f(m0, m1, m2);
+    const float m6 = min3f(m3, m4, x[15]);
+    return min3f(m5, m6, seed);
+}
+
+// One block per query.  umin[q] = minimum score over the seed cells; lo_tab[q][e] / hi_tab[e][q] = the
+// separable halves of the cell lower bound (scaled units, rounded down).
+__global__ __launch_bounds__(256) void knn_cells_seed_kernel(
+    const float *__restrict__ Q, int m, CellGeom g, const float *__restrict__ bounds, double sigma2,
+    const unsigned *__restrict__ tile_start, const h8 *__restrict__ rf, const float *__restrict__ rn,
+    const h8 *__restrict__ qfg, float *__restrict__ umin, float *__restrict__ lo_tab, float *__restrict__ hi_tab,
+    int m_padded)
+{
+    __shared__ float s_gap[16][CELL_MAX_BINS];
+    __shared__ unsigned s_bin[16], s_alt[16];
+    __shared__ float s_altgap[16];
+    __shared__ unsigned s_cells[CELL_SEEDS], s_tiles[CELL_SEEDS + 1];
+    __shared__ float s_red[4];
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const int d = tid >> 4, b = tid & 15;
+        float v = 0.0f;
+        if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
+            const int nbins = 1 << g.nb[d];
+            const float *__restrict__ bnd = bounds + d * (CELL_MAX_BINS - 1);
+            const double q = (double)Q[(size_t)qi * g.k + d];
+            double gap = 0.0;
+            if (b > 0 && (double)bnd[b - 1] > q)
+                gap = (double)bnd[b - 1] - q;        // rows of the bin have x >= bnd[b-1] > q
+            if (b < nbins - 1 && q > (double)bnd[b])
+                gap = q - (double)bnd[b];            // rows of the bin have x < bnd[b] < q
+            v = __double2float_rd(gap * gap * sigma2);
+        }
+        s_gap[d][b] = v;
+    }
+    if (tid < 16) {
+        unsigned b = 0u, alt = 0xFFFFFFFFu;
+        float ag = INFINITY;
+        if (tid < g.k && g.nb[tid]) {
+            const int nbins = 1 << g.nb[tid];
+            const float *__restrict__ bnd = bounds + tid * (CELL_MAX_BINS - 1);
+            const float q = Q[(size_t)qi * g.k + tid];
+            b = cell_bin(bnd, nbins, q);
+            if (b > 0u) {
+                alt = b - 1u;
+                ag = q - bnd[b - 1];
+            }
+            if (b + 1u < (unsigned)nbins && !(bnd[b] - q >= ag)) {
+                alt = b + 1u;
+                ag = bnd[b] - q;
+            }
+            if (!(ag >= 0.0f))
+                ag = 0.0f;
+        }
+        s_bin[tid] = b;
+        s_alt[tid] = alt;
+        s_altgap[tid] = ag;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned own = 0u;
+        for (int d = 0; d < g.k; ++d)
+            own |= s_bin[d] << g.shift[d];
+        int pick[CELL_SEED_DIMS];
+        for (int j = 0; j < CELL_SEED_DIMS; ++j) {   // the dimensions whose next bin is nearest
+            int best = -1;
+            for (int d = 0; d < g.k; ++d) {
+                bool taken = s_alt[d] == 0xFFFFFFFFu;
+                for (int jj = 0; jj < j; ++jj)
+                    taken = taken || pick[jj] == d;
+                if (!taken && (best < 0 || s_altgap[d] < s_altgap[best]))
+                    best = d;
+            }
+            pick[j] = best;
+        }
+        unsigned total = 0u;
+        for (int c = 0; c < CELL_SEEDS; ++c) {
+            unsigned code = own;
+            bool ok = true;
+            for (int j = 0; j < CELL_SEED_DIMS; ++j)
+                if ((c >> j) & 1) {
+                    if (pick[j] < 0)
+                        ok = false;
+                    else
+                        code = (code & ~(((1u << g.nb[pick[j]]) - 1u) << g.shift[pick[j]])) |
+                               (s_alt[pick[j]] << g.shift[pick[j]]);
+                }
+            s_cells[c] = code;
+            s_tiles[c] = total;
+            total += ok ? tile_start[code + 1] - tile_start[code] : 0u;
+        }
+        s_tiles[CELL_SEEDS] = total;
+    }
+    // the tables (independent of the seed cells): double sums of the rounded-down gaps, rounded down again
+    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);
+    for (int e = tid; e < nl + nh; e += 256) {
+        const bool low = e < nl;
+        const unsigned code = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
+        double sum = 0.0;
+        for (int d = 0; d < g.k; ++d)
+            if (g.nb[d] && ((int)g.shift[d] < g.sa) == low)
+                sum += (double)s_gap[d][(code >> g.shift[d]) & ((1u << g.nb[d]) - 1u)];
+        const float v = __double2float_rd(sum);
+        if (low)
+            lo_tab[(size_t)qi * nl + e] = v;
+        else
+            hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
+    }
+    __syncthreads();
+    // the seed cells' tiles, dealt round-robin to the 4 waves, 4 in flight per wave
+    const h8 b = qfg[(size_t)(qi >> 5) * 64 + (lane >> 5) * 32 + (qi & 31)];  // every column = this query
+    float um = INFINITY;
+    const unsigned total = s_tiles[CELL_SEEDS];
+    for (unsigned t0 = (unsigned)wib * 4u; t0 < total; t0 += 16u) {
+        h8 a[4][1];
+        f16v c[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned t = min(t0 + (unsigned)p, total - 1u);
+            int ci = 0;
+#pragma unroll
+            for (int j = 1; j < CELL_SEEDS; ++j)
+                ci += t >= s_tiles[j] ? 1 : 0;
+            const long long tile = (long long)tile_start[s_cells[ci]] + (t - s_tiles[ci]);
+            load_ref_tile<1>(rf, rn, tile, lane, a[p], c[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[p][0], b, c[p], 0, 0, 0);
+            um = min_tree16(d, um);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
+    if (lane == 0)
+        s_red[wib] = um;
+    __syncthreads();
+    if (tid == 0)
+        umin[qi] = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+}
+
+// Cell-major matching: one wave owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive low-table
+// entries).  Pass 1 (wave-wide, queries on the lanes): which queries get past the high table alone — ~15 %
+// for uniform data — compacted into an LDS queue.  Pass 2 (cells on the lanes): the low-table entry of each
+// queued query, 8 loads in flight.  cell_counts[c] = queries that could not rule cell c out,
+// lists[c][0..) = their numbers, ascending.  No atomics: per-cell appends with returning atomics ran at
+// 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
+__global__ __launch_bounds__(64) void knn_cells_match_kernel(
+    const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
+    int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
+    unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off)
+{
+    __shared__ unsigned short s_q[1024];
+    __shared__ float s_hv[1024], s_dq[1024];
+    if (ctl[KNN_CTL_FALLBACK] != 0u)
+        return;
+    const int lane = threadIdx.x;
+    const unsigned c0 = blockIdx.x * 64u;
+    const unsigned cell = c0 + (unsigned)lane;
+    const int nl = 1 << g.sa;
+    const unsigned h = c0 >> g.sa;                      // wave-uniform: nl >= 64
+    const unsigned l = cell & (unsigned)(nl - 1);
+    const float *__restrict__ hrow = hi_tab + (size_t)h * m_padded;
+    unsigned npass = 0u;
+    for (int q0 = 0; q0 < m; q0 += 256) {   // 4 x 64 queries per round: their loads are issued together
+        float hv[4], dq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * 64 + lane;
+            hv[u] = q < m ? hrow[q] : INFINITY;
+            dq[u] = q < m ? dup[q] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * 64 + lane;
+            const bool pass = q < m && !(hv[u] > dq[u]);
+            const u64 mask = __ballot(pass);
+            if (pass) {
+                const unsigned pos = npass + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                s_q[pos] = (unsigned short)q;
+                s_hv[pos] = hv[u];
+                s_dq[pos] = dq[u];
+            }
+            npass += (unsigned)__popcll(mask);
+        }
+    }
+    __syncthreads();
+    unsigned short *__restrict__ my = lists + (size_t)cell * cap;
+    unsigned cnt = 0u;
+    for (unsigned e0 = 0u; e0 < npass; e0 += 8u) {
+        float lo[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned e = min(e0 + (unsigned)u, npass - 1u);
+            lo[u] = lo_tab[(size_t)s_q[e] * nl + l];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned e = e0 + (unsigned)u;
+            if (e < npass && cell < ncells) {
+                const float lb = lo[u] + s_hv[e];
+                if (!(lb > s_dq[e])) {
+                    if (cnt < cap)
+                        my[cnt] = s_q[e];
+                    ++cnt;
+                }
+            }
+        }
+    }
+    if (cell < ncells) {
+        cell_counts[cell] = cnt;
+        if (cnt > cap) {
+            ctl[KNN_CTL_FALLBACK] = 1u;  // a list is cut short: the gated exact scan answers this batch
+            *cells_off = 1u;
+        }
+    }
+}
+
+// The scan.  Block = 4 waves sharing the batch's B operands and thresholds in LDS; wave w walks cells
+// [ncells w / W, ncells (w+1) / W).
+__global__ __launch_bounds__(256, 2) void knn_cells_scan_kernel(
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ tile_start, unsigned ncells,
+    const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m_padded,
+    const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
+    u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
+{
+    extern __shared__ unsigned char s_dyn[];
+    h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
+    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
+    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [4 waves][CELL_TILES_PER_PASS * 8]
+    if (ctl[KNN_CTL_FALLBACK] != 0u)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int i = threadIdx.x; i < m_padded * 2; i += 256)
+        s_qf[i] = qfg[i];
+    for (int i = threadIdx.x; i < m_padded; i += 256)
+        s_thr[i] = thrg[i];
+    __syncthreads();
+    f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
+
+    const unsigned wave = blockIdx.x * 4u + (unsigned)wib, nwaves = gridDim.x * 4u;
+    const unsigned cbeg = (unsigned)((u64)ncells * wave / nwaves), cend = (unsigned)((u64)ncells * (wave + 1u) / nwaves);
+    u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
+    unsigned cnt = 0u;
+    const int col = lane & 31, half = lane >> 5;
+    for (unsigned cell = cbeg; cell < cend; ++cell) {
+        unsigned nq = cell_counts[cell];
+        nq = (unsigned)__builtin_amdgcn_readfirstlane((int)nq);
+        if (nq == 0u)
+            continue;
+        if (nq > cap)
+            nq = cap;
+        const unsigned tb = tile_start[cell], te = tile_start[cell + 1];
+        const unsigned short *__restrict__ list = lists + (size_t)cell * cap;
+        for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
+            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
+            h8 ar[CELL_TILES_PER_PASS];
+#pragma unroll
+            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
+                if (p < nt)
+                    ar[p] = rf[(size_t)(t0 + (unsigned)p) * 64 + lane];
+            // the tiles' norms: nt * 8 float4 chunks, coalesced, into this wave's LDS window
+            __builtin_amdgcn_wave_barrier();   // the previous pass's reads are done
+            for (int i = lane; i < nt * 8; i += 64)
+                my_nrm[i] = *(const f4v *)(rn + (size_t)t0 * 32 + (size_t)i * 4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
+                const bool valid = q0 + (unsigned)col < nq;
+                const unsigned qid = list[valid ? q0 + (unsigned)col : q0];
+                const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
+                const float th = valid ? s_thr[qid] : -INFINITY;
+                u64 any = 0ull;
+                u64 masks[CELL_TILES_PER_PASS];
+#pragma unroll
+                for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                    masks[p] = 0ull;
+                    if (p < nt) {
+                        f16v c;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const f4v v = my_nrm[p * 8 + 2 * gq + half];
+                            c[4 * gq + 0] = v[0];
+                            c[4 * gq + 1] = v[1];
+                            c[4 * gq + 2] = v[2];
+                            c[4 * gq + 3] = v[3];
+                        }
+                        const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
+                        const float mn = min_tree16(d, th);
+                        masks[p] = __ballot(mn < th);
+                        any |= masks[p];
+                    }
+                }
+                if (__builtin_expect(any != 0ull, 0)) {
+                    const u64 me = 1ull << lane;
+#pragma unroll
+                    for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                        const u64 mask = masks[p];
+                        if (mask != 0ull) {
+                            if (mask & me) {
+                                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                if (pos < slice)
+                                    my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
+                            }
+                            cnt += (unsigned)__popcll(mask);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        counts[wave] = cnt;
+        if (cnt > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;
+    }
+}
+
 // Test hook: all scores of one (reference tile, query tile) pair per wave.
 template <int KT>
 __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restrict__ rf,
@@ -993,8 +1419,20 @@ static const unsigned kMaxLists = 1u << 16;
 static const unsigned kSampleBlocks = 512;           // most blocks the sample pass uses (x 4 waves)
 static const float kAmaxLimit = 1024.0f;           // queries far outside the references' box
 
+static void cells_free(CellIndex *&c)
+{
+    if (!c)
+        return;
+    (void)KNN_DEV_FREE(c->bounds);
+    (void)KNN_DEV_FREE(c->tile_start);
+    (void)KNN_DEV_FREE(c->perm);
+    delete c;
+    c = nullptr;
+}
+
 void knn_filter_free(FilterState &st)
 {
+    cells_free(st.cells);
     (void)KNN_DEV_FREE(st.center);
     (void)KNN_DEV_FREE(st.ref_frags);
     (void)KNN_DEV_FREE(st.ref_norms);
@@ -1011,8 +1449,140 @@ void knn_filter_free(FilterState &st)
         (void)KNN_DEV_FREE(w.counts);
         (void)KNN_DEV_FREE(w.umin);
         (void)KNN_DEV_FREE(w.qpart);
+        (void)KNN_DEV_FREE(w.cell_counts);
+        (void)KNN_DEV_FREE(w.cell_lists);
+        (void)KNN_DEV_FREE(w.dup);
+        (void)KNN_DEV_FREE(w.lo_tab);
+        (void)KNN_DEV_FREE(w.hi_tab);
+        if (w.cells_off)
+            (void)hipHostFree(w.cells_off);
     }
     st = FilterState();
+}
+
+// Sorts the shard into cells (see "Cell-pruned scan").  *out stays null when the shard is too small, the
+// dimension does not suit, or the cuts leave the cells badly unbalanced.  samp: the strided host sample
+// of the build (samples x k).  Synchronous.
+static hipError_t cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
+                              long long samples, hipStream_t s, long long *ntiles_out)
+{
+    *out = nullptr;
+    if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
+        return hipSuccess;
+    int bits = 0;
+    while ((224ll << (bits + 1)) <= n)   // cells of >= 224 rows on average (7-9 tiles for uniform data)
+        ++bits;
+    bits = std::min(bits, std::min(16, 4 * k));
+    if (bits < 9)
+        return hipSuccess;
+    CellIndex *c = new CellIndex();
+    c->bits = bits;
+    c->ncells = 1u << bits;
+    // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
+    // in 16 dimensions keeps ~36 of 1024), every query of a batch at <= 2^13 cells
+    c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
+    int pos = 0, sa = 0;
+    for (int d = 0; d < k; ++d) {
+        c->nb[d] = (unsigned char)(bits / k + (d < bits % k ? 1 : 0));
+        c->shift[d] = (unsigned char)pos;
+        if (pos <= 8)
+            sa = pos;
+        pos += c->nb[d];
+    }
+    if (pos <= 8)
+        sa = pos;
+    c->sa = sa;
+    if (sa < 6) {   // a wave of the match pass covers 64 consecutive low-table entries
+        delete c;
+        return hipSuccess;
+    }
+    // cuts at the sample quantiles
+    std::vector<float> bounds((size_t)16 * (CELL_MAX_BINS - 1), INFINITY), col((size_t)samples);
+    for (int d = 0; d < k; ++d) {
+        if (!c->nb[d])
+            continue;
+        for (long long i = 0; i < samples; ++i)
+            col[(size_t)i] = samp[(size_t)i * k + d];
+        std::sort(col.begin(), col.end());
+        const int nbins = 1 << c->nb[d];
+        for (int j = 1; j < nbins; ++j)
+            bounds[(size_t)d * (CELL_MAX_BINS - 1) + (j - 1)] = col[(size_t)(j * samples / nbins)];
+    }
+    CellGeom g;
+    memset(&g, 0, sizeof g);
+    g.k = k;
+    g.bits = bits;
+    g.sa = sa;
+    memcpy(g.nb, c->nb, 16);
+    memcpy(g.shift, c->shift, 16);
+
+    unsigned *code = nullptr, *counts = nullptr;
+    std::vector<unsigned> hcounts((size_t)c->ncells), hstart((size_t)c->ncells + 1);
+    hipError_t e = KNN_DEV_ALLOC((void **)&c->bounds, bounds.size() * sizeof(float));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&c->tile_start, hstart.size() * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&code, (size_t)n * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&counts, hcounts.size() * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(c->bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(knn_cells_code_kernel, dim3(blocks), dim3(256), 0, s, r, n, g, c->bounds, code, counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);   // (also keeps `bounds` alive until its copy is done)
+    bool keep = e == hipSuccess;
+    long long tiles = 0;
+    if (keep) {
+        unsigned biggest = 0u;
+        for (unsigned i = 0; i < c->ncells; ++i) {
+            hstart[i] = (unsigned)tiles;
+            tiles += (hcounts[i] + 31u) / 32u;
+            biggest = std::max(biggest, hcounts[i]);
+        }
+        hstart[c->ncells] = (unsigned)tiles;
+        c->max_cell_rows = biggest;
+        // badly unbalanced cells (clustered data the sample quantiles do not describe) leave a few waves with all the
+        // work and a few lists with all the queries: full scans serve such a shard better
+        keep = (long long)biggest * c->ncells <= 16 * n;
+    }
+    if (keep) {
+        e = hipMemcpyAsync(c->tile_start, hstart.data(), hstart.size() * sizeof(unsigned), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles * 32 * sizeof(unsigned));
+        if (e == hipSuccess)
+            e = hipMemsetAsync(c->perm, 0xFF, (size_t)tiles * 32 * sizeof(unsigned), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(knn_cells_scatter_kernel, dim3(blocks), dim3(256), 0, s, code, n, c->tile_start, counts,
+                               c->perm);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+    }
+    (void)KNN_DEV_FREE(code);
+    (void)KNN_DEV_FREE(counts);
+    if (e == hipErrorOutOfMemory) {   // no room for the sort: the plain layout still works
+        (void)hipGetLastError();
+        e = hipSuccess;
+        keep = false;
+    }
+    if (e != hipSuccess || !keep) {
+        cells_free(c);
+        return e;
+    }
+    *ntiles_out = tiles;
+    *out = c;
+    return hipSuccess;
 }
 
 // Robust box of a sample (samples x k, row-major): per dimension [median - w s, median + w s] clipped to
@@ -1079,14 +1649,14 @@ static double robust_box(const std::vector<float> &samp, long long samples, int 
     return h;
 }
 
-hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s)
+hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s, int want_cells)
 {
     st = FilterState();
     if (n <= 0 || k < 1 || k > 128)
         return hipSuccess;
     const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
     const int kp = 16 * kt;
-    const long long ntiles = (n + 31) / 32;
+    long long ntiles = (n + 31) / 32;
     const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1167,6 +1737,12 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         sigma = (float)ldexp(1.0, -ex);
     }
 
+    // 1c. cell-sorted layout (k <= 16, resident indexes): ntiles becomes the padded tile count
+    if (want_cells && kt == 1) {
+        FTRY(cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles));
+        lap(st.cells ? "cell sort" : "cell sort (not kept)");
+    }
+
     // 2. fragments + norms
     st.k = k;
     st.kt = kt;
@@ -1192,7 +1768,11 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     lap("allocations");
     if (e == hipSuccess) {
         const long long rows_padded = ntiles * 32;
-        if (k == 16 && ((uintptr_t)r & 15u) == 0)
+        if (st.cells)
+            hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
+                               rows_padded, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
+                               st.ref_norms, dout, 0, nullptr, nullptr, st.outliers, ocap, 0u, st.cells->perm);
+        else if (k == 16 && ((uintptr_t)r & 15u) == 0)
             hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s,
                                (const f4v *)r, n, rows_padded, st.center, sigma, (h8 *)st.ref_frags,
                                st.ref_norms, dout, st.outliers, ocap);
@@ -1765,14 +2345,118 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     return hipSuccess;
 }
 
+// ---- cell-pruned scan: host side --------------------------------------------------------------
+static const int kCellBatch = 1024;   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS
+
+static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m)
+{
+    const CellIndex &c = *st.cells;
+    if (!w.cell_counts)
+        FTRY(KNN_DEV_ALLOC((void **)&w.cell_counts, (size_t)c.ncells * sizeof(unsigned)));
+    if (!w.cell_lists)
+        FTRY(KNN_DEV_ALLOC((void **)&w.cell_lists, (size_t)c.ncells * c.cap * sizeof(unsigned short)));
+    if (!w.cells_off) {
+        FTRY(hipHostMalloc((void **)&w.cells_off, sizeof(unsigned), hipHostMallocDefault));
+        *w.cells_off = 0u;
+    }
+    const int m_padded = (m + 31) / 32 * 32;
+    if (m_padded > w.cell_m_cap) {
+        (void)KNN_DEV_FREE(w.dup);
+        (void)KNN_DEV_FREE(w.lo_tab);
+        (void)KNN_DEV_FREE(w.hi_tab);
+        w.dup = w.lo_tab = w.hi_tab = nullptr;
+        w.cell_m_cap = 0;
+        FTRY(KNN_DEV_ALLOC((void **)&w.dup, (size_t)m_padded * sizeof(float)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.lo_tab, (size_t)m_padded * ((size_t)1 << c.sa) * sizeof(float)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.hi_tab, (size_t)m_padded * ((size_t)1 << (c.bits - c.sa)) * sizeof(float)));
+        w.cell_m_cap = m_padded;
+    }
+    if ((size_t)m_padded > w.umin_cap) {
+        (void)KNN_DEV_FREE(w.umin);
+        w.umin = nullptr;
+        w.umin_cap = 0;
+        FTRY(KNN_DEV_ALLOC((void **)&w.umin, (size_t)m_padded * sizeof(float)));
+        w.umin_cap = (size_t)m_padded;
+    }
+    return hipSuccess;
+}
+
+// One batch of <= kCellBatch queries (already prepared by prep_queries): seed, thresholds, match, scan.
+static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const float *q, int num_cu, bool timed,
+                               hipStream_t s)
+{
+    const CellIndex &c = *st.cells;
+    const int m_padded = (m + 31) / 32 * 32;
+    CellGeom g;
+    memset(&g, 0, sizeof g);
+    g.k = st.k;
+    g.bits = c.bits;
+    g.sa = c.sa;
+    memcpy(g.nb, c.nb, 16);
+    memcpy(g.shift, c.shift, 16);
+    unsigned gx = (unsigned)num_cu * 3u;
+    if (gx * 4u > c.ncells)
+        gx = c.ncells / 4u;
+    w.nlists = gx * 4u;
+    w.slice = w.rec_cap / w.nlists;
+    w.has_rows = false;
+    w.pieces = RerankPieces();
+
+    hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds,
+                       (double)st.sigma * (double)st.sigma, c.tile_start, (const h8 *)st.ref_frags, st.ref_norms,
+                       (const h8 *)w.qry_frags, w.umin, w.lo_tab, w.hi_tab, m_padded);
+    FTRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin, 1, w.qry_norms,
+                       w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.ctl, w.qpart,
+                       (m_padded + 255) / 256, w.counts, w.nlists, w.dup, w.cells_off);
+    FTRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(64), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
+                       g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
+    FTRY(hipGetLastError());
+    if (timed && w.ev_begin)
+        FTRY(hipEventRecord(w.ev_begin, s));
+    const size_t lds = (size_t)m_padded * 36 + (size_t)4 * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    hipLaunchKernelGGL(knn_cells_scan_kernel, dim3(gx), dim3(256), lds, s, (const h8 *)st.ref_frags, st.ref_norms,
+                       c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded, w.cell_counts, w.cell_lists, c.cap,
+                       w.records, w.counts, w.ctl, w.slice);
+    FTRY(hipGetLastError());
+    if (timed && w.ev_end)
+        FTRY(hipEventRecord(w.ev_end, s));
+    return hipSuccess;
+}
+
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
                             u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     FilterWorkspace &w = st.ws[slot];
-    FTRY(ensure_workspace(st, w, m));
-    FTRY(prep_queries(st, w, m, q, s));
+    const unsigned *perm = st.cells ? st.cells->perm : nullptr;
+    const long long positions = st.cells ? st.ntiles * 32 : st.n;
+    // a batch the cells did not fit (reported through the pinned word, read here without waiting for anything)
+    // sends this index back to full scans for good
+    if (st.cells && !st.cells->off && w.cells_off && *(volatile unsigned *)w.cells_off != 0u)
+        st.cells->off = true;
+    const bool cells = st.cells && !st.cells->off && st.cells_policy != 2 && st.kt == 1;
+    w.last_used_cells = cells;
     w.ev_begin = ev_begin;
     w.ev_end = ev_end;
+    if (cells) {
+        FTRY(ensure_workspace(st, w, std::min(m, kCellBatch)));
+        FTRY(ensure_cells_workspace(st, w, std::min(m, kCellBatch)));
+        for (int q0 = 0; q0 < m; q0 += kCellBatch) {
+            const int mb = std::min(kCellBatch, m - q0);
+            const float *qb = q + (size_t)q0 * st.k;
+            u64 *kb = keys + q0;
+            FTRY(prep_queries(st, w, mb, qb, s));
+            FTRY(launch_cells(st, w, mb, qb, num_cu, q0 == 0, s));
+            FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl,
+                                   kb, w.pieces, s, perm));
+            FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
+            FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl + KNN_CTL_FALLBACK, s));
+        }
+        return hipSuccess;
+    }
+    FTRY(ensure_workspace(st, w, m));
+    FTRY(prep_queries(st, w, m, q, s));
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {
     case 1: FTRY(launch_filter<1>(st, w, m, num_cu, s)); break;
@@ -1791,9 +2475,9 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
         break;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
-    FTRY(knn_rerank_launch(st.k, st.n, q, r, base, w.records,
+    FTRY(knn_rerank_launch(st.k, positions, q, r, base, w.records,
                            w.has_rows ? (const unsigned short *)(w.records + w.rec_cap) : nullptr, w.counts, w.nlists,
-                           w.slice, w.ctl, keys, w.pieces, s));
+                           w.slice, w.ctl, keys, w.pieces, s, perm));
     // rows outside the robust box never entered the filter: exact scan of that (short) list
     FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
@@ -1804,6 +2488,8 @@ hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float 
                             float *thr_out, float *qnorm_out, double consts[8], hipStream_t s)
 {
     FilterWorkspace &w = st.ws[0];
+    if (st.cells)
+        return hipErrorInvalidValue;  // scores[q][row] assumes the layout is in row order
     FTRY(ensure_workspace(st, w, m));
     FTRY(prep_queries(st, w, m, q, s));
     const int qtiles = (m + 31) / 32;
