@@ -108,9 +108,11 @@ __global__ __launch_bounds__(256) void knn_ref_stats_kernel(const float *__restr
     for (long long e = gtid < stride ? gtid : count; e < count; e += stride) {
         const float v = R[e];
         if (!(fabsf(v) < INFINITY))
-            ++bad;
-        lo = fminf(lo, v);
-        hi = fmaxf(hi, v);
+            ++bad;   // counted, kept out of the range: such rows leave the filter for the exact list
+        else {
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
     }
     // fold the block in LDS first (k <= 128): one guarded global atomic per dimension per block —
     // per-thread atomics on the same 2k words ran at the single-word rate (1.4 ms for a 20 MB shard)
@@ -157,9 +159,11 @@ __global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restri
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (!(fabsf(v[c]) < INFINITY))
-                ++bad;
-            lo[c] = fminf(lo[c], v[c]);
-            hi[c] = fmaxf(hi[c], v[c]);
+                ++bad;   // counted, kept out of the range
+            else {
+                lo[c] = fminf(lo[c], v[c]);
+                hi[c] = fmaxf(hi[c], v[c]);
+            }
         }
     }
     // fold the block in LDS first (k <= 128): one guarded global atomic per dimension per block
@@ -1198,87 +1202,122 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
         umin[qi] = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
 }
 
-// Cell-major matching: one wave owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive low-table
-// entries).  Pass 1 (wave-wide, queries on the lanes): which queries get past the high table alone — ~15 %
-// for uniform data — compacted into an LDS queue.  Pass 2 (cells on the lanes): the low-table entry of each
-// queued query, 8 loads in flight.  cell_counts[c] = queries that could not rule cell c out,
-// lists[c][0..) = their numbers, ascending.  No atomics: per-cell appends with returning atomics ran at
-// 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
-__global__ __launch_bounds__(64) void knn_cells_match_kernel(
+// Cell-major matching: a block of 4 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
+// low-table entries).  Pass 1 (queries on the lanes, a quarter of the batch per wave): which queries get past
+// the high table alone — about a third for uniform data — compacted into an LDS queue.  Pass 2 (cells on
+// the lanes, the queue dealt round-robin to the waves): the low-table entry of each queued query, 16 loads in
+// flight per wave; survivors are appended to the cell's list under an LDS counter.  cell_counts[c] = queries
+// that could not rule cell c out, lists[c][0..) = their numbers (any order).  No global atomics: per-cell
+// appends with returning atomics ran at 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
+__global__ __launch_bounds__(256) void knn_cells_match_kernel(
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
     int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
     unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off)
 {
     __shared__ unsigned short s_q[1024];
     __shared__ float s_hv[1024], s_dq[1024];
+    __shared__ unsigned s_npass, s_cnt[64];
+    // lists of up to 128 entries are put together in LDS (row stride 65 dwords: lanes appending at the same
+    // depth hit different banks) and written out as whole 256-byte rows; longer ones (few, large cells) go
+    // straight to memory
+    __shared__ unsigned short s_list[64][130];
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned c0 = blockIdx.x * 64u;
     const unsigned cell = c0 + (unsigned)lane;
     const int nl = 1 << g.sa;
-    const unsigned h = c0 >> g.sa;                      // wave-uniform: nl >= 64
+    const unsigned h = c0 >> g.sa;                      // block-uniform: nl >= 64
     const unsigned l = cell & (unsigned)(nl - 1);
     const float *__restrict__ hrow = hi_tab + (size_t)h * m_padded;
-    unsigned npass = 0u;
-    for (int q0 = 0; q0 < m; q0 += 256) {   // 4 x 64 queries per round: their loads are issued together
+    if (threadIdx.x == 0)
+        s_npass = 0u;
+    if (threadIdx.x < 64)
+        s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    {   // pass 1: this wave's quarter of the batch (m <= 1024: at most 4 x 64 queries)
         float hv[4], dq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int q = q0 + u * 64 + lane;
+            const int q = (u * 4 + wib) * 64 + lane;
             hv[u] = q < m ? hrow[q] : INFINITY;
             dq[u] = q < m ? dup[q] : -INFINITY;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int q = q0 + u * 64 + lane;
+            const int q = (u * 4 + wib) * 64 + lane;
             const bool pass = q < m && !(hv[u] > dq[u]);
             const u64 mask = __ballot(pass);
-            if (pass) {
-                const unsigned pos = npass + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                s_q[pos] = (unsigned short)q;
-                s_hv[pos] = hv[u];
-                s_dq[pos] = dq[u];
-            }
-            npass += (unsigned)__popcll(mask);
-        }
-    }
-    __syncthreads();
-    unsigned short *__restrict__ my = lists + (size_t)cell * cap;
-    unsigned cnt = 0u;
-    for (unsigned e0 = 0u; e0 < npass; e0 += 8u) {
-        float lo[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned e = min(e0 + (unsigned)u, npass - 1u);
-            lo[u] = lo_tab[(size_t)s_q[e] * nl + l];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned e = e0 + (unsigned)u;
-            if (e < npass && cell < ncells) {
-                const float lb = lo[u] + s_hv[e];
-                if (!(lb > s_dq[e])) {
-                    if (cnt < cap)
-                        my[cnt] = s_q[e];
-                    ++cnt;
+            if (mask != 0ull) {   // wave-uniform
+                unsigned base = 0u;
+                if (lane == 0)
+                    base = atomicAdd(&s_npass, (unsigned)__popcll(mask));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (pass) {
+                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    s_q[pos] = (unsigned short)q;
+                    s_hv[pos] = hv[u];
+                    s_dq[pos] = dq[u];
                 }
             }
         }
     }
-    if (cell < ncells) {
+    __syncthreads();
+    const unsigned npass = s_npass;
+    const bool staged = cap <= 128u;
+    unsigned short *__restrict__ my = staged ? &s_list[lane][0] : lists + (size_t)cell * cap;
+    for (unsigned e0 = (unsigned)wib * 16u; e0 < npass; e0 += 64u) {
+        float lo[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned e = min(e0 + (unsigned)u, npass - 1u);
+            lo[u] = lo_tab[(size_t)s_q[e] * nl + l];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned e = e0 + (unsigned)u;
+            if (e < npass) {
+                const float lb = lo[u] + s_hv[e];
+                if (!(lb > s_dq[e])) {
+                    const unsigned pos = atomicAdd(&s_cnt[lane], 1u);
+                    if (pos < cap)
+                        my[pos] = s_q[e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wib == 0) {
+        const unsigned cnt = s_cnt[lane];
         cell_counts[cell] = cnt;
         if (cnt > cap) {
             ctl[KNN_CTL_FALLBACK] = 1u;  // a list is cut short: the gated exact scan answers this batch
             *cells_off = 1u;
         }
     }
+    if (staged) {
+        for (int j = wib; j < 64; j += 4) {
+            const unsigned cj = min(s_cnt[j], cap);
+            if ((unsigned)lane * 2u < cj)
+                ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[lane] = ((const unsigned *)&s_list[j][0])[lane];
+        }
+    }
 }
 
-// The scan.  Block = 4 waves sharing the batch's B operands and thresholds in LDS; wave w walks cells
-// [ncells w / W, ncells (w+1) / W).
-__global__ __launch_bounds__(256, 2) void knn_cells_scan_kernel(
+// The scan.  A block's waves share the batch's B operands and thresholds in LDS; wave w walks cells
+// [ncells w / W, ncells (w+1) / W).  Only ~4 % of the full scan's MFMA work is left (25 listed queries per
+// cell at C3), so what bounds the kernel is getting the fragments out of HBM: per cell a wave issues every
+// load it needs at once (tiles, norms, list: one round trip), and the kernel is written lean (~80 VGPRs, 12
+// waves per block) so that 5-6 waves per SIMD each have a cell in flight — ~50 MB outstanding chip-wide.
+// (Measured alternatives, C3, kernel alone: 4-wave blocks without any prefetch 0.151 ms; the next cell
+// prefetched into a second register set, 162 VGPRs / 3 waves per SIMD 0.145; that plus the C tile read once per
+// tile for up to 4 blocks of queries, 212 VGPRs / 2 waves per SIMD 0.171 — more registers per wave bought less
+// than they cost in waves.)
+#define CELL_SCAN_WAVES 12
+
+__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ tile_start, unsigned ncells,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
@@ -1287,85 +1326,104 @@ __global__ __launch_bounds__(256, 2) void knn_cells_scan_kernel(
     extern __shared__ unsigned char s_dyn[];
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
-    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [4 waves][CELL_TILES_PER_PASS * 8]
+    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int i = threadIdx.x; i < m_padded * 2; i += 256)
+    for (int i = threadIdx.x; i < m_padded * 2; i += 64 * CELL_SCAN_WAVES)
         s_qf[i] = qfg[i];
-    for (int i = threadIdx.x; i < m_padded; i += 256)
+    for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
         s_thr[i] = thrg[i];
     __syncthreads();
     f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
 
-    const unsigned wave = blockIdx.x * 4u + (unsigned)wib, nwaves = gridDim.x * 4u;
+    const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
     const unsigned cbeg = (unsigned)((u64)ncells * wave / nwaves), cend = (unsigned)((u64)ncells * (wave + 1u) / nwaves);
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
     unsigned cnt = 0u;
     const int col = lane & 31, half = lane >> 5;
-    for (unsigned cell = cbeg; cell < cend; ++cell) {
-        unsigned nq = cell_counts[cell];
-        nq = (unsigned)__builtin_amdgcn_readfirstlane((int)nq);
-        if (nq == 0u)
-            continue;
-        if (nq > cap)
-            nq = cap;
-        const unsigned tb = tile_start[cell], te = tile_start[cell + 1];
-        const unsigned short *__restrict__ list = lists + (size_t)cell * cap;
-        for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
-            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
-            h8 ar[CELL_TILES_PER_PASS];
+    for (unsigned g0 = cbeg; g0 < cend; g0 += 64u) {
+        // counts and tile ranges of up to 64 cells, one per lane
+        const unsigned mine = g0 + (unsigned)lane;
+        const bool in = mine < cend;
+        unsigned v_nq = in ? cell_counts[mine] : 0u;
+        const unsigned v_tb = in ? tile_start[mine] : 0u;
+        const unsigned v_te = in ? tile_start[mine + 1u] : 0u;
+        if (v_nq > cap)
+            v_nq = cap;
+        for (u64 todo = __ballot(v_nq != 0u && v_te > v_tb); todo != 0ull; todo &= todo - 1ull) {
+            const int j = (int)__builtin_ctzll(todo);
+            const unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
+            const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
+            const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, j);
+            const unsigned short *__restrict__ list = lists + (size_t)(g0 + (unsigned)j) * cap;
+            // the first two blocks of the list travel with the tiles (one round trip per cell)
+            const unsigned l0 = list[min((unsigned)lane, nq - 1u)];
+            for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
+                const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
+                h8 ar[CELL_TILES_PER_PASS];
 #pragma unroll
-            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                if (p < nt)
-                    ar[p] = rf[(size_t)(t0 + (unsigned)p) * 64 + lane];
-            // the tiles' norms: nt * 8 float4 chunks, coalesced, into this wave's LDS window
-            __builtin_amdgcn_wave_barrier();   // the previous pass's reads are done
-            for (int i = lane; i < nt * 8; i += 64)
-                my_nrm[i] = *(const f4v *)(rn + (size_t)t0 * 32 + (size_t)i * 4);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
-                const bool valid = q0 + (unsigned)col < nq;
-                const unsigned qid = list[valid ? q0 + (unsigned)col : q0];
-                const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
-                const float th = valid ? s_thr[qid] : -INFINITY;
-                u64 any = 0ull;
-                u64 masks[CELL_TILES_PER_PASS];
-#pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                    masks[p] = 0ull;
-                    if (p < nt) {
-                        f16v c;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const f4v v = my_nrm[p * 8 + 2 * gq + half];
-                            c[4 * gq + 0] = v[0];
-                            c[4 * gq + 1] = v[1];
-                            c[4 * gq + 2] = v[2];
-                            c[4 * gq + 3] = v[3];
-                        }
-                        const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
-                        const float mn = min_tree16(d, th);
-                        masks[p] = __ballot(mn < th);
-                        any |= masks[p];
+                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
+                    if (p < nt)
+                        ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
+                const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
+                const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
+                const f4v n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
+                __builtin_amdgcn_wave_barrier();   // the previous pass's reads of the window are done
+                my_nrm[lane] = n0;
+                if (lane < CELL_TILES_PER_PASS * 8 - 64)
+                    my_nrm[64 + lane] = n1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
+                    const unsigned idx = q0 + (unsigned)col;
+                    const bool valid = idx < nq;
+                    unsigned qid;
+                    if (q0 < 64u) {
+                        const unsigned from = __shfl(l0, (int)idx, KNN_WAVE);
+                        qid = valid ? from : __shfl(l0, 0, KNN_WAVE);
+                    } else {
+                        qid = list[valid ? idx : 0u];
                     }
-                }
-                if (__builtin_expect(any != 0ull, 0)) {
-                    const u64 me = 1ull << lane;
+                    const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
+                    const float th = valid ? s_thr[qid] : -INFINITY;
+                    u64 any = 0ull;
+                    u64 masks[CELL_TILES_PER_PASS];
 #pragma unroll
                     for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                        const u64 mask = masks[p];
-                        if (mask != 0ull) {
-                            if (mask & me) {
-                                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                if (pos < slice)
-                                    my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
+                        masks[p] = 0ull;
+                        if (p < nt) {
+                            f16v c;
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                const f4v v = my_nrm[p * 8 + 2 * gq + half];
+                                c[4 * gq + 0] = v[0];
+                                c[4 * gq + 1] = v[1];
+                                c[4 * gq + 2] = v[2];
+                                c[4 * gq + 3] = v[3];
                             }
-                            cnt += (unsigned)__popcll(mask);
+                            const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
+                            const float mn = min_tree16(d, th);
+                            masks[p] = __ballot(mn < th);
+                            any |= masks[p];
+                        }
+                    }
+                    if (__builtin_expect(any != 0ull, 0)) {
+                        const u64 me = 1ull << lane;
+#pragma unroll
+                        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                            const u64 mask = masks[p];
+                            if (mask != 0ull) {
+                                if (mask & me) {
+                                    const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                    if (pos < slice)
+                                        my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
+                                }
+                                cnt += (unsigned)__popcll(mask);
+                            }
                         }
                     }
                 }
@@ -1470,7 +1528,7 @@ static hipError_t cells_build(CellIndex **out, int k, long long n, const float *
     if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
         return hipSuccess;
     int bits = 0;
-    while ((224ll << (bits + 1)) <= n)   // cells of >= 224 rows on average (7-9 tiles for uniform data)
+    while ((160ll << (bits + 1)) <= n)   // cells of 160 .. 320 rows on average: 5-10 tiles each
         ++bits;
     bits = std::min(bits, std::min(16, 4 * k));
     if (bits < 9)
@@ -1693,8 +1751,14 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     (void)KNN_DEV_FREE(dstats);
     FTRY(e);
     lap("range kernel + sync");
-    if (hstats[(size_t)2 * k] != 0u)
-        return hipSuccess;  // NaN / Inf among the references: exact path only
+    // NaN / Inf among the references: those rows are outside any box and go to the exact list like every other
+    // outlier (the fragment kernels test for them); only a shard that is mostly such rows gets no layouts
+    const bool has_nonfinite = hstats[(size_t)2 * k] != 0u;
+    if ((long long)hstats[(size_t)2 * k] > n / 32)
+        return hipSuccess;
+    for (int d = 0; d < k; ++d)
+        if (hstats[(size_t)d] == 0xFFFFFFFFu || hstats[(size_t)k + d] == 0u)
+            return hipSuccess;  // a dimension without a single finite value
 
     // 1b. robust box: per dimension [median - w s, median + w s] clipped to [min, max], with
     // s = 1.4826 * MAD from a strided sample of up to 1024 rows (median/MAD do not move when a few rows sit
@@ -1721,12 +1785,28 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         FTRY(e);
         lap("sample rows + copy");
     }
+    long long samples_used = samples;
+    if (has_nonfinite) {   // the statistics below want finite rows only
+        samples_used = 0;
+        for (long long i = 0; i < samples; ++i) {
+            bool fin = true;
+            for (int d = 0; d < k; ++d)
+                fin = fin && fabsf(samp[(size_t)i * k + d]) < INFINITY;
+            if (fin) {
+                if (samples_used != i)
+                    memcpy(&samp[(size_t)samples_used * k], &samp[(size_t)i * k], (size_t)k * sizeof(float));
+                ++samples_used;
+            }
+        }
+        if (samples_used < 1)
+            return hipSuccess;
+    }
     std::vector<float> center, dlo((size_t)k), dhi((size_t)k);
     for (int d = 0; d < k; ++d) {
         dlo[(size_t)d] = ord2f_host(hstats[(size_t)d]);
         dhi[(size_t)d] = ord2f_host(hstats[(size_t)k + d]);
     }
-    const double h = robust_box(samp, samples, k, kp, dlo, dhi, center);
+    const double h = robust_box(samp, samples_used, k, kp, dlo, dhi, center);
     lap("median / MAD box (host)");
     if (!(h <= 1e15) || (h != 0.0 && h < 1e-15))
         return hipSuccess;
@@ -1739,7 +1819,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
 
     // 1c. cell-sorted layout (k <= 16, resident indexes): ntiles becomes the padded tile count
     if (want_cells && kt == 1) {
-        FTRY(cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles));
+        FTRY(cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles));
         lap(st.cells ? "cell sort" : "cell sort (not kept)");
     }
 
@@ -2394,10 +2474,10 @@ static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const
     g.sa = c.sa;
     memcpy(g.nb, c.nb, 16);
     memcpy(g.shift, c.shift, 16);
-    unsigned gx = (unsigned)num_cu * 3u;
-    if (gx * 4u > c.ncells)
-        gx = c.ncells / 4u;
-    w.nlists = gx * 4u;
+    unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
+    if (gx * CELL_SCAN_WAVES * 4u > c.ncells)
+        gx = std::max(1u, c.ncells / (CELL_SCAN_WAVES * 4u));
+    w.nlists = gx * CELL_SCAN_WAVES;
     w.slice = w.rec_cap / w.nlists;
     w.has_rows = false;
     w.pieces = RerankPieces();
@@ -2410,18 +2490,34 @@ static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const
                        w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.ctl, w.qpart,
                        (m_padded + 255) / 256, w.counts, w.nlists, w.dup, w.cells_off);
     FTRY(hipGetLastError());
-    hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(64), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
+    hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(256), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
                        g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
     FTRY(hipGetLastError());
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    const size_t lds = (size_t)m_padded * 36 + (size_t)4 * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
-    hipLaunchKernelGGL(knn_cells_scan_kernel, dim3(gx), dim3(256), lds, s, (const h8 *)st.ref_frags, st.ref_norms,
+    const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    hipLaunchKernelGGL(knn_cells_scan_kernel, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, st.ref_norms,
                        c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded, w.cell_counts, w.cell_lists, c.cap,
                        w.records, w.counts, w.ctl, w.slice);
     FTRY(hipGetLastError());
     if (timed && w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));
+    if (getenv("KNN_MI355X_TRACE_CELLS")) {   // development aid: how long the lists of this batch are (synchronises)
+        std::vector<unsigned> hc((size_t)c.ncells);
+        FTRY(hipStreamSynchronize(s));
+        FTRY(hipMemcpy(hc.data(), w.cell_counts, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        unsigned long long sum = 0, blocks = 0, groups = 0;
+        unsigned mx = 0, nz = 0;
+        for (unsigned v : hc) {
+            sum += v;
+            blocks += (v + 31) / 32;
+            groups += (v + 127) / 128;
+            mx = std::max(mx, v);
+            nz += v != 0;
+        }
+        fprintf(stderr, "[knn cells] m %d: %u cells, %u non-empty, %llu (cell, query) pairs = %.1f per cell, longest list %u, "
+                        "%llu blocks of 32, %llu groups of 128\n", m, c.ncells, nz, sum, (double)sum / c.ncells, mx, blocks, groups);
+    }
     return hipSuccess;
 }
 
