@@ -1068,10 +1068,15 @@ __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
 __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     const float *__restrict__ Q, int m, CellGeom g, const float *__restrict__ bounds, double sigma2,
     const unsigned *__restrict__ tile_start, const h8 *__restrict__ rf, const float *__restrict__ rn,
-    const h8 *__restrict__ qfg, float *__restrict__ umin, float *__restrict__ lo_tab, float *__restrict__ hi_tab,
-    int m_padded)
+    const h8 *__restrict__ qfg, float *__restrict__ lo_tab, float *__restrict__ hi_tab, int m_padded,
+    // thresholds (what knn_thr_kernel does for the full scan, here per block = per query)
+    const float *__restrict__ qnorm, const float *__restrict__ qamax, const unsigned *__restrict__ qpart, int qblocks,
+    int kt, float sigma, float bmax, float nmax, float amax_limit, float *__restrict__ thr, float *__restrict__ dup_out,
+    unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off, unsigned *__restrict__ counts, unsigned nlists)
 {
     __shared__ float s_gap[16][CELL_MAX_BINS];
+    __shared__ f4v s_nrm[4][CELL_TILES_PER_PASS * 8];
+    __shared__ unsigned s_tb[CELL_SEEDS];
     __shared__ unsigned s_bin[16], s_alt[16];
     __shared__ float s_altgap[16];
     __shared__ unsigned s_cells[CELL_SEEDS], s_tiles[CELL_SEEDS + 1];
@@ -1149,7 +1154,9 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
                 }
             s_cells[c] = code;
             s_tiles[c] = total;
-            total += ok ? tile_start[code + 1] - tile_start[code] : 0u;
+            const unsigned tb = tile_start[code];
+            s_tb[c] = tb;
+            total += ok ? tile_start[code + 1] - tb : 0u;
         }
         s_tiles[CELL_SEEDS] = total;
     }
@@ -1169,27 +1176,46 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
             hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
     }
     __syncthreads();
-    // the seed cells' tiles, dealt round-robin to the 4 waves, 4 in flight per wave
+    // housekeeping folded in here to save a launch: zero the record counters of the scan
+    for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < nlists; i += gridDim.x * 256u)
+        counts[i] = 0u;
+    // one seed cell per wave, all its tiles in flight at once (like the scan: one round trip)
     const h8 b = qfg[(size_t)(qi >> 5) * 64 + (lane >> 5) * 32 + (qi & 31)];  // every column = this query
     float um = INFINITY;
-    const unsigned total = s_tiles[CELL_SEEDS];
-    for (unsigned t0 = (unsigned)wib * 4u; t0 < total; t0 += 16u) {
-        h8 a[4][1];
-        f16v c[4];
+    for (int ci = wib; ci < CELL_SEEDS; ci += 4) {
+        const unsigned ntile = s_tiles[ci + 1] - s_tiles[ci], tb = s_tb[ci];
+        for (unsigned t0 = 0u; t0 < ntile; t0 += CELL_TILES_PER_PASS) {
+            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, ntile - t0);
+            h8 ar[CELL_TILES_PER_PASS];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned t = min(t0 + (unsigned)p, total - 1u);
-            int ci = 0;
+            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
+                if (p < nt)
+                    ar[p] = rf[(size_t)(tb + t0 + (unsigned)p) * 64 + lane];
+            const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)(tb + t0) * 8;
+            const f4v n0 = lane < nt * 8 ? rn4[lane] : (f4v){0.f, 0.f, 0.f, 0.f};
+            const f4v n1 = 64 + lane < nt * 8 ? rn4[64 + lane] : (f4v){0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_wave_barrier();
+            s_nrm[wib][lane] = n0;
+            if (lane < CELL_TILES_PER_PASS * 8 - 64)
+                s_nrm[wib][64 + lane] = n1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int j = 1; j < CELL_SEEDS; ++j)
-                ci += t >= s_tiles[j] ? 1 : 0;
-            const long long tile = (long long)tile_start[s_cells[ci]] + (t - s_tiles[ci]);
-            load_ref_tile<1>(rf, rn, tile, lane, a[p], c[p]);
-        }
+            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
+                if (p < nt) {
+                    f16v c;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[p][0], b, c[p], 0, 0, 0);
-            um = min_tree16(d, um);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f4v v = s_nrm[wib][p * 8 + 2 * gq + (lane >> 5)];
+                        c[4 * gq + 0] = v[0];
+                        c[4 * gq + 1] = v[1];
+                        c[4 * gq + 2] = v[2];
+                        c[4 * gq + 3] = v[3];
+                    }
+                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
+                    um = min_tree16(d, um);
+                }
         }
     }
 #pragma unroll
@@ -1198,8 +1224,46 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     if (lane == 0)
         s_red[wib] = um;
     __syncthreads();
-    if (tid == 0)
-        umin[qi] = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    if (tid == 0) {
+        const float u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+        float amax = 0.0f;
+        unsigned qbad = 0u;
+        for (int bq = 0; bq < qblocks; ++bq) {  // per-block partials of the query fragment kernel
+            amax = fmaxf(amax, __uint_as_float(qpart[3 * bq]));
+            qbad |= qpart[3 * bq + 2];
+        }
+        if (qi == 0) {
+            ctl[KNN_CTL_AMAX] = __float_as_uint(amax);
+            ctl[KNN_CTL_QBAD] = qbad;
+            for (int i = m; i < m_padded; ++i) {   // padding queries never pass
+                thr[i] = -INFINITY;
+                dup_out[i] = -INFINITY;
+            }
+        }
+        bool bad = qbad != 0u || !(amax <= amax_limit);
+        float t = -INFINITY, dupf = -INFINITY;
+        if (!bad && !(u < INFINITY)) {
+            bad = true;        // the seed cells held no row of the filter: cannot bound
+            *cells_off = 1u;   // the strided sample of the full scan will serve the next batches
+        }
+        if (!bad) {
+            const BoundConsts cst = knn_bound_consts(g.k, kt, sigma, qamax[qi], bmax, nmax);
+            double dup = 0.0;
+            t = knn_threshold(cst, u, qnorm[qi], &dup);
+            if (!(t < INFINITY))
+                bad = true;
+            else {
+                dup *= 1.0 + 1e-6;
+                dupf = (float)dup;
+                if ((double)dupf < dup)
+                    dupf = nextafterf(dupf, INFINITY);
+            }
+        }
+        thr[qi] = bad ? -INFINITY : t;
+        dup_out[qi] = bad ? -INFINITY : dupf;
+        if (bad)
+            ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
+    }
 }
 
 // Cell-major matching: a block of 4 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
@@ -1339,14 +1403,17 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
     f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
 
     const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
-    const unsigned cbeg = (unsigned)((u64)ncells * wave / nwaves), cend = (unsigned)((u64)ncells * (wave + 1u) / nwaves);
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
     unsigned cnt = 0u;
     const int col = lane & 31, half = lane >> 5;
+    const bool interleave = true;   // wave w takes cells w, w + W, ...: all waves read one moving window of the layout (contiguous ranges per wave: +6 %)
+    const unsigned per_wave = (ncells + nwaves - 1u) / nwaves;
+    const unsigned cbeg = interleave ? 0u : (unsigned)((u64)ncells * wave / nwaves);
+    const unsigned cend = interleave ? per_wave : (unsigned)((u64)ncells * (wave + 1u) / nwaves);
     for (unsigned g0 = cbeg; g0 < cend; g0 += 64u) {
         // counts and tile ranges of up to 64 cells, one per lane
-        const unsigned mine = g0 + (unsigned)lane;
-        const bool in = mine < cend;
+        const unsigned mine = interleave ? (g0 + (unsigned)lane) * nwaves + wave : g0 + (unsigned)lane;
+        const bool in = interleave ? (g0 + (unsigned)lane < per_wave && mine < ncells) : mine < cend;
         unsigned v_nq = in ? cell_counts[mine] : 0u;
         const unsigned v_tb = in ? tile_start[mine] : 0u;
         const unsigned v_te = in ? tile_start[mine + 1u] : 0u;
@@ -1357,7 +1424,8 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
             const unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
             const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
             const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, j);
-            const unsigned short *__restrict__ list = lists + (size_t)(g0 + (unsigned)j) * cap;
+            const unsigned cellj = interleave ? (g0 + (unsigned)j) * nwaves + wave : g0 + (unsigned)j;
+            const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
             // the first two blocks of the list travel with the tiles (one round trip per cell)
             const unsigned l0 = list[min((unsigned)lane, nq - 1u)];
             for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
@@ -2484,11 +2552,9 @@ static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const
 
     hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds,
                        (double)st.sigma * (double)st.sigma, c.tile_start, (const h8 *)st.ref_frags, st.ref_norms,
-                       (const h8 *)w.qry_frags, w.umin, w.lo_tab, w.hi_tab, m_padded);
-    FTRY(hipGetLastError());
-    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin, 1, w.qry_norms,
-                       w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.ctl, w.qpart,
-                       (m_padded + 255) / 256, w.counts, w.nlists, w.dup, w.cells_off);
+                       (const h8 *)w.qry_frags, w.lo_tab, w.hi_tab, m_padded, w.qry_norms, w.qry_amax, w.qpart,
+                       (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup, w.ctl, w.cells_off,
+                       w.counts, w.nlists);
     FTRY(hipGetLastError());
     hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(256), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
                        g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
