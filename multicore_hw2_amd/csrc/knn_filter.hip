@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_sample_kernel(
 #define CELL_MAX_BINS 16
 #define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts
 #define CELL_SEEDS (1 << CELL_SEED_DIMS)
-#define CELL_TILES_PER_PASS 10                // reference tiles a wave holds in registers at a time
+#define CELL_TILES_PER_PASS 9                 // reference tiles a wave holds in registers at a time (one more costs the sixth wave per SIMD)
 
 struct CellGeom {
     int k, bits, sa;                 // dimensions, total bits, bits of the low table
@@ -1381,6 +1381,8 @@ __global__ __launch_bounds__(256) void knn_cells_match_kernel(
 // than they cost in waves.)
 #define CELL_SCAN_WAVES 12
 
+// (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512 — at 81, with ten
+// tiles per pass, the second block of a CU waited for the first to finish and the kernel took two rounds)
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ tile_start, unsigned ncells,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m_padded,
@@ -1596,7 +1598,7 @@ static hipError_t cells_build(CellIndex **out, int k, long long n, const float *
     if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
         return hipSuccess;
     int bits = 0;
-    while ((160ll << (bits + 1)) <= n)   // cells of 160 .. 320 rows on average: 5-10 tiles each
+    while ((144ll << (bits + 1)) <= n)   // cells of 144 .. 288 rows on average: 5-9 tiles each
         ++bits;
     bits = std::min(bits, std::min(16, 4 * k));
     if (bits < 9)
