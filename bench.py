@@ -188,7 +188,8 @@ def main():
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
     # (the library chains the scans of different slots for shards of >= 16M rows: two in flight are enough then)
     long_scan = n_local >= (1 << 24)
-    inflight = args.inflight if args.inflight > 0 else (2 if long_scan else 3)
+    cells_expected = k <= 16 and n_local >= (1 << 17) and pkg.get_option("cells") != 2 and pkg.get_option("path") in (0, 2)
+    inflight = args.inflight if args.inflight > 0 else (2 if long_scan and not cells_expected else 3)
     nbuf = 1 if args.serial else max(1, min(4, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.
     keys_all = torch.empty((2, nbuf, m), dtype=torch.int64, device=dev)
@@ -311,6 +312,16 @@ def main():
                     "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None,
                     "kernel": "knn_filter (f16 MFMA 32x32x16 + exact re-rank)",
                     "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / HBM_PEAK_GBPS}
+        elif path_taken == 4:
+            # cell-pruned scan: ~4 % of the pairs are scored (MFMA work is no longer the bound); the kernel reads the
+            # fp16 fragments + norms of the shard once (36 B per row against the 64 B of the fp32 row the algorithmic
+            # figure counts), so `achieved` can exceed what the wires carry: hbm_frac_physical is the wire rate
+            phys = 36.0 * n_local * 1.04 + 2.0 * 128 * (n_local / 256.0)   # layout (4 % padding) + the per-cell lists
+            roof = {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": hbm_gbps / HBM_PEAK_GBPS, "traffic": None,
+                    "kernel": "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out + exact re-rank)",
+                    "physical_bytes_per_launch_estimate": phys,
+                    "hbm_frac_physical": phys / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         else:
             lane_ops = (3.0 * k + 3.0) * m * n_local
             roof = {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -329,7 +340,7 @@ def main():
             with open(pmc_path) as f:
                 pmc_doc = json.load(f)
             if pmc_doc.get("kernel_source_sha256") == kernel_source_sha():
-                kname = "_Z17knn_filter" if path_taken == 2 else "void knn_exact_qreg<16, 2>"
+                kname = {2: "_Z17knn_filter", 4: "_Z21knn_cells_scan"}.get(path_taken, "void knn_exact_qreg<16, 2>")
                 best = None
                 for name, ent in pmc_doc["kernels"].items():
                     if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
@@ -365,6 +376,8 @@ def main():
         roof["kernel_launches_timed"] = launches
         chain = pkg.get_option("filter_chain") if hasattr(pkg, "get_option") else 0
         roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or (chain == 0 and not long_scan)))
+        if path_taken == 4 and "hbm_frac_physical" in roof and alone_n:
+            roof["hbm_frac_physical_alone"] = roof["hbm_frac_physical"] * kern_avg_ms / (alone_ms / alone_n)
         if roof["launches_overlap"]:
             roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
                            "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \
@@ -386,10 +399,11 @@ def main():
             "metric": "queries/sec (brute-force 1-NN, bit-exact vs v0), m=%d n=%d k=%d" % (m, n, k),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 results (f16 MFMA filter + f32 exact re-rank)" if path_taken == 2 else "f32", "data": "synthetic",
+            "dtype": "f32 results (f16 MFMA filter + f32 exact re-rank)" if path_taken in (2, 4) else "f32", "data": "synthetic",
             "config": {"workload": "%s: k=%d m=%d n=%d uniform[0,1) fp32, refs resident in HBM, sharded over n" %
                                    (wname, k, m, n),
-                       "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank", 3: "grid_index"}.get(path_taken),
+                       "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank", 3: "grid_index",
+                                                     4: "cell_pruned_mfma_filter+exact_rerank"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "batches_in_flight": nstreams, "setup_steps": SETUP_STEPS,
                        "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %

@@ -1,0 +1,220 @@
+"""The cell-pruned form of the MFMA filter (k <= 16, resident shards of >= 2^17 rows) against the CPU oracle.
+What is under test is the pruning argument: a cell is skipped for a query only if NO row in it can be the
+answer v0 would give — ties, rows on the cut planes, duplicates, queries far away or not finite included —
+and everything the cells cannot serve falls to the exact scan without a wrong index.  Bar: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch  # imported BEFORE libknn_mi355x.so is dlopen'ed: one HIP runtime (torch's) per process
+
+import multicore_hw2_amd as pkg
+
+pytestmark = pytest.mark.gpu
+THREADS = min(16, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
+    assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
+    yield
+    for name in ("path", "shards", "cells"):
+        pkg.set_option(name, 0)
+
+
+def _query(ix, Q):
+    got = ix.query(Q)
+    return got, ix.last_stats()
+
+
+def _cases(rng, name, k, m, n):
+    R = rng.random((n, k), dtype=np.float32)
+    Q = rng.random((m, k), dtype=np.float32)
+    if name == "offset":                      # far from the origin: the cuts sit at 4096.x
+        R += np.float32(4096.0)
+        Q += np.float32(4096.0)
+    elif name == "lattice":                   # few distinct coordinate values: rows and queries ON the cuts, many exact ties
+        R = (rng.integers(0, 5, (n, k)) * 0.25).astype(np.float32)
+        Q = (rng.integers(0, 5, (m, k)) * 0.25).astype(np.float32)
+    elif name == "clustered":                 # 16 tight blobs: unbalanced cells (the build may decline them)
+        c = rng.random((16, k), dtype=np.float32)
+        R = (c[rng.integers(0, 16, n)] + rng.normal(0, 0.01, (n, k))).astype(np.float32)
+        Q = (c[rng.integers(0, 16, m)] + rng.normal(0, 0.02, (m, k))).astype(np.float32)
+    elif name == "skewed":                    # x^4: the quantile cuts are far from the middle of the range
+        R = R ** 4
+        Q = Q ** 4
+    elif name == "queries_outside":           # most queries outside the references' box, some far outside
+        Q = (Q * 3.0 - 1.0).astype(np.float32)
+        Q[:4] = np.float32(300.0)
+    elif name == "copies":                    # every query is a reference row: distance 0, lowest index of its copies
+        src = rng.integers(0, n, m)
+        Q = R[src].copy()
+        R[rng.integers(0, n, 64)] = R[src[:64]]
+    return Q, R
+
+
+@pytest.mark.parametrize("k", [3, 5, 8, 12, 16])
+@pytest.mark.parametrize("dist", ["uniform", "offset", "lattice", "clustered", "skewed", "queries_outside", "copies"])
+def test_cell_pruned_scan_is_bit_exact(oracle, k, dist):
+    m, n = 600, (1 << 17) + 4321
+    rng = np.random.default_rng(k * 1000 + len(dist))
+    Q, R = _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("path", 2)
+    pkg.set_option("cells", 1)
+    try:
+        ix = pkg.KnnIndex(k, R, base_index=1000)
+        got, st = _query(ix, Q)
+        again, _ = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("path", 0)
+        pkg.set_option("cells", 0)
+    np.testing.assert_array_equal(got - 1000, want, err_msg=f"{dist} k={k} stats={st}")
+    np.testing.assert_array_equal(again, got)
+    if dist in ("uniform", "offset", "skewed"):
+        assert st[0] == 4 and st[2] == 0, st      # the cells served the batch: no device fallback
+
+
+def test_equidistant_rows_in_different_cells_resolve_to_the_lower_index(oracle):
+    """Pairs of rows mirrored about a query along one axis (exactly equal v0 distances, different cells on
+    either side of a cut): the answer is the lower index, wherever it sits."""
+    k, m, n = 16, 256, 1 << 17
+    rng = np.random.default_rng(77)
+    R = rng.random((n, k), dtype=np.float32)
+    Q = (rng.random((m, k), dtype=np.float32) * 0.5 + 0.25).astype(np.float32)
+    Q[:, 0] = np.float32(0.5)                                  # on (or next to) the cut of dimension 0
+    lo = rng.choice(n, m, replace=False)
+    hi = rng.choice(np.setdiff1d(np.arange(n), lo), m, replace=False)
+    d = np.float32(2.0 ** -6)
+    for j in range(m):                                         # closer than any random row can be in 16 dimensions
+        a, b = (lo[j], hi[j]) if j % 2 else (hi[j], lo[j])
+        R[a] = Q[j]
+        R[a, 0] = np.float32(0.5) - d
+        R[b] = Q[j]
+        R[b, 0] = np.float32(0.5) + d
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    np.testing.assert_array_equal(want, np.minimum(lo, hi))   # the construction holds under v0
+    pkg.set_option("cells", 1)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+    np.testing.assert_array_equal(got, want)
+    assert st[0] == 4 and st[2] == 0, st
+
+
+def test_batches_longer_than_one_pass_and_single_queries(oracle):
+    k, n = 16, 1 << 18
+    R = oracle.synth(n * k, 31).reshape(n, k)
+    ix = pkg.KnnIndex(k, R)                                     # library policy: cells for a resident index this size
+    try:
+        for m in (1, 31, 1024, 1025, 2500):
+            Q = oracle.synth(m * k, 100 + m).reshape(m, k)
+            got, st = _query(ix, Q)
+            np.testing.assert_array_equal(got, oracle.v0(k, Q, R, threads=THREADS), err_msg=f"m={m}")
+            assert st[0] == 4 and st[2] == 0, (m, st)
+    finally:
+        ix.close()
+
+
+def test_a_batch_the_cells_cannot_hold_is_answered_exactly_and_switches_the_index_to_full_scans(oracle):
+    """1024 copies of one query want the same ~4 % of the cells: their lists (128 entries per cell at 2^16
+    cells) overflow.  The batch must come back exact (device-side fallback), and the index must stop using
+    the cells afterwards (the pinned flag), still exact."""
+    k, n, m = 16, 1 << 24, 1024
+    dev = torch.device("cuda:0")
+    r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    pkg.synth_fill_device(r_d.data_ptr(), n * k, 1001, device=0, stream=stream)
+    torch.cuda.synchronize()
+    q1 = oracle.synth(k, 5)
+    Q = np.tile(q1, (m, 1)).astype(np.float32)
+    Qv = oracle.synth(m * k, 6).reshape(m, k)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True, stream=stream)
+    try:
+        sel = slice(0, 8)
+        R = oracle.synth(n * k, 1001)
+        want_same = oracle.v0(k, Q[sel], R, threads=THREADS)
+        want_var = oracle.v0(k, Qv[sel], R, threads=THREADS)
+        got, st = _query(ix, Qv)                                # a normal batch first: cells, no fallback
+        assert st[0] == 4 and st[2] == 0, st
+        np.testing.assert_array_equal(got[sel], want_var)
+        got, st = _query(ix, Q)                                 # the overflowing batch
+        assert st[0] == 4 and st[2] == 1, st
+        assert (got == want_same[0]).all()
+        got, st = _query(ix, Qv)                                # afterwards: full scans
+        assert st[0] == 2 and st[2] == 0, st
+        np.testing.assert_array_equal(got[sel], want_var)
+    finally:
+        ix.close()
+
+
+def test_non_finite_queries_take_the_exact_scan_for_their_batch_only(oracle):
+    k, n, m = 16, 1 << 17, 200
+    R = oracle.synth(n * k, 41).reshape(n, k)
+    Q = oracle.synth(m * k, 42).reshape(m, k).copy()
+    Qbad = Q.copy()
+    Qbad[3, 5] = np.nan
+    Qbad[7, 0] = np.inf
+    ix = pkg.KnnIndex(k, R)
+    try:
+        got, st = _query(ix, Qbad)
+        np.testing.assert_array_equal(got, oracle.v0(k, Qbad, R, threads=THREADS))
+        assert st[0] == 4 and st[2] == 1, st
+        got, st = _query(ix, Q)                                 # bad queries are not the cells' fault: still on
+        np.testing.assert_array_equal(got, oracle.v0(k, Q, R, threads=THREADS))
+        assert st[0] == 4 and st[2] == 0, st
+    finally:
+        ix.close()
+
+
+def test_cells_policy_and_option(oracle):
+    """Library policy: cell-sorted layouts for resident indexes of >= 2^17 rows with k <= 16; never for the
+    one-shot drop-in call; `cells` = 2 switches them off, 1 asks for them wherever the dimension allows."""
+    k = 16
+    Q = oracle.synth(64 * k, 2).reshape(64, k)
+    for n, cells, expect in (((1 << 17), 0, 4), ((1 << 17) - 1, 0, 2), ((1 << 17), 2, 2), ((1 << 17), 1, 4)):
+        R = oracle.synth(n * k, 3).reshape(n, k)
+        pkg.set_option("cells", cells)
+        try:
+            ix = pkg.KnnIndex(k, R)
+            got, st = _query(ix, Q)
+            ix.close()
+        finally:
+            pkg.set_option("cells", 0)
+        np.testing.assert_array_equal(got, oracle.v0(k, Q, R, threads=THREADS))
+        assert st[0] == expect, (n, cells, st)
+    with pytest.raises(pkg.KnnError):
+        pkg.set_option("cells", 3)
+    n = 1 << 17
+    R = oracle.synth(n * k, 3).reshape(n, k)
+    np.testing.assert_array_equal(pkg.cudaCallback(k, 64, n, Q, R), oracle.v0(k, Q, R, threads=THREADS))
+
+
+def test_two_batches_in_flight_on_their_own_slots_and_streams(oracle):
+    k, n, m = 16, 1 << 18, 512
+    dev = torch.device("cuda:0")
+    R = oracle.synth(n * k, 51).reshape(n, k)
+    r_d = torch.from_numpy(R).to(dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    try:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        Qs = [oracle.synth(m * k, 60 + i).reshape(m, k) for i in range(3)]
+        q_d = [torch.from_numpy(q).to(dev) for q in Qs]
+        keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(3)]
+        outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(3)]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for i, s in enumerate(streams):
+                pkg.keys_init(keys[i].data_ptr(), m, device=0, stream=s.cuda_stream)
+                ix.query_keys(m, q_d[i].data_ptr(), keys[i].data_ptr(), stream=s.cuda_stream, slot=i)
+                pkg.keys_to_indices(keys[i].data_ptr(), m, outs[i].data_ptr(), device=0, stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(3):
+            np.testing.assert_array_equal(outs[i].cpu().numpy(), oracle.v0(k, Qs[i], R, threads=THREADS), err_msg=f"slot {i}")
+    finally:
+        ix.close()
