@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every N-th launch of the dominant kernel with HIP events (roofline.kernel_avg_ms)")
     ap.add_argument("--deepk", type=int, default=0, help="A/B: deep-K LDS-tiled scan, 0 = 4 waves per block, 1 = 8 waves per block")
+    ap.add_argument("--cells", type=int, default=0, help="A/B: cell-sorted layouts, 0 = library policy, 1 = always (k <= 16), 2 = never")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
@@ -172,6 +173,8 @@ def main():
         pkg.set_option("filter_chain", args.filter_chain)
     if args.deepk:
         pkg.set_option("deepk", args.deepk)
+    if args.cells:
+        pkg.set_option("cells", args.cells)
 
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)

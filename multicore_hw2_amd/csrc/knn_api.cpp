@@ -70,7 +70,7 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_deepk{0};
-std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes of >= 2^17 rows, 1 every index, 2 never
+std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
 std::atomic<long long> g_rccl_reductions{0}; // cudaCallback merges done by the RCCL all-reduce
@@ -445,9 +445,13 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     // MFMA filter layouts (skipped for small shards and when the exact path is forced)
     idx->filter_wanted = build_filter > 0;
     // cell-sorted layout for the pruned scan: indexes the caller keeps (library policy) or on request; the
-    // one-shot cudaCallback asks for explicit layouts and answers one batch, which does not repay the sort
+    // one-shot cudaCallback asks for explicit layouts and answers one batch, which does not repay the sort.
+    // Pruning needs enough cells for the dimension: measured on uniform data at m = 1024 (profiles/r02_cells_policy.txt)
+    // the pruned scan wins from 2^19 rows for k <= 12 and from 2^21 rows for k = 13..16; below that the lists
+    // hold most of the batch and the full scan's register-resident loop is the faster way to score them.
+    const long long cells_from = k <= 12 ? (1ll << 19) : (1ll << 21);
     const bool want_cells = k <= 16 && n_local >= (1ll << 17) &&
-                            (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0));
+                            (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));
     if (build_filter < 0) {
         // library policy: shards of >= 65536 rows; for 32 < k <= 128 (3k+3 exact lane-ops per pair,
         // one query per lane above k = 64) the MFMA filter pays off from 4096 rows already

@@ -110,7 +110,9 @@ def test_equidistant_rows_in_different_cells_resolve_to_the_lower_index(oracle):
 def test_batches_longer_than_one_pass_and_single_queries(oracle):
     k, n = 16, 1 << 18
     R = oracle.synth(n * k, 31).reshape(n, k)
-    ix = pkg.KnnIndex(k, R)                                     # library policy: cells for a resident index this size
+    pkg.set_option("cells", 1)
+    ix = pkg.KnnIndex(k, R)
+    pkg.set_option("cells", 0)
     try:
         for m in (1, 31, 1024, 1025, 2500):
             Q = oracle.synth(m * k, 100 + m).reshape(m, k)
@@ -160,7 +162,9 @@ def test_non_finite_queries_take_the_exact_scan_for_their_batch_only(oracle):
     Qbad = Q.copy()
     Qbad[3, 5] = np.nan
     Qbad[7, 0] = np.inf
+    pkg.set_option("cells", 1)
     ix = pkg.KnnIndex(k, R)
+    pkg.set_option("cells", 0)
     try:
         got, st = _query(ix, Qbad)
         np.testing.assert_array_equal(got, oracle.v0(k, Qbad, R, threads=THREADS))
@@ -173,11 +177,13 @@ def test_non_finite_queries_take_the_exact_scan_for_their_batch_only(oracle):
 
 
 def test_cells_policy_and_option(oracle):
-    """Library policy: cell-sorted layouts for resident indexes of >= 2^17 rows with k <= 16; never for the
-    one-shot drop-in call; `cells` = 2 switches them off, 1 asks for them wherever the dimension allows."""
-    k = 16
-    Q = oracle.synth(64 * k, 2).reshape(64, k)
-    for n, cells, expect in (((1 << 17), 0, 4), ((1 << 17) - 1, 0, 2), ((1 << 17), 2, 2), ((1 << 17), 1, 4)):
+    """Library policy: cell-sorted layouts for resident indexes of >= 2^19 rows (k <= 12) or >= 2^21 rows
+    (k = 13..16); never for the one-shot drop-in call; `cells` = 2 switches them off, 1 asks for them from 2^17
+    rows on."""
+    Q16 = oracle.synth(64 * 16, 2).reshape(64, 16)
+    for k, n, cells, expect in ((16, 1 << 21, 0, 4), (16, (1 << 21) - 1, 0, 2), (8, 1 << 19, 0, 4), (8, (1 << 19) - 1, 0, 2),
+                                (16, 1 << 21, 2, 2), (16, 1 << 17, 1, 4), (16, (1 << 17) - 1, 1, 2)):
+        Q = np.ascontiguousarray(Q16[:, :k])
         R = oracle.synth(n * k, 3).reshape(n, k)
         pkg.set_option("cells", cells)
         try:
@@ -190,9 +196,9 @@ def test_cells_policy_and_option(oracle):
         assert st[0] == expect, (n, cells, st)
     with pytest.raises(pkg.KnnError):
         pkg.set_option("cells", 3)
-    n = 1 << 17
+    k, n = 16, 1 << 21
     R = oracle.synth(n * k, 3).reshape(n, k)
-    np.testing.assert_array_equal(pkg.cudaCallback(k, 64, n, Q, R), oracle.v0(k, Q, R, threads=THREADS))
+    np.testing.assert_array_equal(pkg.cudaCallback(k, 64, n, Q16, R), oracle.v0(k, Q16, R, threads=THREADS))
 
 
 def test_two_batches_in_flight_on_their_own_slots_and_streams(oracle):
@@ -200,7 +206,9 @@ def test_two_batches_in_flight_on_their_own_slots_and_streams(oracle):
     dev = torch.device("cuda:0")
     R = oracle.synth(n * k, 51).reshape(n, k)
     r_d = torch.from_numpy(R).to(dev)
+    pkg.set_option("cells", 1)
     ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    pkg.set_option("cells", 0)
     try:
         streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
         Qs = [oracle.synth(m * k, 60 + i).reshape(m, k) for i in range(3)]
