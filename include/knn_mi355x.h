@@ -156,6 +156,13 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             (also with one GPU: a 1-rank communicator); 2 = host merge always.
  *             knn_get_option("rccl_reductions") counts the merges RCCL has done,
  *             knn_get_option("rccl_version") is the loaded library's NCCL_VERSION_CODE (0: none)
+ *   "cells"   the MFMA filter's cell-pruned form (k <= 16): the index sorts the shard into 2^B cells (every
+ *             dimension cut at sample quantiles), and a batch scores only the cells each query could not
+ *             rule out by its distance to the cell's box.  0 = library policy: indexes created with
+ *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^21 rows (k = 13 .. 16); never for the
+ *             one-shot cudaCallback (one batch does not repay the sort).  1 = every index of >= 2^17 rows,
+ *             cudaCallback's shards included; 2 = never.  Read when an index is created; 2 also makes
+ *             existing indexes use the full scan.  Results are bit-exact either way
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the
@@ -166,7 +173,8 @@ long long knn_get_option(const char *name);
 
 /* Statistics of the most recent knn_index_query_keys on this index (filled
  * when the stream has completed; call after synchronising):
- *   [0] path taken (1 exact, 2 filter, 3 grid index)   [1] candidates re-ranked exactly
+ *   [0] path taken (1 exact, 2 filter, 3 grid index, 4 filter in its cell-pruned form)
+ *   [1] candidates re-ranked exactly
  *   [2] != 0: the device fell back to the exact scan   [3] reference rows outside the filter's
  *   robust box (scanned exactly on every query) */
 int knn_index_last_stats(knn_index *idx, long long stats[4]);
@@ -175,7 +183,8 @@ int knn_index_last_stats(knn_index *idx, long long stats[4]);
  * device) for a query batch, the fp32 squared norms M[m] of the fp16 query rows (device), and
  * consts = {sigma, eta, rho, Amax, Bmax, g2, gamma, #non-finite fp16 query coordinates}.  A pair's
  * score obeys |S + M - sigma^2 d^2| <= 2 eta sigma d + eta^2 + rho (+ gamma M), d = real distance.
- * Synchronous; needs an index that has filter layouts (else KNN_EINVAL). */
+ * Synchronous; needs an index that has filter layouts in row order (else KNN_EINVAL / KNN_EHIP: a cell-sorted
+ * index — option "cells" — has no [m][n_local] score matrix). */
 int knn_debug_filter_scores(knn_index *idx, int m, const float *queries_dev, float *scores_dev,
                             float *qnorm_dev, double consts[8]);
 

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
 step "bench lines"
 timeout -k 10 300 python3 $R/bench.py > $O/c3_bench.json 2> $O/c3_bench.err || exit 1
+timeout -k 10 300 python3 $R/bench.py --cells 2 --cpu-queries 0 > $O/c3_fullscan_bench.json 2>> $O/c3_bench.err || exit 1
 timeout -k 10 200 python3 $R/bench.py --workload c2 > $O/c2_bench.json 2>> $O/c3_bench.err || exit 1
 timeout -k 10 200 python3 $R/bench.py --workload c5 --cpu-queries 2048 > $O/c5_bench.json 2>> $O/c3_bench.err || exit 1
 timeout -k 10 200 python3 $R/bench.py --workload c4 --cpu-queries 0 > $O/c4_1gpu_bench.json 2>> $O/c3_bench.err || exit 1
@@ -24,6 +25,14 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_sq3 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
+step "small-shard rows (the per-rank shards of N = 2, 4, 8)"
+for n in 8388608 4194304 2097152; do
+  timeout -k 10 200 python3 $R/bench.py --workload 16,1024,$n --cpu-queries 0 > $O/16_1024_${n}_bench.json 2>> $O/c3_bench.err || exit 1
+done
+step "probes"
+timeout -k 10 100 $R/tools/read_probe > $O/read_probe.txt 2>&1 || exit 1
+timeout -k 10 100 $R/tools/atomic_probe > $O/atomic_probe.txt 2>&1 || exit 1
 step "drop-in timing"
 cd $R
 timeout -k 10 300 python3 tools/dropin_timing.py > $O/dropin_timing.txt 2>&1 || exit 1
