@@ -1040,15 +1040,66 @@ __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__rest
     atomicAdd(&counts[c], 1u);
 }
 
-__global__ __launch_bounds__(256) void knn_cells_scatter_kernel(const unsigned *__restrict__ code, long long n,
-                                                                const unsigned *__restrict__ tile_start,
-                                                                unsigned *__restrict__ fill, unsigned *__restrict__ perm)
+// Scatter + layout in one pass (k <= 16): row i, read in row order, goes to the next free position of its
+// cell as an fp16 fragment + norm — what knn_frag_kernel would write there (same arithmetic, same outlier
+// rule), without a second pass that gathers 64-byte rows in cell order (8.8 ms for 2^24 rows, against 1.1).
+// frag / norms / perm arrive pre-filled with the padding values (0, +INF, ~0u); out[] as in knn_frag_kernel.
+__global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
+    const float *__restrict__ R, long long n, int k, const unsigned *__restrict__ code,
+    const unsigned *__restrict__ tile_start, unsigned *__restrict__ fill, const float *__restrict__ center, float sigma,
+    h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ perm, unsigned *__restrict__ out,
+    unsigned *__restrict__ olist, unsigned ocap)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const unsigned c = code[i];
-    perm[(size_t)tile_start[c] * 32 + atomicAdd(&fill[c], 1u)] = (unsigned)i;
+    float vmax = 0.0f, nrm = 0.0f;
+    unsigned bad = 0;
+    if (i < n) {
+        const float *__restrict__ x = R + (size_t)i * k;
+        bool real = true;
+        h8 v[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = half * 8 + j;
+                const float sc = d < k ? (x[d] - center[d]) * sigma : 0.0f;  // fp32 subtract, exact power-of-two scale
+                const _Float16 hval = (_Float16)sc;                          // round to nearest even
+                const float back = (float)hval;
+                real = real && fabsf(back) <= 1.0f;                          // outside the robust box, NaN included
+                vmax = fmaxf(vmax, fabsf(back));
+                nrm = nrm + back * back;                                     // exact products, fp32 sum
+                v[half][j] = hval;
+            }
+        if (!real) {   // out of the filter (zero fragment, +INF norm), into the exact list
+            const unsigned opos = atomicAdd(&out[3], 1u);
+            if (opos < ocap)
+                olist[opos] = (unsigned)i;
+            v[0] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            v[1] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            vmax = 0.0f;
+            nrm = 0.0f;
+        }
+        const unsigned c = code[i];
+        const size_t pos = (size_t)tile_start[c] * 32 + atomicAdd(&fill[c], 1u);
+        frag[(pos >> 5) * 64 + (pos & 31)] = v[0];
+        frag[(pos >> 5) * 64 + 32 + (pos & 31)] = v[1];
+        norms[pos] = real ? nrm : INFINITY;
+        perm[pos] = (unsigned)i;
+    }
+    vmax = wave_max_f(vmax);
+    nrm = wave_max_f(nrm);
+    __shared__ float s_v[4], s_n[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = vmax;
+        s_n[threadIdx.x >> 6] = nrm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        guarded_atomic_max(&out[0], __float_as_uint(fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]))));
+        guarded_atomic_max(&out[1], __float_as_uint(fmaxf(fmaxf(s_n[0], s_n[1]), fmaxf(s_n[2], s_n[3]))));
+    }
+    if (bad)
+        atomicAdd(&out[2], bad);
 }
 
 __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
@@ -1592,9 +1643,12 @@ void knn_filter_free(FilterState &st)
 // dimension does not suit, or the cuts leave the cells badly unbalanced.  samp: the strided host sample
 // of the build (samples x k).  Synchronous.
 static hipError_t cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
-                              long long samples, hipStream_t s, long long *ntiles_out)
+                              long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
+                              unsigned **fill_out)
 {
     *out = nullptr;
+    *code_out = nullptr;
+    *fill_out = nullptr;
     if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
         return hipSuccess;
     int bits = 0;
@@ -1682,6 +1736,8 @@ static hipError_t cells_build(CellIndex **out, int k, long long n, const float *
         keep = (long long)biggest * c->ncells <= 16 * n;
     }
     if (keep) {
+        // the rows are placed (and turned into fragments) by knn_cells_scatter_frag_kernel once the layout buffers
+        // exist: `code` and the zeroed fill counters go back to the caller
         e = hipMemcpyAsync(c->tile_start, hstart.data(), hstart.size() * sizeof(unsigned), hipMemcpyHostToDevice, s);
         if (e == hipSuccess)
             e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
@@ -1689,25 +1745,22 @@ static hipError_t cells_build(CellIndex **out, int k, long long n, const float *
             e = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles * 32 * sizeof(unsigned));
         if (e == hipSuccess)
             e = hipMemsetAsync(c->perm, 0xFF, (size_t)tiles * 32 * sizeof(unsigned), s);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(knn_cells_scatter_kernel, dim3(blocks), dim3(256), 0, s, code, n, c->tile_start, counts,
-                               c->perm);
-            e = hipGetLastError();
-        }
         if (e == hipSuccess)
-            e = hipStreamSynchronize(s);
+            e = hipStreamSynchronize(s);   // hstart is about to go out of scope
     }
-    (void)KNN_DEV_FREE(code);
-    (void)KNN_DEV_FREE(counts);
     if (e == hipErrorOutOfMemory) {   // no room for the sort: the plain layout still works
         (void)hipGetLastError();
         e = hipSuccess;
         keep = false;
     }
     if (e != hipSuccess || !keep) {
+        (void)KNN_DEV_FREE(code);
+        (void)KNN_DEV_FREE(counts);
         cells_free(c);
         return e;
     }
+    *code_out = code;
+    *fill_out = counts;
     *ntiles_out = tiles;
     *out = c;
     return hipSuccess;
@@ -1888,9 +1941,10 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     }
 
     // 1c. cell-sorted layout (k <= 16, resident indexes): ntiles becomes the padded tile count
+    unsigned *cell_code = nullptr, *cell_fill = nullptr;
     if (want_cells && kt == 1) {
-        FTRY(cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles));
-        lap(st.cells ? "cell sort" : "cell sort (not kept)");
+        FTRY(cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles, &cell_code, &cell_fill));
+        lap(st.cells ? "cell codes + counts" : "cell codes (not kept)");
     }
 
     // 2. fragments + norms
@@ -1918,11 +1972,16 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     lap("allocations");
     if (e == hipSuccess) {
         const long long rows_padded = ntiles * 32;
-        if (st.cells)
-            hipLaunchKernelGGL(knn_frag_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s, r,
-                               rows_padded, rows_padded, k, kt, st.center, sigma, 1.0f, INFINITY, (h8 *)st.ref_frags,
-                               st.ref_norms, dout, 0, nullptr, nullptr, st.outliers, ocap, 0u, st.cells->perm);
-        else if (k == 16 && ((uintptr_t)r & 15u) == 0)
+        if (st.cells) {
+            // padding first (zero fragments, +INF norms), then every row to its cell
+            e = hipMemsetAsync(st.ref_frags, 0, (size_t)ntiles * 64 * 16, s);
+            if (e == hipSuccess)
+                e = hipMemsetD32Async((hipDeviceptr_t)st.ref_norms, 0x7F800000, (size_t)rows_padded, s);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r, n, k,
+                                   cell_code, st.cells->tile_start, cell_fill, st.center, sigma, (h8 *)st.ref_frags,
+                                   st.ref_norms, st.cells->perm, dout, st.outliers, ocap);
+        } else if (k == 16 && ((uintptr_t)r & 15u) == 0)
             hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s,
                                (const f4v *)r, n, rows_padded, st.center, sigma, (h8 *)st.ref_frags,
                                st.ref_norms, dout, st.outliers, ocap);
@@ -1937,6 +1996,8 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);  // also keeps `center` alive until the copy is done
     lap("fragment kernel + sync");
+    (void)KNN_DEV_FREE(cell_code);
+    (void)KNN_DEV_FREE(cell_fill);
     (void)KNN_DEV_FREE(dout);
     if (e != hipSuccess) {
         knn_filter_free(st);
