@@ -1317,14 +1317,15 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     }
 }
 
-// Cell-major matching: a block of 4 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
-// low-table entries).  Pass 1 (queries on the lanes, a quarter of the batch per wave): which queries get past
+// Cell-major matching: a block of 8 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
+// low-table entries).  Pass 1 (queries on the lanes, an eighth of the batch per wave): which queries get past
 // the high table alone — about a third for uniform data — compacted into an LDS queue.  Pass 2 (cells on
 // the lanes, the queue dealt round-robin to the waves): the low-table entry of each queued query, 16 loads in
 // flight per wave; survivors are appended to the cell's list under an LDS counter.  cell_counts[c] = queries
 // that could not rule cell c out, lists[c][0..) = their numbers (any order).  No global atomics: per-cell
 // appends with returning atomics ran at 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
-__global__ __launch_bounds__(256) void knn_cells_match_kernel(
+#define CELL_MATCH_WAVES 8
+__global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
     int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
     unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off)
@@ -1351,17 +1352,18 @@ __global__ __launch_bounds__(256) void knn_cells_match_kernel(
     if (threadIdx.x < 64)
         s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    {   // pass 1: this wave's quarter of the batch (m <= 1024: at most 4 x 64 queries)
-        float hv[4], dq[4];
+    {   // pass 1: this wave's share of the batch (m <= 1024: 16 chunks of 64 queries over the waves)
+        constexpr int U = 16 / CELL_MATCH_WAVES;
+        float hv[U], dq[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = (u * 4 + wib) * 64 + lane;
+        for (int u = 0; u < U; ++u) {
+            const int q = (u * CELL_MATCH_WAVES + wib) * 64 + lane;
             hv[u] = q < m ? hrow[q] : INFINITY;
             dq[u] = q < m ? dup[q] : -INFINITY;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = (u * 4 + wib) * 64 + lane;
+        for (int u = 0; u < U; ++u) {
+            const int q = (u * CELL_MATCH_WAVES + wib) * 64 + lane;
             const bool pass = q < m && !(hv[u] > dq[u]);
             const u64 mask = __ballot(pass);
             if (mask != 0ull) {   // wave-uniform
@@ -1383,7 +1385,7 @@ __global__ __launch_bounds__(256) void knn_cells_match_kernel(
     const unsigned npass = s_npass;
     const bool staged = cap <= 128u;
     unsigned short *__restrict__ my = staged ? &s_list[lane][0] : lists + (size_t)cell * cap;
-    for (unsigned e0 = (unsigned)wib * 16u; e0 < npass; e0 += 64u) {
+    for (unsigned e0 = (unsigned)wib * 16u; e0 < npass; e0 += 16u * CELL_MATCH_WAVES) {
         float lo[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -1413,7 +1415,7 @@ __global__ __launch_bounds__(256) void knn_cells_match_kernel(
         }
     }
     if (staged) {
-        for (int j = wib; j < 64; j += 4) {
+        for (int j = wib; j < 64; j += CELL_MATCH_WAVES) {
             const unsigned cj = min(s_cnt[j], cap);
             if ((unsigned)lane * 2u < cj)
                 ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[lane] = ((const unsigned *)&s_list[j][0])[lane];
@@ -2619,7 +2621,7 @@ static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const
                        (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup, w.ctl, w.cells_off,
                        w.counts, w.nlists);
     FTRY(hipGetLastError());
-    hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(256), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
+    hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(64 * CELL_MATCH_WAVES), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
                        g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
     FTRY(hipGetLastError());
     if (timed && w.ev_begin)

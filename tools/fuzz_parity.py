@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the drop-in entry against the CPU oracle: random shapes,
 distributions, paths, shard counts and one-shot strategies.  usage: fuzz_parity.py [cases] [seed]
-(FUZZ_BIG=1: large shapes, 48 sampled queries checked per case)
+(FUZZ_BIG=1: large shapes, 48 sampled queries checked per case; FUZZ_CELLS=1: the cell-pruned scan — shards of
+>= 2^17 rows, k <= 16, `cells` = 1, through the drop-in entry and through a resident index queried twice)
 Exit status 1 on the first mismatch (prints the case so it can be replayed)."""
 import os
 import sys
@@ -91,6 +92,43 @@ def big_case(o, rng, case):
     return True
 
 
+def cells_case(o, rng, case):
+    """The cell-pruned scan: cells forced on, every distribution (incl. ties, clusters, non-finite values), the
+    drop-in entry and a resident index that answers two different batches (the second sees whatever the
+    first left in the workspace: lists, flags, the pinned switch-off word)."""
+    k = int(rng.choice([3, 5, 8, 12, 15, 16]))
+    m = int(rng.choice([1, 7, 33, 100, 257, 1000, 1024, 1300]))
+    n = int(rng.choice([1 << 17, 150001, 262144, 400000, 600000, 1200000]))
+    kind = str(rng.choice(["uniform", "gauss", "offset", "grid", "clusters", "heavy"]))
+    shards = int(rng.choice([0, 0, 0, 2]))
+    R = make_data(rng, kind, n, k)
+    Q = make_data(rng, kind, m, k)
+    Q2 = make_data(rng, str(rng.choice(["uniform", kind])), m, k)
+    if rng.random() < 0.3:
+        Q[: min(m, 8)] = R[rng.integers(0, n, min(m, 8))]
+    if rng.random() < 0.15:
+        R[rng.integers(0, n), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3e38]))
+    if rng.random() < 0.1:
+        Q2[rng.integers(0, m), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, 1e30]))
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards)
+    pkg.set_option("cells", 1)
+    pkg.set_option("shards", shards)
+    pkg.set_option("path", int(rng.choice([0, 2])))
+    want, want2 = o.v0(k, Q, R), o.v0(k, Q2, R)
+    got = pkg.cudaCallback(k, m, n, Q, R)
+    ix = pkg.KnnIndex(k, R)
+    pkg.set_option("path", 0)
+    got_a, got_b, got_c = ix.query(Q), ix.query(Q2), ix.query(Q)
+    st = ix.last_stats()
+    ix.close()
+    for name, g, w in (("callback", got, want), ("index 1st", got_a, want), ("index 2nd", got_b, want2), ("index 3rd", got_c, want)):
+        if not (g == w).all():
+            j = int(np.flatnonzero(g != w)[0])
+            print("MISMATCH", name, desc, "stats", st, "query", j, "got", int(g[j]), "want", int(w[j]), flush=True)
+            return False
+    return True
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
@@ -99,12 +137,13 @@ def main():
     t0 = time.time()
     try:
         for case in range(cases):
-            if not (big_case if os.environ.get("FUZZ_BIG") == "1" else one_case)(o, rng, case):
+            fn = cells_case if os.environ.get("FUZZ_CELLS") == "1" else big_case if os.environ.get("FUZZ_BIG") == "1" else one_case
+            if not fn(o, rng, case):
                 return 1
             if case % 25 == 24:
                 print("%d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
     finally:
-        for name in ("path", "shards", "stream"):
+        for name in ("path", "shards", "stream", "cells"):
             pkg.set_option(name, 0)
     print("all %d cases bit-exact (seed %d)" % (cases, seed))
     return 0
