@@ -70,6 +70,11 @@ def test_option_hooks_reject_unknown_names():
         pkg.set_option("no_such_option", 1)
     with pytest.raises(pkg.KnnError):
         pkg.set_option("path", 99)
+    for v in (1, 2, 0):                                   # cell-sorted layouts: policy / always / never
+        pkg.set_option("cells", v)
+        assert pkg.get_option("cells") == v
+    with pytest.raises(pkg.KnnError):
+        pkg.set_option("cells", 3)
 
 
 def test_product_does_not_link_or_reference_the_oracle():
