@@ -1128,9 +1128,7 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     __shared__ float s_gap[16][CELL_MAX_BINS];
     __shared__ f4v s_nrm[4][CELL_TILES_PER_PASS * 8];
     __shared__ unsigned s_tb[CELL_SEEDS];
-    __shared__ unsigned s_bin[16], s_alt[16];
-    __shared__ float s_altgap[16];
-    __shared__ unsigned s_cells[CELL_SEEDS], s_tiles[CELL_SEEDS + 1];
+    __shared__ unsigned s_tiles[CELL_SEEDS];
     __shared__ float s_red[4];
     const int qi = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1151,66 +1149,84 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
         }
         s_gap[d][b] = v;
     }
-    if (tid < 16) {
-        unsigned b = 0u, alt = 0xFFFFFFFFu;
+    // loads nothing below depends on, issued first: this query's B operand, and (thread 0) what the threshold needs
+    const h8 bq = qfg[(size_t)(qi >> 5) * 64 + (lane >> 5) * 32 + (qi & 31)];  // every column = this query
+    float pre_amax = 0.0f, pre_qnorm = 0.0f, pre_qamax = 0.0f;
+    unsigned pre_qbad = 0u;
+    if (tid == 0) {
+        for (int bq2 = 0; bq2 < qblocks; ++bq2) {  // per-block partials of the query fragment kernel
+            pre_amax = fmaxf(pre_amax, __uint_as_float(qpart[3 * bq2]));
+            pre_qbad |= qpart[3 * bq2 + 2];
+        }
+        pre_qnorm = qnorm[qi];
+        pre_qamax = qamax[qi];
+    }
+    if (wib == 0) {
+        // wave 0, dimensions on the lanes: the query's own bin, and the neighbouring bin nearest to it
+        unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
         float ag = INFINITY;
-        if (tid < g.k && g.nb[tid]) {
-            const int nbins = 1 << g.nb[tid];
-            const float *__restrict__ bnd = bounds + tid * (CELL_MAX_BINS - 1);
-            const float q = Q[(size_t)qi * g.k + tid];
-            b = cell_bin(bnd, nbins, q);
-            if (b > 0u) {
-                alt = b - 1u;
-                ag = q - bnd[b - 1];
+        if (lane < g.k) {
+            nbl = g.nb[lane];
+            shl = g.shift[lane];
+        }
+        if (nbl) {
+            const int nbins = 1 << nbl;
+            const float *__restrict__ bnd = bounds + lane * (CELL_MAX_BINS - 1);
+            const float q = Q[(size_t)qi * g.k + lane];
+            bin = cell_bin(bnd, nbins, q);
+            if (bin > 0u) {
+                alt = bin - 1u;
+                ag = q - bnd[bin - 1];
             }
-            if (b + 1u < (unsigned)nbins && !(bnd[b] - q >= ag)) {
-                alt = b + 1u;
-                ag = bnd[b] - q;
+            if (bin + 1u < (unsigned)nbins && !(bnd[bin] - q >= ag)) {
+                alt = bin + 1u;
+                ag = bnd[bin] - q;
             }
             if (!(ag >= 0.0f))
                 ag = 0.0f;
         }
-        s_bin[tid] = b;
-        s_alt[tid] = alt;
-        s_altgap[tid] = ag;
+        unsigned own = bin << shl;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+            own |= (unsigned)__shfl_xor((int)own, off, KNN_WAVE);
+        own = (unsigned)__shfl((int)own, 0, KNN_WAVE);
+        // the CELL_SEED_DIMS dimensions whose next bin is nearest: arg-min over the lanes, twice
+        int pick[CELL_SEED_DIMS];
+        u64 key = alt != 0xFFFFFFFFu ? ((u64)__float_as_uint(ag) << 32) | (u64)lane : ~0ull;
+#pragma unroll
+        for (int j = 0; j < CELL_SEED_DIMS; ++j) {
+            u64 best = key;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 o = __shfl_xor(best, off, KNN_WAVE);
+                best = o < best ? o : best;
+            }
+            pick[j] = best == ~0ull ? -1 : (int)(best & 0xFFFFFFFFull);
+            if (lane == pick[j])
+                key = ~0ull;
+        }
+        // seed cell c (on lane c): the own cell with the picked dimensions moved to their neighbouring bin
+        unsigned code = own;
+        bool ok = lane < CELL_SEEDS;
+#pragma unroll
+        for (int j = 0; j < CELL_SEED_DIMS; ++j) {
+            const int pj = pick[j] < 0 ? 0 : pick[j];
+            const unsigned pa = (unsigned)__shfl((int)alt, pj, KNN_WAVE), pn = (unsigned)__shfl((int)nbl, pj, KNN_WAVE),
+                           ps = (unsigned)__shfl((int)shl, pj, KNN_WAVE);
+            if ((lane >> j) & 1) {
+                if (pick[j] < 0)
+                    ok = false;
+                else
+                    code = (code & ~(((1u << pn) - 1u) << ps)) | (pa << ps);
+            }
+        }
+        if (lane < CELL_SEEDS) {
+            const unsigned tb = tile_start[code];
+            s_tb[lane] = tb;
+            s_tiles[lane] = ok ? tile_start[code + 1] - tb : 0u;   // tiles of seed cell `lane`
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned own = 0u;
-        for (int d = 0; d < g.k; ++d)
-            own |= s_bin[d] << g.shift[d];
-        int pick[CELL_SEED_DIMS];
-        for (int j = 0; j < CELL_SEED_DIMS; ++j) {   // the dimensions whose next bin is nearest
-            int best = -1;
-            for (int d = 0; d < g.k; ++d) {
-                bool taken = s_alt[d] == 0xFFFFFFFFu;
-                for (int jj = 0; jj < j; ++jj)
-                    taken = taken || pick[jj] == d;
-                if (!taken && (best < 0 || s_altgap[d] < s_altgap[best]))
-                    best = d;
-            }
-            pick[j] = best;
-        }
-        unsigned total = 0u;
-        for (int c = 0; c < CELL_SEEDS; ++c) {
-            unsigned code = own;
-            bool ok = true;
-            for (int j = 0; j < CELL_SEED_DIMS; ++j)
-                if ((c >> j) & 1) {
-                    if (pick[j] < 0)
-                        ok = false;
-                    else
-                        code = (code & ~(((1u << g.nb[pick[j]]) - 1u) << g.shift[pick[j]])) |
-                               (s_alt[pick[j]] << g.shift[pick[j]]);
-                }
-            s_cells[c] = code;
-            s_tiles[c] = total;
-            const unsigned tb = tile_start[code];
-            s_tb[c] = tb;
-            total += ok ? tile_start[code + 1] - tb : 0u;
-        }
-        s_tiles[CELL_SEEDS] = total;
-    }
     // the tables (independent of the seed cells): double sums of the rounded-down gaps, rounded down again
     const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);
     for (int e = tid; e < nl + nh; e += 256) {
@@ -1231,10 +1247,9 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < nlists; i += gridDim.x * 256u)
         counts[i] = 0u;
     // one seed cell per wave, all its tiles in flight at once (like the scan: one round trip)
-    const h8 b = qfg[(size_t)(qi >> 5) * 64 + (lane >> 5) * 32 + (qi & 31)];  // every column = this query
     float um = INFINITY;
     for (int ci = wib; ci < CELL_SEEDS; ci += 4) {
-        const unsigned ntile = s_tiles[ci + 1] - s_tiles[ci], tb = s_tb[ci];
+        const unsigned ntile = s_tiles[ci], tb = s_tb[ci];
         for (unsigned t0 = 0u; t0 < ntile; t0 += CELL_TILES_PER_PASS) {
             const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, ntile - t0);
             h8 ar[CELL_TILES_PER_PASS];
@@ -1264,7 +1279,7 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
                         c[4 * gq + 2] = v[2];
                         c[4 * gq + 3] = v[3];
                     }
-                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
+                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], bq, c, 0, 0, 0);
                     um = min_tree16(d, um);
                 }
         }
@@ -1277,12 +1292,8 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     __syncthreads();
     if (tid == 0) {
         const float u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-        float amax = 0.0f;
-        unsigned qbad = 0u;
-        for (int bq = 0; bq < qblocks; ++bq) {  // per-block partials of the query fragment kernel
-            amax = fmaxf(amax, __uint_as_float(qpart[3 * bq]));
-            qbad |= qpart[3 * bq + 2];
-        }
+        const float amax = pre_amax;
+        const unsigned qbad = pre_qbad;
         if (qi == 0) {
             ctl[KNN_CTL_AMAX] = __float_as_uint(amax);
             ctl[KNN_CTL_QBAD] = qbad;
@@ -1298,9 +1309,9 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
             *cells_off = 1u;   // the strided sample of the full scan will serve the next batches
         }
         if (!bad) {
-            const BoundConsts cst = knn_bound_consts(g.k, kt, sigma, qamax[qi], bmax, nmax);
+            const BoundConsts cst = knn_bound_consts(g.k, kt, sigma, pre_qamax, bmax, nmax);
             double dup = 0.0;
-            t = knn_threshold(cst, u, qnorm[qi], &dup);
+            t = knn_threshold(cst, u, pre_qnorm, &dup);
             if (!(t < INFINITY))
                 bad = true;
             else {
@@ -1385,15 +1396,16 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const unsigned npass = s_npass;
     const bool staged = cap <= 128u;
     unsigned short *__restrict__ my = staged ? &s_list[lane][0] : lists + (size_t)cell * cap;
-    for (unsigned e0 = (unsigned)wib * 16u; e0 < npass; e0 += 16u * CELL_MATCH_WAVES) {
-        float lo[16];
+    constexpr int INFLIGHT = 16;   // low-table loads a wave has outstanding (32: 15 -> 23 us at C3, 22 -> 19 us at 2^21 rows)
+    for (unsigned e0 = (unsigned)wib * INFLIGHT; e0 < npass; e0 += INFLIGHT * CELL_MATCH_WAVES) {
+        float lo[INFLIGHT];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < INFLIGHT; ++u) {
             const unsigned e = min(e0 + (unsigned)u, npass - 1u);
             lo[u] = lo_tab[(size_t)s_q[e] * nl + l];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < INFLIGHT; ++u) {
             const unsigned e = e0 + (unsigned)u;
             if (e < npass) {
                 const float lb = lo[u] + s_hv[e];
