@@ -159,7 +159,7 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "cells"   the MFMA filter's cell-pruned form (k <= 16): the index sorts the shard into 2^B cells (every
  *             dimension cut at sample quantiles), and a batch scores only the cells each query could not
  *             rule out by its distance to the cell's box.  0 = library policy: indexes created with
- *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^21 rows (k = 13 .. 16); never for the
+ *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^20 rows (k = 13 .. 16); never for the
  *             one-shot cudaCallback (one batch does not repay the sort).  1 = every index of >= 2^17 rows,
  *             cudaCallback's shards included; 2 = never.  Read when an index is created; 2 also makes
  *             existing indexes use the full scan.  Results are bit-exact either way

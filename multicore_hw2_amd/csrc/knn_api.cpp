@@ -447,9 +447,9 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     // cell-sorted layout for the pruned scan: indexes the caller keeps (library policy) or on request; the
     // one-shot cudaCallback asks for explicit layouts and answers one batch, which does not repay the sort.
     // Pruning needs enough cells for the dimension: measured on uniform data at m = 1024 (profiles/r02_cells_policy.txt)
-    // the pruned scan wins from 2^19 rows for k <= 12 and from 2^21 rows for k = 13..16; below that the lists
+    // the pruned scan wins from 2^19 rows for k <= 12 and from 2^20 rows for k = 13..16; below that the lists
     // hold most of the batch and the full scan's register-resident loop is the faster way to score them.
-    const long long cells_from = k <= 12 ? (1ll << 19) : (1ll << 21);
+    const long long cells_from = k <= 12 ? (1ll << 19) : (1ll << 20);
     const bool want_cells = k <= 16 && n_local >= (1ll << 17) &&
                             (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));
     if (build_filter < 0) {

@@ -2620,8 +2620,8 @@ static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const
     memcpy(g.nb, c.nb, 16);
     memcpy(g.shift, c.shift, 16);
     unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
-    if (gx * CELL_SCAN_WAVES * 4u > c.ncells)
-        gx = std::max(1u, c.ncells / (CELL_SCAN_WAVES * 4u));
+    if (gx * CELL_SCAN_WAVES > c.ncells)   // (a wave per cell at least; holding the grid to 4 cells per wave left a third
+        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);   //  of the CUs idle at 2^13 cells: 0.049 -> see profiles)
     w.nlists = gx * CELL_SCAN_WAVES;
     w.slice = w.rec_cap / w.nlists;
     w.has_rows = false;

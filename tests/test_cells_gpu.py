@@ -177,12 +177,12 @@ def test_non_finite_queries_take_the_exact_scan_for_their_batch_only(oracle):
 
 
 def test_cells_policy_and_option(oracle):
-    """Library policy: cell-sorted layouts for resident indexes of >= 2^19 rows (k <= 12) or >= 2^21 rows
+    """Library policy: cell-sorted layouts for resident indexes of >= 2^19 rows (k <= 12) or >= 2^20 rows
     (k = 13..16); never for the one-shot drop-in call; `cells` = 2 switches them off, 1 asks for them from 2^17
     rows on."""
     Q16 = oracle.synth(64 * 16, 2).reshape(64, 16)
-    for k, n, cells, expect in ((16, 1 << 21, 0, 4), (16, (1 << 21) - 1, 0, 2), (8, 1 << 19, 0, 4), (8, (1 << 19) - 1, 0, 2),
-                                (16, 1 << 21, 2, 2), (16, 1 << 17, 1, 4), (16, (1 << 17) - 1, 1, 2)):
+    for k, n, cells, expect in ((16, 1 << 20, 0, 4), (16, (1 << 20) - 1, 0, 2), (8, 1 << 19, 0, 4), (8, (1 << 19) - 1, 0, 2),
+                                (16, 1 << 20, 2, 2), (16, 1 << 17, 1, 4), (16, (1 << 17) - 1, 1, 2)):
         Q = np.ascontiguousarray(Q16[:, :k])
         R = oracle.synth(n * k, 3).reshape(n, k)
         pkg.set_option("cells", cells)
@@ -196,7 +196,7 @@ def test_cells_policy_and_option(oracle):
         assert st[0] == expect, (n, cells, st)
     with pytest.raises(pkg.KnnError):
         pkg.set_option("cells", 3)
-    k, n = 16, 1 << 21
+    k, n = 16, 1 << 20
     R = oracle.synth(n * k, 3).reshape(n, k)
     np.testing.assert_array_equal(pkg.cudaCallback(k, 64, n, Q16, R), oracle.v0(k, Q16, R, threads=THREADS))
 

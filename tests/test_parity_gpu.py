@@ -691,9 +691,10 @@ def test_ingest_builds_the_layouts_chunk_by_chunk_under_the_copy(oracle, k, m, n
             np.testing.assert_array_equal(got, want, err_msg=f"ingest={ingest} cells={cells}")
             # the filter ran (NaN / Inf rows are outliers like any other), no device fallback
             assert st[0] == (4 if cells == 0 and k <= 16 else 2), (ingest, cells, st)
-            # (copy-then-build takes its box from the full range, which the far-out rows stretch to 12 MADs: the
-            # five far-away queries then overflow the candidate lists at k = 3 and the exact scan answers them)
-            assert st[2] == 0 or ingest == 1, (ingest, cells, st)
+            # (copy-then-build — which the cell sort uses too — takes its box from the full range, which the far-out
+            # rows stretch to 12 MADs: the five far-away queries may then overflow the candidate lists at k = 3 and
+            # the exact scan answers the batch; the sampled box of the ingest path keeps them inside the lists)
+            assert st[2] == 0 or ingest == 1 or cells == 0, (ingest, cells, st)
             assert 10 <= st[3] <= 4096, st                          # the planted rows are on the exact list
     finally:
         pkg.set_option("ingest", 0)
