@@ -191,7 +191,8 @@ def main():
     # Every step is still a complete pass (init, scan, [reduce], unpack) inside the timed region.
     # (the library chains the scans of different slots for shards of >= 16M rows: two in flight are enough then)
     long_scan = n_local >= (1 << 24)
-    cells_expected = k <= 16 and n_local >= (1 << 17) and pkg.get_option("cells") != 2 and pkg.get_option("path") in (0, 2)
+    cells_from = {0: (1 << 19) if k <= 12 else (1 << 20), 1: 1 << 17}.get(pkg.get_option("cells"))   # the library's policy
+    cells_expected = k <= 16 and cells_from is not None and n_local >= cells_from and pkg.get_option("path") in (0, 2)
     inflight = args.inflight if args.inflight > 0 else (2 if long_scan and not cells_expected else 3)
     nbuf = 1 if args.serial else max(1, min(4, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.

@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
 // flight per wave; survivors are appended to the cell's list under an LDS counter.  cell_counts[c] = queries
 // that could not rule cell c out, lists[c][0..) = their numbers (any order).  No global atomics: per-cell
 // appends with returning atomics ran at 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
-#define CELL_MATCH_WAVES 8
+template <int CELL_MATCH_WAVES>   // 8, or 16 for shards of few cells (one block per 64 cells: 128 blocks at 2^13 cells)
 __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
     int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
@@ -2633,8 +2633,12 @@ static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const
                        (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup, w.ctl, w.cells_off,
                        w.counts, w.nlists);
     FTRY(hipGetLastError());
-    hipLaunchKernelGGL(knn_cells_match_kernel, dim3(c.ncells / 64u), dim3(64 * CELL_MATCH_WAVES), 0, s, w.lo_tab, w.hi_tab, w.dup, m, m_padded,
-                       g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
+    if (c.ncells <= 16384u)
+        hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
+                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
+    else
+        hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
+                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
     FTRY(hipGetLastError());
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
