@@ -78,6 +78,6 @@ for name in ["uniform", "gaussian", "heavy_tail", "clusters64", "low_rank", "off
     sel = np.random.default_rng(0).choice(m, 16, replace=False)
     Q, R = q_d.cpu().numpy(), r_d.cpu().numpy()
     ok = (out.cpu().numpy()[sel] == o.v0(k, Q[sel], R)).all()
-    print(f"{name:12s} {dt * 1e3:8.3f} ms/step  path={'filter' if st[0] == 2 else 'exact'}  records={st[1]:9d}  "
+    print(f"{name:12s} {dt * 1e3:8.3f} ms/step  path={ {1: 'exact', 2: 'filter', 3: 'grid', 4: 'cell-pruned filter'}.get(st[0], st[0])}  records={st[1]:9d}  "
           f"device fallback to exact scan={bool(st[2])}  bit-exact on 16 sampled queries: {ok}", flush=True)
     ix.close()
