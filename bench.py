@@ -338,7 +338,7 @@ def main():
         # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
         # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json).  Quoted only when the profile
         # was taken on the kernel source that is running now (the profile records the sha256 of
-        # knn_filter.hip + knn_exact.hip); a stale profile is named, not used.
+        # the filter / cells / exact sources); a stale profile is named, not used.
         pmc_path = os.path.join(ROOT, "profiles", "r02_c3_pmc_traffic.json")
         if wname == "C3" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -432,7 +432,7 @@ def main():
 def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
-    for name in ("knn_filter.hip", "knn_exact.hip"):
+    for name in ("knn_filter.hip", "knn_cells.hip", "knn_filter_dev.h", "knn_exact.hip"):
         with open(os.path.join(ROOT, "multicore_hw2_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -128,6 +128,25 @@ struct FilterState {
     bool scan_recorded = false;
 };
 
+// ---- cell-pruned form of the filter (knn_cells.hip) -----------------------------------------
+#define KNN_CELL_BATCH 1024   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS
+#ifdef __cplusplus
+#include <vector>
+// Cell codes + counts of the shard (cuts from the strided host sample of the build).  *out stays null when the
+// shard does not suit; else *code_out / *fill_out (device; the caller frees them) feed knn_cells_place_rows.
+hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r_dev, const std::vector<float> &samp,
+                           long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
+                           unsigned **fill_out);
+#endif
+hipError_t knn_cells_place_rows(FilterState &st, const float *r_dev, const unsigned *code, unsigned *fill, unsigned *out,
+                                unsigned ocap, hipStream_t s);
+void knn_cells_free(CellIndex *&c);
+void knn_cells_workspace_free(FilterWorkspace &w);
+// One batch of <= KNN_CELL_BATCH queries already prepared by the filter's query-fragment kernel: seed, thresholds,
+// match, scan (records in w, as the full scan leaves them).  Asynchronous.
+hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q_dev, int num_cu, bool timed,
+                           hipStream_t s);
+
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
 // (and returns hipSuccess) when the data rules the filter out.
 // pooled device memory for the CURRENT device (knn_api.cpp); knn_dev_free waits for the device first

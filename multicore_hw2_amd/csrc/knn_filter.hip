@@ -28,68 +28,7 @@
 // exact arithmetic by knn_rerank_kernel, which folds them into the packed keys.  If anything
 // rules the filter out (non-finite data, fp16 range, record overflow) a device-side flag makes
 // the gated exact kernels scan everything instead: results are bit-exact either way.
-#include "knn_common.h"
-
-// Device buffers of an index come from the library's pool (knn_api.cpp): a one-shot cudaCallback that
-// builds the filter layouts makes ~20 allocations, and hipMalloc + hipFree (a device-wide sync and
-// ~0.2 ms each) cost more than its kernels.  Stand-alone tools that include this file define KNN_NO_POOL.
-#ifdef KNN_NO_POOL
-#define KNN_DEV_ALLOC(p, bytes) hipMalloc(p, bytes)
-#define KNN_DEV_FREE(p) hipFree(p)
-#else
-#define KNN_DEV_ALLOC(p, bytes) knn_dev_alloc((void **)(p), bytes)
-#define KNN_DEV_FREE(p) knn_dev_free((void *)(p))
-#endif
-
-#include <math.h>
-#include <stdio.h>
-#include <string.h>
-#include <stdlib.h>
-#include <algorithm>
-#include <chrono>
-#include <vector>
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f4v __attribute__((ext_vector_type(4)));
-
-#define FILTER_BLOCK 256
-
-// order-preserving map float -> uint (for atomic min/max over signed floats)
-__device__ __forceinline__ unsigned f2ord(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-static inline float ord2f_host(unsigned o)
-{
-    const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
-// Monotone accumulators on a few hot words: a plain (possibly stale) read first.  The target only
-// moves one way, so a stale value can cost a spare atomic, never lose an update; without the
-// guard half a million atomics on one word serialise at ~88/us (6 ms on a 2^24-row shard).
-__device__ __forceinline__ void guarded_atomic_max(unsigned *p, unsigned v)
-{
-    if (v > __builtin_nontemporal_load(p))
-        atomicMax(p, v);
-}
-__device__ __forceinline__ void guarded_atomic_min(unsigned *p, unsigned v)
-{
-    if (v < __builtin_nontemporal_load(p))
-        atomicMin(p, v);
-}
-
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v = fmaxf(v, __shfl_xor(v, off, KNN_WAVE));
-    return v;
-}
+#include "knn_filter_dev.h"
 
 // ------------------------------------------------------------------------------------------
 // Per-dimension min / max of the reference coordinates (+ count of non-finite values).
@@ -407,57 +346,7 @@ __global__ __launch_bounds__(256) void knn_frag16_kernel(const f4v *__restrict__
         atomicAdd(&out[2], bad);
 }
 
-// ------------------------------------------------------------------------------------------
-// Per-query pruning threshold (double arithmetic; see the header comment for the derivation).
-// ------------------------------------------------------------------------------------------
-struct BoundConsts {
-    double eta, eta2, rho, g2, tau, gam, sigma2;
-};
-
-__host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double sigma, double amax,
-                                                        double bmax, double nmax)
-{
-    const double u = 0x1p-24;
-    const double theta = 0x1p-11 + 0x1p-23;          // fp32 centring + fp16 rounding, relative
-    const double thp = theta / (1.0 - theta);
-    const double nu0 = 0x1p-14 * 1.001;               // fp16 subnormal rounding or flush-to-zero
-    const double kp = 16.0 * kt;
-    const double emax = thp * (amax + bmax) + 2.0 * nu0;
-    BoundConsts c;
-    c.eta2 = k * emax * emax;
-    c.eta = sqrt(c.eta2);
-    const double omega = kt * 0x1p-18;                // MFMA internal accumulation, per chained K-step (assumed bound)
-    c.gam = (kp + 2.0) * u;
-    const double mmax = kp * amax * amax;
-    c.rho = (omega + 2.0 * c.gam) * 2.0 * (nmax + mmax) + kp * 0x1p-27;
-    c.g2 = (k + 3.0) * u * 1.0001;
-    c.tau = k * 0x1p-125;
-    c.sigma2 = sigma * sigma;
-    return c;
-}
-
-// Threshold implied by a filter score `u` = S of SOME real reference j0 of the shard (the minimum
-// over the sample pass), for a query whose fp16 row has computed squared norm mq:
-//   D~_j0 <= u + mq(1+g) + rho;  (sqrt(D_j0) - eta)^2 <= D~_j0 + 2 eta^2  =>  D_j0 <= D0up
-//   the winner j* has E_j* <= E_j0 (v0 values), hence D_j* <= D0up (1+g2)^2 + sigma^2 tau =: Dup
-//   and its own score obeys S_j* <= Dup + 2 eta sqrt(Dup) + eta^2 + rho - mq(1-g).
-// Monotone in u, so any upper bound of the true sample minimum is safe too.
-__host__ __device__ inline float knn_threshold(const BoundConsts &c, double u, double mq, double *dup_out = nullptr)
-{
-    double dt = u + mq * (1.0 + 1.01 * c.gam) + c.rho;
-    if (dt < 0.0)
-        dt = 0.0;
-    const double sq0 = c.eta + sqrt(dt + 2.0 * c.eta2);
-    const double dup = sq0 * sq0 * (1.0 + c.g2) * (1.0 + c.g2) + c.sigma2 * c.tau;
-    if (dup_out)
-        *dup_out = dup;  // real scaled squared distance no candidate for the answer can exceed (cell pruning)
-    double thr = dup + 2.0 * c.eta * sqrt(dup) + c.eta2 + c.rho - mq * (1.0 - c.gam);
-    thr += fabs(thr) * 1e-6 + 1e-30;                  // slack for the double arithmetic above
-    float tf = (float)thr;
-    if ((double)tf < thr)
-        tf = nextafterf(tf, INFINITY);
-    return nextafterf(tf, INFINITY);                  // the kernel tests S < thr (strict)
-}
+// (BoundConsts, knn_bound_consts, knn_threshold: knn_filter_dev.h)
 
 // umin: per-block minima of the sample pass, [nblocks][m_padded].  Block = 32 queries x 32
 // parts: each part folds every 32nd sample block (coalesced over the 32 queries, all its loads
@@ -562,10 +451,6 @@ __device__ __forceinline__ void load_ref_tile(const h8 *__restrict__ rf, const f
     }
 }
 
-__device__ __forceinline__ float min3f(float a, float b, float c)
-{
-    return __builtin_fminf(__builtin_fminf(a, b), c);
-}
 
 // One (reference tile, query tile) step, software-pipelined by one tile: the MFMA of the NEXT
 // query tile is issued first (into the other accumulator buffer), then the min3 tree of the
@@ -982,596 +867,6 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_sample_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Cell-pruned scan (k <= 16, resident index).  Scoring every (query, reference) pair costs ~50 issue
-// cycles per 32x32 tile pair whatever the schedule, so the only way under it is not to
-// score most pairs.  The index sorts the rows into 2^B cells — every dimension cut into 2^nb[d] bins at
-// sample quantiles, cell = the tuple of bin numbers — and lays the fp16 fragments out cell by cell (each
-// cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch:
-//   seed    : every query scores its own cell and the 3 cells next to it (MFMA, same scores as the scan):
-//             the minimum is a score of a real reference, which is all knn_threshold needs.  The same
-//             kernel tabulates the query's squared gap to every bin of every dimension.
-//   thr     : threshold thr_q for the scores, and Dup_q = the largest real (scaled) squared distance any
-//             candidate for the answer can have (see knn_threshold).
-//   match   : a row of cell c differs from the query by at least gap_d(bin_d(c)) in every dimension, so
-//             LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of the cell, and LB > Dup_q rules the whole
-//             cell out (ties included: a row that ties with the answer obeys the Dup bound too).  LB is separable:
-//             lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  Cell-major, no atomics: a wave owns 64
-//             consecutive cells and appends the surviving queries to its lanes' lists.
-//   scan    : a wave walks its cells; per cell it gathers the listed queries' B operands from LDS (32 per
-//             block of columns) and runs the usual MFMA + min3 tree + threshold test over the cell's tiles.
-// Uniform data in 16 dimensions, n = 2^24: ~2400 of 65536 cells survive per query, ~36 queries per cell —
-// 1/20 of the MFMA work of the full scan, and the fragments are read once: the scan is HBM-bound.
-// Anything that does not fit (a list overflows, a query's seed cells are empty) raises the FALLBACK
-// flag for this batch — the gated exact scan answers it — and the host-visible `cells_off` word, after
-// which the index goes back to the full scan with the strided sample.
-// ------------------------------------------------------------------------------------------
-#define CELL_MAX_BINS 16
-#define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts
-#define CELL_SEEDS (1 << CELL_SEED_DIMS)
-#define CELL_TILES_PER_PASS 9                 // reference tiles a wave holds in registers at a time (one more costs the sixth wave per SIMD)
-
-struct CellGeom {
-    int k, bits, sa;                 // dimensions, total bits, bits of the low table
-    unsigned char nb[16], shift[16]; // bits of dimension d (0 = not cut), position of its bin number in the cell code
-};
-
-__device__ __forceinline__ unsigned cell_bin(const float *__restrict__ bnd, int nbins, float x)
-{
-    unsigned b = 0u;
-    for (int j = 0; j < nbins - 1; ++j)   // ascending cuts: bin b <=> bnd[b-1] <= x < bnd[b]; NaN -> bin 0
-        b += x >= bnd[j] ? 1u : 0u;
-    return b;
-}
-
-__global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__restrict__ R, long long n, CellGeom g,
-                                                             const float *__restrict__ bounds,
-                                                             unsigned *__restrict__ code, unsigned *__restrict__ counts)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const float *__restrict__ x = R + (size_t)i * g.k;
-    unsigned c = 0u;
-    for (int d = 0; d < g.k; ++d)
-        if (g.nb[d])
-            c |= cell_bin(bounds + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], x[d]) << g.shift[d];
-    code[i] = c;
-    atomicAdd(&counts[c], 1u);
-}
-
-// Scatter + layout in one pass (k <= 16): row i, read in row order, goes to the next free position of its
-// cell as an fp16 fragment + norm — what knn_frag_kernel would write there (same arithmetic, same outlier
-// rule), without a second pass that gathers 64-byte rows in cell order (8.8 ms for 2^24 rows, against 1.1).
-// frag / norms / perm arrive pre-filled with the padding values (0, +INF, ~0u); out[] as in knn_frag_kernel.
-__global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
-    const float *__restrict__ R, long long n, int k, const unsigned *__restrict__ code,
-    const unsigned *__restrict__ tile_start, unsigned *__restrict__ fill, const float *__restrict__ center, float sigma,
-    h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ perm, unsigned *__restrict__ out,
-    unsigned *__restrict__ olist, unsigned ocap)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    float vmax = 0.0f, nrm = 0.0f;
-    unsigned bad = 0;
-    if (i < n) {
-        const float *__restrict__ x = R + (size_t)i * k;
-        bool real = true;
-        h8 v[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = half * 8 + j;
-                const float sc = d < k ? (x[d] - center[d]) * sigma : 0.0f;  // fp32 subtract, exact power-of-two scale
-                const _Float16 hval = (_Float16)sc;                          // round to nearest even
-                const float back = (float)hval;
-                real = real && fabsf(back) <= 1.0f;                          // outside the robust box, NaN included
-                vmax = fmaxf(vmax, fabsf(back));
-                nrm = nrm + back * back;                                     // exact products, fp32 sum
-                v[half][j] = hval;
-            }
-        if (!real) {   // out of the filter (zero fragment, +INF norm), into the exact list
-            const unsigned opos = atomicAdd(&out[3], 1u);
-            if (opos < ocap)
-                olist[opos] = (unsigned)i;
-            v[0] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-            v[1] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-            vmax = 0.0f;
-            nrm = 0.0f;
-        }
-        const unsigned c = code[i];
-        const size_t pos = (size_t)tile_start[c] * 32 + atomicAdd(&fill[c], 1u);
-        frag[(pos >> 5) * 64 + (pos & 31)] = v[0];
-        frag[(pos >> 5) * 64 + 32 + (pos & 31)] = v[1];
-        norms[pos] = real ? nrm : INFINITY;
-        perm[pos] = (unsigned)i;
-    }
-    vmax = wave_max_f(vmax);
-    nrm = wave_max_f(nrm);
-    __shared__ float s_v[4], s_n[4];
-    if ((threadIdx.x & 63) == 0) {
-        s_v[threadIdx.x >> 6] = vmax;
-        s_n[threadIdx.x >> 6] = nrm;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        guarded_atomic_max(&out[0], __float_as_uint(fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]))));
-        guarded_atomic_max(&out[1], __float_as_uint(fmaxf(fmaxf(s_n[0], s_n[1]), fmaxf(s_n[2], s_n[3]))));
-    }
-    if (bad)
-        atomicAdd(&out[2], bad);
-}
-
-__device__ __forceinline__ float min_tree16(const f16v &x, float seed)
-{
-    const float m0 = min3f(x[0], x[1], x[2]);
-    const float m1 = min3f(x[3], x[4], x[5]);
-    const float m2 = min3f(x[6], x[7], x[8]);
-    const float m3 = min3f(x[9], x[10], x[11]);
-    const float m4 = min3f(x[12], x[13], x[14]);
-    const float m5 = min3f(m0, m1, m2);
-    const float m6 = min3f(m3, m4, x[15]);
-    return min3f(m5, m6, seed);
-}
-
-// One block per query.  umin[q] = minimum score over the seed cells; lo_tab[q][e] / hi_tab[e][q] = the
-// separable halves of the cell lower bound (scaled units, rounded down).
-__global__ __launch_bounds__(256) void knn_cells_seed_kernel(
-    const float *__restrict__ Q, int m, CellGeom g, const float *__restrict__ bounds, double sigma2,
-    const unsigned *__restrict__ tile_start, const h8 *__restrict__ rf, const float *__restrict__ rn,
-    const h8 *__restrict__ qfg, float *__restrict__ lo_tab, float *__restrict__ hi_tab, int m_padded,
-    // thresholds (what knn_thr_kernel does for the full scan, here per block = per query)
-    const float *__restrict__ qnorm, const float *__restrict__ qamax, const unsigned *__restrict__ qpart, int qblocks,
-    int kt, float sigma, float bmax, float nmax, float amax_limit, float *__restrict__ thr, float *__restrict__ dup_out,
-    unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off, unsigned *__restrict__ counts, unsigned nlists)
-{
-    __shared__ float s_gap[16][CELL_MAX_BINS];
-    __shared__ f4v s_nrm[4][CELL_TILES_PER_PASS * 8];
-    __shared__ unsigned s_tb[CELL_SEEDS];
-    __shared__ unsigned s_tiles[CELL_SEEDS];
-    __shared__ float s_red[4];
-    const int qi = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {
-        const int d = tid >> 4, b = tid & 15;
-        float v = 0.0f;
-        if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
-            const int nbins = 1 << g.nb[d];
-            const float *__restrict__ bnd = bounds + d * (CELL_MAX_BINS - 1);
-            const double q = (double)Q[(size_t)qi * g.k + d];
-            double gap = 0.0;
-            if (b > 0 && (double)bnd[b - 1] > q)
-                gap = (double)bnd[b - 1] - q;        // rows of the bin have x >= bnd[b-1] > q
-            if (b < nbins - 1 && q > (double)bnd[b])
-                gap = q - (double)bnd[b];            // rows of the bin have x < bnd[b] < q
-            v = __double2float_rd(gap * gap * sigma2);
-        }
-        s_gap[d][b] = v;
-    }
-    // loads nothing below depends on, issued first: this query's B operand, and (thread 0) what the threshold needs
-    const h8 bq = qfg[(size_t)(qi >> 5) * 64 + (lane >> 5) * 32 + (qi & 31)];  // every column = this query
-    float pre_amax = 0.0f, pre_qnorm = 0.0f, pre_qamax = 0.0f;
-    unsigned pre_qbad = 0u;
-    if (tid == 0) {
-        for (int bq2 = 0; bq2 < qblocks; ++bq2) {  // per-block partials of the query fragment kernel
-            pre_amax = fmaxf(pre_amax, __uint_as_float(qpart[3 * bq2]));
-            pre_qbad |= qpart[3 * bq2 + 2];
-        }
-        pre_qnorm = qnorm[qi];
-        pre_qamax = qamax[qi];
-    }
-    if (wib == 0) {
-        // wave 0, dimensions on the lanes: the query's own bin, and the neighbouring bin nearest to it
-        unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
-        float ag = INFINITY;
-        if (lane < g.k) {
-            nbl = g.nb[lane];
-            shl = g.shift[lane];
-        }
-        if (nbl) {
-            const int nbins = 1 << nbl;
-            const float *__restrict__ bnd = bounds + lane * (CELL_MAX_BINS - 1);
-            const float q = Q[(size_t)qi * g.k + lane];
-            bin = cell_bin(bnd, nbins, q);
-            if (bin > 0u) {
-                alt = bin - 1u;
-                ag = q - bnd[bin - 1];
-            }
-            if (bin + 1u < (unsigned)nbins && !(bnd[bin] - q >= ag)) {
-                alt = bin + 1u;
-                ag = bnd[bin] - q;
-            }
-            if (!(ag >= 0.0f))
-                ag = 0.0f;
-        }
-        unsigned own = bin << shl;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-            own |= (unsigned)__shfl_xor((int)own, off, KNN_WAVE);
-        own = (unsigned)__shfl((int)own, 0, KNN_WAVE);
-        // the CELL_SEED_DIMS dimensions whose next bin is nearest: arg-min over the lanes, twice
-        int pick[CELL_SEED_DIMS];
-        u64 key = alt != 0xFFFFFFFFu ? ((u64)__float_as_uint(ag) << 32) | (u64)lane : ~0ull;
-#pragma unroll
-        for (int j = 0; j < CELL_SEED_DIMS; ++j) {
-            u64 best = key;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const u64 o = __shfl_xor(best, off, KNN_WAVE);
-                best = o < best ? o : best;
-            }
-            pick[j] = best == ~0ull ? -1 : (int)(best & 0xFFFFFFFFull);
-            if (lane == pick[j])
-                key = ~0ull;
-        }
-        // seed cell c (on lane c): the own cell with the picked dimensions moved to their neighbouring bin
-        unsigned code = own;
-        bool ok = lane < CELL_SEEDS;
-#pragma unroll
-        for (int j = 0; j < CELL_SEED_DIMS; ++j) {
-            const int pj = pick[j] < 0 ? 0 : pick[j];
-            const unsigned pa = (unsigned)__shfl((int)alt, pj, KNN_WAVE), pn = (unsigned)__shfl((int)nbl, pj, KNN_WAVE),
-                           ps = (unsigned)__shfl((int)shl, pj, KNN_WAVE);
-            if ((lane >> j) & 1) {
-                if (pick[j] < 0)
-                    ok = false;
-                else
-                    code = (code & ~(((1u << pn) - 1u) << ps)) | (pa << ps);
-            }
-        }
-        if (lane < CELL_SEEDS) {
-            const unsigned tb = tile_start[code];
-            s_tb[lane] = tb;
-            s_tiles[lane] = ok ? tile_start[code + 1] - tb : 0u;   // tiles of seed cell `lane`
-        }
-    }
-    __syncthreads();
-    // the tables (independent of the seed cells): double sums of the rounded-down gaps, rounded down again
-    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);
-    for (int e = tid; e < nl + nh; e += 256) {
-        const bool low = e < nl;
-        const unsigned code = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
-        double sum = 0.0;
-        for (int d = 0; d < g.k; ++d)
-            if (g.nb[d] && ((int)g.shift[d] < g.sa) == low)
-                sum += (double)s_gap[d][(code >> g.shift[d]) & ((1u << g.nb[d]) - 1u)];
-        const float v = __double2float_rd(sum);
-        if (low)
-            lo_tab[(size_t)qi * nl + e] = v;
-        else
-            hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
-    }
-    __syncthreads();
-    // housekeeping folded in here to save a launch: zero the record counters of the scan
-    for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < nlists; i += gridDim.x * 256u)
-        counts[i] = 0u;
-    // one seed cell per wave, all its tiles in flight at once (like the scan: one round trip)
-    float um = INFINITY;
-    for (int ci = wib; ci < CELL_SEEDS; ci += 4) {
-        const unsigned ntile = s_tiles[ci], tb = s_tb[ci];
-        for (unsigned t0 = 0u; t0 < ntile; t0 += CELL_TILES_PER_PASS) {
-            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, ntile - t0);
-            h8 ar[CELL_TILES_PER_PASS];
-#pragma unroll
-            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                if (p < nt)
-                    ar[p] = rf[(size_t)(tb + t0 + (unsigned)p) * 64 + lane];
-            const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)(tb + t0) * 8;
-            const f4v n0 = lane < nt * 8 ? rn4[lane] : (f4v){0.f, 0.f, 0.f, 0.f};
-            const f4v n1 = 64 + lane < nt * 8 ? rn4[64 + lane] : (f4v){0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_wave_barrier();
-            s_nrm[wib][lane] = n0;
-            if (lane < CELL_TILES_PER_PASS * 8 - 64)
-                s_nrm[wib][64 + lane] = n1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                if (p < nt) {
-                    f16v c;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const f4v v = s_nrm[wib][p * 8 + 2 * gq + (lane >> 5)];
-                        c[4 * gq + 0] = v[0];
-                        c[4 * gq + 1] = v[1];
-                        c[4 * gq + 2] = v[2];
-                        c[4 * gq + 3] = v[3];
-                    }
-                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], bq, c, 0, 0, 0);
-                    um = min_tree16(d, um);
-                }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
-    if (lane == 0)
-        s_red[wib] = um;
-    __syncthreads();
-    if (tid == 0) {
-        const float u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-        const float amax = pre_amax;
-        const unsigned qbad = pre_qbad;
-        if (qi == 0) {
-            ctl[KNN_CTL_AMAX] = __float_as_uint(amax);
-            ctl[KNN_CTL_QBAD] = qbad;
-            for (int i = m; i < m_padded; ++i) {   // padding queries never pass
-                thr[i] = -INFINITY;
-                dup_out[i] = -INFINITY;
-            }
-        }
-        bool bad = qbad != 0u || !(amax <= amax_limit);
-        float t = -INFINITY, dupf = -INFINITY;
-        if (!bad && !(u < INFINITY)) {
-            bad = true;        // the seed cells held no row of the filter: cannot bound
-            *cells_off = 1u;   // the strided sample of the full scan will serve the next batches
-        }
-        if (!bad) {
-            const BoundConsts cst = knn_bound_consts(g.k, kt, sigma, pre_qamax, bmax, nmax);
-            double dup = 0.0;
-            t = knn_threshold(cst, u, pre_qnorm, &dup);
-            if (!(t < INFINITY))
-                bad = true;
-            else {
-                dup *= 1.0 + 1e-6;
-                dupf = (float)dup;
-                if ((double)dupf < dup)
-                    dupf = nextafterf(dupf, INFINITY);
-            }
-        }
-        thr[qi] = bad ? -INFINITY : t;
-        dup_out[qi] = bad ? -INFINITY : dupf;
-        if (bad)
-            ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
-    }
-}
-
-// Cell-major matching: a block of 8 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
-// low-table entries).  Pass 1 (queries on the lanes, an eighth of the batch per wave): which queries get past
-// the high table alone — about a third for uniform data — compacted into an LDS queue.  Pass 2 (cells on
-// the lanes, the queue dealt round-robin to the waves): the low-table entry of each queued query, 16 loads in
-// flight per wave; survivors are appended to the cell's list under an LDS counter.  cell_counts[c] = queries
-// that could not rule cell c out, lists[c][0..) = their numbers (any order).  No global atomics: per-cell
-// appends with returning atomics ran at 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
-template <int CELL_MATCH_WAVES>   // 8, or 16 for shards of few cells (one block per 64 cells: 128 blocks at 2^13 cells)
-__global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
-    const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
-    int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
-    unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off)
-{
-    __shared__ unsigned short s_q[1024];
-    __shared__ float s_hv[1024], s_dq[1024];
-    __shared__ unsigned s_npass, s_cnt[64];
-    // lists of up to 128 entries are put together in LDS (row stride 65 dwords: lanes appending at the same
-    // depth hit different banks) and written out as whole 256-byte rows; longer ones (few, large cells) go
-    // straight to memory
-    __shared__ unsigned short s_list[64][130];
-    if (ctl[KNN_CTL_FALLBACK] != 0u)
-        return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned c0 = blockIdx.x * 64u;
-    const unsigned cell = c0 + (unsigned)lane;
-    const int nl = 1 << g.sa;
-    const unsigned h = c0 >> g.sa;                      // block-uniform: nl >= 64
-    const unsigned l = cell & (unsigned)(nl - 1);
-    const float *__restrict__ hrow = hi_tab + (size_t)h * m_padded;
-    if (threadIdx.x == 0)
-        s_npass = 0u;
-    if (threadIdx.x < 64)
-        s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    {   // pass 1: this wave's share of the batch (m <= 1024: 16 chunks of 64 queries over the waves)
-        constexpr int U = 16 / CELL_MATCH_WAVES;
-        float hv[U], dq[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = (u * CELL_MATCH_WAVES + wib) * 64 + lane;
-            hv[u] = q < m ? hrow[q] : INFINITY;
-            dq[u] = q < m ? dup[q] : -INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = (u * CELL_MATCH_WAVES + wib) * 64 + lane;
-            const bool pass = q < m && !(hv[u] > dq[u]);
-            const u64 mask = __ballot(pass);
-            if (mask != 0ull) {   // wave-uniform
-                unsigned base = 0u;
-                if (lane == 0)
-                    base = atomicAdd(&s_npass, (unsigned)__popcll(mask));
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if (pass) {
-                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    s_q[pos] = (unsigned short)q;
-                    s_hv[pos] = hv[u];
-                    s_dq[pos] = dq[u];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned npass = s_npass;
-    const bool staged = cap <= 128u;
-    unsigned short *__restrict__ my = staged ? &s_list[lane][0] : lists + (size_t)cell * cap;
-    constexpr int INFLIGHT = 16;   // low-table loads a wave has outstanding (32: 15 -> 23 us at C3, 22 -> 19 us at 2^21 rows)
-    for (unsigned e0 = (unsigned)wib * INFLIGHT; e0 < npass; e0 += INFLIGHT * CELL_MATCH_WAVES) {
-        float lo[INFLIGHT];
-#pragma unroll
-        for (int u = 0; u < INFLIGHT; ++u) {
-            const unsigned e = min(e0 + (unsigned)u, npass - 1u);
-            lo[u] = lo_tab[(size_t)s_q[e] * nl + l];
-        }
-#pragma unroll
-        for (int u = 0; u < INFLIGHT; ++u) {
-            const unsigned e = e0 + (unsigned)u;
-            if (e < npass) {
-                const float lb = lo[u] + s_hv[e];
-                if (!(lb > s_dq[e])) {
-                    const unsigned pos = atomicAdd(&s_cnt[lane], 1u);
-                    if (pos < cap)
-                        my[pos] = s_q[e];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (wib == 0) {
-        const unsigned cnt = s_cnt[lane];
-        cell_counts[cell] = cnt;
-        if (cnt > cap) {
-            ctl[KNN_CTL_FALLBACK] = 1u;  // a list is cut short: the gated exact scan answers this batch
-            *cells_off = 1u;
-        }
-    }
-    if (staged) {
-        for (int j = wib; j < 64; j += CELL_MATCH_WAVES) {
-            const unsigned cj = min(s_cnt[j], cap);
-            if ((unsigned)lane * 2u < cj)
-                ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[lane] = ((const unsigned *)&s_list[j][0])[lane];
-        }
-    }
-}
-
-// The scan.  A block's waves share the batch's B operands and thresholds in LDS; wave w walks cells
-// [ncells w / W, ncells (w+1) / W).  Only ~4 % of the full scan's MFMA work is left (25 listed queries per
-// cell at C3), so what bounds the kernel is getting the fragments out of HBM: per cell a wave issues every
-// load it needs at once (tiles, norms, list: one round trip), and the kernel is written lean (~80 VGPRs, 12
-// waves per block) so that 5-6 waves per SIMD each have a cell in flight — ~50 MB outstanding chip-wide.
-// (Measured alternatives, C3, kernel alone: 4-wave blocks without any prefetch 0.151 ms; the next cell
-// prefetched into a second register set, 162 VGPRs / 3 waves per SIMD 0.145; that plus the C tile read once per
-// tile for up to 4 blocks of queries, 212 VGPRs / 2 waves per SIMD 0.171 — more registers per wave bought less
-// than they cost in waves.)
-#define CELL_SCAN_WAVES 12
-
-// (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512 — at 81, with ten
-// tiles per pass, the second block of a CU waited for the first to finish and the kernel took two rounds)
-__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel(
-    const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ tile_start, unsigned ncells,
-    const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m_padded,
-    const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
-    u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
-{
-    extern __shared__ unsigned char s_dyn[];
-    h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
-    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
-    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
-    if (ctl[KNN_CTL_FALLBACK] != 0u)
-        return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int i = threadIdx.x; i < m_padded * 2; i += 64 * CELL_SCAN_WAVES)
-        s_qf[i] = qfg[i];
-    for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
-        s_thr[i] = thrg[i];
-    __syncthreads();
-    f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
-
-    const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
-    u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
-    unsigned cnt = 0u;
-    const int col = lane & 31, half = lane >> 5;
-    const bool interleave = true;   // wave w takes cells w, w + W, ...: all waves read one moving window of the layout (contiguous ranges per wave: +6 %)
-    const unsigned per_wave = (ncells + nwaves - 1u) / nwaves;
-    const unsigned cbeg = interleave ? 0u : (unsigned)((u64)ncells * wave / nwaves);
-    const unsigned cend = interleave ? per_wave : (unsigned)((u64)ncells * (wave + 1u) / nwaves);
-    for (unsigned g0 = cbeg; g0 < cend; g0 += 64u) {
-        // counts and tile ranges of up to 64 cells, one per lane
-        const unsigned mine = interleave ? (g0 + (unsigned)lane) * nwaves + wave : g0 + (unsigned)lane;
-        const bool in = interleave ? (g0 + (unsigned)lane < per_wave && mine < ncells) : mine < cend;
-        unsigned v_nq = in ? cell_counts[mine] : 0u;
-        const unsigned v_tb = in ? tile_start[mine] : 0u;
-        const unsigned v_te = in ? tile_start[mine + 1u] : 0u;
-        if (v_nq > cap)
-            v_nq = cap;
-        for (u64 todo = __ballot(v_nq != 0u && v_te > v_tb); todo != 0ull; todo &= todo - 1ull) {
-            const int j = (int)__builtin_ctzll(todo);
-            const unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
-            const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
-            const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, j);
-            const unsigned cellj = interleave ? (g0 + (unsigned)j) * nwaves + wave : g0 + (unsigned)j;
-            const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
-            // the first two blocks of the list travel with the tiles (one round trip per cell)
-            const unsigned l0 = list[min((unsigned)lane, nq - 1u)];
-            for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
-                const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
-                h8 ar[CELL_TILES_PER_PASS];
-#pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                    if (p < nt)
-                        ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
-                const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
-                const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
-                const f4v n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
-                __builtin_amdgcn_wave_barrier();   // the previous pass's reads of the window are done
-                my_nrm[lane] = n0;
-                if (lane < CELL_TILES_PER_PASS * 8 - 64)
-                    my_nrm[64 + lane] = n1;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
-                    const unsigned idx = q0 + (unsigned)col;
-                    const bool valid = idx < nq;
-                    unsigned qid;
-                    if (q0 < 64u) {
-                        const unsigned from = __shfl(l0, (int)idx, KNN_WAVE);
-                        qid = valid ? from : __shfl(l0, 0, KNN_WAVE);
-                    } else {
-                        qid = list[valid ? idx : 0u];
-                    }
-                    const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
-                    const float th = valid ? s_thr[qid] : -INFINITY;
-                    u64 any = 0ull;
-                    u64 masks[CELL_TILES_PER_PASS];
-#pragma unroll
-                    for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                        masks[p] = 0ull;
-                        if (p < nt) {
-                            f16v c;
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                const f4v v = my_nrm[p * 8 + 2 * gq + half];
-                                c[4 * gq + 0] = v[0];
-                                c[4 * gq + 1] = v[1];
-                                c[4 * gq + 2] = v[2];
-                                c[4 * gq + 3] = v[3];
-                            }
-                            const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
-                            const float mn = min_tree16(d, th);
-                            masks[p] = __ballot(mn < th);
-                            any |= masks[p];
-                        }
-                    }
-                    if (__builtin_expect(any != 0ull, 0)) {
-                        const u64 me = 1ull << lane;
-#pragma unroll
-                        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                            const u64 mask = masks[p];
-                            if (mask != 0ull) {
-                                if (mask & me) {
-                                    const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                    if (pos < slice)
-                                        my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
-                                }
-                                cnt += (unsigned)__popcll(mask);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (lane == 0) {
-        counts[wave] = cnt;
-        if (cnt > slice)
-            ctl[KNN_CTL_FALLBACK] = 1u;
-    }
-}
-
 // Test hook: all scores of one (reference tile, query tile) pair per wave.
 template <int KT>
 __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restrict__ rf,
@@ -1600,32 +895,14 @@ __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restr
 // ------------------------------------------------------------------------------------------
 // Host side.
 // ------------------------------------------------------------------------------------------
-#define FTRY(call)                       \
-    do {                                 \
-        hipError_t e_ = (call);          \
-        if (e_ != hipSuccess)            \
-            return e_;                   \
-    } while (0)
 
 static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB, split evenly over the waves
 static const unsigned kMaxLists = 1u << 16;
 static const unsigned kSampleBlocks = 512;           // most blocks the sample pass uses (x 4 waves)
-static const float kAmaxLimit = 1024.0f;           // queries far outside the references' box
-
-static void cells_free(CellIndex *&c)
-{
-    if (!c)
-        return;
-    (void)KNN_DEV_FREE(c->bounds);
-    (void)KNN_DEV_FREE(c->tile_start);
-    (void)KNN_DEV_FREE(c->perm);
-    delete c;
-    c = nullptr;
-}
 
 void knn_filter_free(FilterState &st)
 {
-    cells_free(st.cells);
+    knn_cells_free(st.cells);
     (void)KNN_DEV_FREE(st.center);
     (void)KNN_DEV_FREE(st.ref_frags);
     (void)KNN_DEV_FREE(st.ref_norms);
@@ -1642,142 +919,9 @@ void knn_filter_free(FilterState &st)
         (void)KNN_DEV_FREE(w.counts);
         (void)KNN_DEV_FREE(w.umin);
         (void)KNN_DEV_FREE(w.qpart);
-        (void)KNN_DEV_FREE(w.cell_counts);
-        (void)KNN_DEV_FREE(w.cell_lists);
-        (void)KNN_DEV_FREE(w.dup);
-        (void)KNN_DEV_FREE(w.lo_tab);
-        (void)KNN_DEV_FREE(w.hi_tab);
-        if (w.cells_off)
-            (void)hipHostFree(w.cells_off);
+        knn_cells_workspace_free(w);
     }
     st = FilterState();
-}
-
-// Sorts the shard into cells (see "Cell-pruned scan").  *out stays null when the shard is too small, the
-// dimension does not suit, or the cuts leave the cells badly unbalanced.  samp: the strided host sample
-// of the build (samples x k).  Synchronous.
-static hipError_t cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
-                              long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                              unsigned **fill_out)
-{
-    *out = nullptr;
-    *code_out = nullptr;
-    *fill_out = nullptr;
-    if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
-        return hipSuccess;
-    int bits = 0;
-    while ((144ll << (bits + 1)) <= n)   // cells of 144 .. 288 rows on average: 5-9 tiles each
-        ++bits;
-    bits = std::min(bits, std::min(16, 4 * k));
-    if (bits < 9)
-        return hipSuccess;
-    CellIndex *c = new CellIndex();
-    c->bits = bits;
-    c->ncells = 1u << bits;
-    // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
-    // in 16 dimensions keeps ~36 of 1024), every query of a batch at <= 2^13 cells
-    c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
-    int pos = 0, sa = 0;
-    for (int d = 0; d < k; ++d) {
-        c->nb[d] = (unsigned char)(bits / k + (d < bits % k ? 1 : 0));
-        c->shift[d] = (unsigned char)pos;
-        if (pos <= 8)
-            sa = pos;
-        pos += c->nb[d];
-    }
-    if (pos <= 8)
-        sa = pos;
-    c->sa = sa;
-    if (sa < 6) {   // a wave of the match pass covers 64 consecutive low-table entries
-        delete c;
-        return hipSuccess;
-    }
-    // cuts at the sample quantiles
-    std::vector<float> bounds((size_t)16 * (CELL_MAX_BINS - 1), INFINITY), col((size_t)samples);
-    for (int d = 0; d < k; ++d) {
-        if (!c->nb[d])
-            continue;
-        for (long long i = 0; i < samples; ++i)
-            col[(size_t)i] = samp[(size_t)i * k + d];
-        std::sort(col.begin(), col.end());
-        const int nbins = 1 << c->nb[d];
-        for (int j = 1; j < nbins; ++j)
-            bounds[(size_t)d * (CELL_MAX_BINS - 1) + (j - 1)] = col[(size_t)(j * samples / nbins)];
-    }
-    CellGeom g;
-    memset(&g, 0, sizeof g);
-    g.k = k;
-    g.bits = bits;
-    g.sa = sa;
-    memcpy(g.nb, c->nb, 16);
-    memcpy(g.shift, c->shift, 16);
-
-    unsigned *code = nullptr, *counts = nullptr;
-    std::vector<unsigned> hcounts((size_t)c->ncells), hstart((size_t)c->ncells + 1);
-    hipError_t e = KNN_DEV_ALLOC((void **)&c->bounds, bounds.size() * sizeof(float));
-    if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&c->tile_start, hstart.size() * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&code, (size_t)n * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = KNN_DEV_ALLOC((void **)&counts, hcounts.size() * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(c->bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess)
-        e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(knn_cells_code_kernel, dim3(blocks), dim3(256), 0, s, r, n, g, c->bounds, code, counts);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(s);   // (also keeps `bounds` alive until its copy is done)
-    bool keep = e == hipSuccess;
-    long long tiles = 0;
-    if (keep) {
-        unsigned biggest = 0u;
-        for (unsigned i = 0; i < c->ncells; ++i) {
-            hstart[i] = (unsigned)tiles;
-            tiles += (hcounts[i] + 31u) / 32u;
-            biggest = std::max(biggest, hcounts[i]);
-        }
-        hstart[c->ncells] = (unsigned)tiles;
-        c->max_cell_rows = biggest;
-        // badly unbalanced cells (clustered data the sample quantiles do not describe) leave a few waves with all the
-        // work and a few lists with all the queries: full scans serve such a shard better
-        keep = (long long)biggest * c->ncells <= 16 * n;
-    }
-    if (keep) {
-        // the rows are placed (and turned into fragments) by knn_cells_scatter_frag_kernel once the layout buffers
-        // exist: `code` and the zeroed fill counters go back to the caller
-        e = hipMemcpyAsync(c->tile_start, hstart.data(), hstart.size() * sizeof(unsigned), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess)
-            e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
-        if (e == hipSuccess)
-            e = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles * 32 * sizeof(unsigned));
-        if (e == hipSuccess)
-            e = hipMemsetAsync(c->perm, 0xFF, (size_t)tiles * 32 * sizeof(unsigned), s);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(s);   // hstart is about to go out of scope
-    }
-    if (e == hipErrorOutOfMemory) {   // no room for the sort: the plain layout still works
-        (void)hipGetLastError();
-        e = hipSuccess;
-        keep = false;
-    }
-    if (e != hipSuccess || !keep) {
-        (void)KNN_DEV_FREE(code);
-        (void)KNN_DEV_FREE(counts);
-        cells_free(c);
-        return e;
-    }
-    *code_out = code;
-    *fill_out = counts;
-    *ntiles_out = tiles;
-    *out = c;
-    return hipSuccess;
 }
 
 // Robust box of a sample (samples x k, row-major): per dimension [median - w s, median + w s] clipped to
@@ -1957,7 +1101,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     // 1c. cell-sorted layout (k <= 16, resident indexes): ntiles becomes the padded tile count
     unsigned *cell_code = nullptr, *cell_fill = nullptr;
     if (want_cells && kt == 1) {
-        FTRY(cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles, &cell_code, &cell_fill));
+        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles, &cell_code, &cell_fill));
         lap(st.cells ? "cell codes + counts" : "cell codes (not kept)");
     }
 
@@ -1987,14 +1131,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     if (e == hipSuccess) {
         const long long rows_padded = ntiles * 32;
         if (st.cells) {
-            // padding first (zero fragments, +INF norms), then every row to its cell
-            e = hipMemsetAsync(st.ref_frags, 0, (size_t)ntiles * 64 * 16, s);
-            if (e == hipSuccess)
-                e = hipMemsetD32Async((hipDeviceptr_t)st.ref_norms, 0x7F800000, (size_t)rows_padded, s);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r, n, k,
-                                   cell_code, st.cells->tile_start, cell_fill, st.center, sigma, (h8 *)st.ref_frags,
-                                   st.ref_norms, st.cells->perm, dout, st.outliers, ocap);
+            e = knn_cells_place_rows(st, r, cell_code, cell_fill, dout, ocap, s);
         } else if (k == 16 && ((uintptr_t)r & 15u) == 0)
             hipLaunchKernelGGL(knn_frag16_kernel, dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, s,
                                (const f4v *)r, n, rows_padded, st.center, sigma, (h8 *)st.ref_frags,
@@ -2570,104 +1707,6 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     return hipSuccess;
 }
 
-// ---- cell-pruned scan: host side --------------------------------------------------------------
-static const int kCellBatch = 1024;   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS
-
-static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m)
-{
-    const CellIndex &c = *st.cells;
-    if (!w.cell_counts)
-        FTRY(KNN_DEV_ALLOC((void **)&w.cell_counts, (size_t)c.ncells * sizeof(unsigned)));
-    if (!w.cell_lists)
-        FTRY(KNN_DEV_ALLOC((void **)&w.cell_lists, (size_t)c.ncells * c.cap * sizeof(unsigned short)));
-    if (!w.cells_off) {
-        FTRY(hipHostMalloc((void **)&w.cells_off, sizeof(unsigned), hipHostMallocDefault));
-        *w.cells_off = 0u;
-    }
-    const int m_padded = (m + 31) / 32 * 32;
-    if (m_padded > w.cell_m_cap) {
-        (void)KNN_DEV_FREE(w.dup);
-        (void)KNN_DEV_FREE(w.lo_tab);
-        (void)KNN_DEV_FREE(w.hi_tab);
-        w.dup = w.lo_tab = w.hi_tab = nullptr;
-        w.cell_m_cap = 0;
-        FTRY(KNN_DEV_ALLOC((void **)&w.dup, (size_t)m_padded * sizeof(float)));
-        FTRY(KNN_DEV_ALLOC((void **)&w.lo_tab, (size_t)m_padded * ((size_t)1 << c.sa) * sizeof(float)));
-        FTRY(KNN_DEV_ALLOC((void **)&w.hi_tab, (size_t)m_padded * ((size_t)1 << (c.bits - c.sa)) * sizeof(float)));
-        w.cell_m_cap = m_padded;
-    }
-    if ((size_t)m_padded > w.umin_cap) {
-        (void)KNN_DEV_FREE(w.umin);
-        w.umin = nullptr;
-        w.umin_cap = 0;
-        FTRY(KNN_DEV_ALLOC((void **)&w.umin, (size_t)m_padded * sizeof(float)));
-        w.umin_cap = (size_t)m_padded;
-    }
-    return hipSuccess;
-}
-
-// One batch of <= kCellBatch queries (already prepared by prep_queries): seed, thresholds, match, scan.
-static hipError_t launch_cells(FilterState &st, FilterWorkspace &w, int m, const float *q, int num_cu, bool timed,
-                               hipStream_t s)
-{
-    const CellIndex &c = *st.cells;
-    const int m_padded = (m + 31) / 32 * 32;
-    CellGeom g;
-    memset(&g, 0, sizeof g);
-    g.k = st.k;
-    g.bits = c.bits;
-    g.sa = c.sa;
-    memcpy(g.nb, c.nb, 16);
-    memcpy(g.shift, c.shift, 16);
-    unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
-    if (gx * CELL_SCAN_WAVES > c.ncells)   // (a wave per cell at least; holding the grid to 4 cells per wave left a third
-        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);   //  of the CUs idle at 2^13 cells: 0.049 -> see profiles)
-    w.nlists = gx * CELL_SCAN_WAVES;
-    w.slice = w.rec_cap / w.nlists;
-    w.has_rows = false;
-    w.pieces = RerankPieces();
-
-    hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds,
-                       (double)st.sigma * (double)st.sigma, c.tile_start, (const h8 *)st.ref_frags, st.ref_norms,
-                       (const h8 *)w.qry_frags, w.lo_tab, w.hi_tab, m_padded, w.qry_norms, w.qry_amax, w.qpart,
-                       (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup, w.ctl, w.cells_off,
-                       w.counts, w.nlists);
-    FTRY(hipGetLastError());
-    if (c.ncells <= 16384u)
-        hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
-                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
-    else
-        hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
-                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
-    FTRY(hipGetLastError());
-    if (timed && w.ev_begin)
-        FTRY(hipEventRecord(w.ev_begin, s));
-    const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
-    hipLaunchKernelGGL(knn_cells_scan_kernel, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, st.ref_norms,
-                       c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded, w.cell_counts, w.cell_lists, c.cap,
-                       w.records, w.counts, w.ctl, w.slice);
-    FTRY(hipGetLastError());
-    if (timed && w.ev_end)
-        FTRY(hipEventRecord(w.ev_end, s));
-    if (getenv("KNN_MI355X_TRACE_CELLS")) {   // development aid: how long the lists of this batch are (synchronises)
-        std::vector<unsigned> hc((size_t)c.ncells);
-        FTRY(hipStreamSynchronize(s));
-        FTRY(hipMemcpy(hc.data(), w.cell_counts, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        unsigned long long sum = 0, blocks = 0, groups = 0;
-        unsigned mx = 0, nz = 0;
-        for (unsigned v : hc) {
-            sum += v;
-            blocks += (v + 31) / 32;
-            groups += (v + 127) / 128;
-            mx = std::max(mx, v);
-            nz += v != 0;
-        }
-        fprintf(stderr, "[knn cells] m %d: %u cells, %u non-empty, %llu (cell, query) pairs = %.1f per cell, longest list %u, "
-                        "%llu blocks of 32, %llu groups of 128\n", m, c.ncells, nz, sum, (double)sum / c.ncells, mx, blocks, groups);
-    }
-    return hipSuccess;
-}
-
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
                             u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
@@ -2683,14 +1722,13 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     w.ev_begin = ev_begin;
     w.ev_end = ev_end;
     if (cells) {
-        FTRY(ensure_workspace(st, w, std::min(m, kCellBatch)));
-        FTRY(ensure_cells_workspace(st, w, std::min(m, kCellBatch)));
-        for (int q0 = 0; q0 < m; q0 += kCellBatch) {
-            const int mb = std::min(kCellBatch, m - q0);
+        FTRY(ensure_workspace(st, w, std::min(m, KNN_CELL_BATCH)));
+        for (int q0 = 0; q0 < m; q0 += KNN_CELL_BATCH) {
+            const int mb = std::min(KNN_CELL_BATCH, m - q0);
             const float *qb = q + (size_t)q0 * st.k;
             u64 *kb = keys + q0;
             FTRY(prep_queries(st, w, mb, qb, s));
-            FTRY(launch_cells(st, w, mb, qb, num_cu, q0 == 0, s));
+            FTRY(knn_cells_query(st, w, mb, qb, num_cu, q0 == 0, s));
             FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl,
                                    kb, w.pieces, s, perm));
             FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));

@@ -122,13 +122,17 @@ def test_filter_kernels_keep_mfma_results_12_wait_states_from_their_readers(tmp_
         import mfma_hazard_audit
     finally:
         sys.path.pop(0)
-    src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", "knn_filter.hip")
-    asm = tmp_path / "knn_filter.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                           "--cuda-device-only", "-o", str(asm), src])
-    bad, n_mfma = mfma_hazard_audit.audit(asm.read_text())
-    assert n_mfma >= 300, n_mfma
-    assert not bad, bad[:5]
+    total = 0
+    for name in ("knn_filter.hip", "knn_cells.hip"):
+        src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", name)
+        asm = tmp_path / (name + ".s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", "-o", str(asm), src])
+        bad, n_mfma = mfma_hazard_audit.audit(asm.read_text())
+        assert not bad, (name, bad[:5])
+        assert n_mfma >= 20, (name, n_mfma)
+        total += n_mfma
+    assert total >= 300, total
 
 
 
