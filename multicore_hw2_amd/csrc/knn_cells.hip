@@ -17,18 +17,18 @@
 // cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch:
 //   seed    : every query scores its own cell and the 3 cells next to it (MFMA, same scores as the scan):
 //             the minimum is a score of a real reference, which is all knn_threshold needs.  The same
-//             kernel tabulates the query's squared gap to every bin of every dimension.
-//   thr     : threshold thr_q for the scores, and Dup_q = the largest real (scaled) squared distance any
-//             candidate for the answer can have (see knn_threshold).
+//             kernel tabulates the query's squared gap to every bin of every dimension and, from the minimum,
+//             derives thr_q for the scores and Dup_q = the largest real (scaled) squared distance any
+//             candidate for the answer can have (knn_threshold, knn_filter_dev.h).
 //   match   : a row of cell c differs from the query by at least gap_d(bin_d(c)) in every dimension, so
 //             LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of the cell, and LB > Dup_q rules the whole
 //             cell out (ties included: a row that ties with the answer obeys the Dup bound too).  LB is separable:
-//             lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  Cell-major, no atomics: a wave owns 64
-//             consecutive cells and appends the surviving queries to its lanes' lists.
+//             lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  Cell-major, no global atomics: a block owns
+//             64 consecutive cells and appends the surviving queries to their lists.
 //   scan    : a wave walks its cells; per cell it gathers the listed queries' B operands from LDS (32 per
 //             block of columns) and runs the usual MFMA + min3 tree + threshold test over the cell's tiles.
-// Uniform data in 16 dimensions, n = 2^24: ~2400 of 65536 cells survive per query, ~36 queries per cell —
-// 1/20 of the MFMA work of the full scan, and the fragments are read once: the scan is HBM-bound.
+// Uniform data in 16 dimensions, n = 2^24: ~1600 of 65536 cells survive per query, 25 queries per cell —
+// 1/25 of the MFMA work of the full scan, and the fragments are read once: the scan is HBM-bound.
 // Anything that does not fit (a list overflows, a query's seed cells are empty) raises the FALLBACK
 // flag for this batch — the gated exact scan answers it — and the host-visible `cells_off` word, after
 // which the index goes back to the full scan with the strided sample.
@@ -614,7 +614,7 @@ void knn_cells_free(CellIndex *&c)
 }
 
 
-// Sorts the shard into cells (see "Cell-pruned scan").  *out stays null when the shard is too small, the
+// Sorts the shard into cells (see the head of this file).  *out stays null when the shard is too small, the
 // dimension does not suit, or the cuts leave the cells badly unbalanced.  samp: the strided host sample
 // of the build (samples x k).  Synchronous.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,

@@ -90,7 +90,7 @@ struct FilterWorkspace {
     bool last_used_cells = false;
 };
 
-// Cell-sorted layout of the references (k <= 16): see "Cell-pruned scan" in knn_filter.hip.
+// Cell-sorted layout of the references (k <= 16): see the head of knn_cells.hip.
 struct CellIndex {
     int bits = 0, sa = 0;            // cells = 2^bits; low pruning table = 2^sa entries
     unsigned char nb[16] = {0}, shift[16] = {0};
