@@ -1,0 +1,87 @@
+"""The pruning argument of the cell-pruned scan (multicore_hw2_amd/csrc/knn_cells.hip), restated in numpy — no GPU.
+Rows are binned per dimension by `x >= cut` compares; for a query q the squared gap to a row's bin, summed over
+the dimensions, must never exceed the squared distance to the row — for rows and queries ON the cuts, duplicated
+cuts, values far from the origin, and under the kernel's own rounding (terms rounded DOWN to float32)."""
+import numpy as np
+import pytest
+
+
+def assign_bins(x, cuts):
+    """bin b <=> cuts[b-1] <= x < cuts[b] (ascending cuts; NaN -> bin 0), as cell_bin() does."""
+    return (x[:, None] >= cuts[None, :]).sum(axis=1)
+
+
+def gap_table(q, cuts):
+    """gap[b] = distance from q to bin b's interval, 0 inside (as knn_cells_seed_kernel computes it, in float64)."""
+    nb = len(cuts) + 1
+    g = np.zeros(nb)
+    for b in range(nb):
+        if b > 0 and cuts[b - 1] > q:
+            g[b] = float(cuts[b - 1]) - float(q)
+        if b < nb - 1 and q > cuts[b]:
+            g[b] = float(q) - float(cuts[b])
+    return g
+
+
+def round_down_f32(v):
+    f = np.float32(v)
+    return np.where(f.astype(np.float64) > v, np.nextafter(f, np.float32(-np.inf)), f).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "offset", "duplicate_cuts", "wide_range"])
+@pytest.mark.parametrize("k,bins", [(16, 2), (5, 8), (3, 16)])
+def test_cell_lower_bound_never_exceeds_the_distance(kind, k, bins):
+    rng = np.random.default_rng(hash((kind, k, bins)) % (1 << 32))
+    n, m = 4000, 64
+    R = rng.random((n, k)).astype(np.float32)
+    Q = rng.random((m, k)).astype(np.float32)
+    if kind == "lattice":
+        R = (rng.integers(0, 5, (n, k)) * 0.25).astype(np.float32)
+        Q = (rng.integers(0, 5, (m, k)) * 0.25).astype(np.float32)
+    elif kind == "offset":
+        R += np.float32(4096)
+        Q += np.float32(4096)
+    elif kind == "wide_range":
+        R = (R * np.float32(1e6) - np.float32(5e5)).astype(np.float32)
+        Q = (Q * np.float32(3e6) - np.float32(1.5e6)).astype(np.float32)
+    cuts = [np.sort(R[:: max(1, n // 256), d])[[(j * (len(R[:: max(1, n // 256)]))) // bins for j in range(1, bins)]]
+            for d in range(k)]
+    if kind == "duplicate_cuts":
+        cuts = [np.sort(np.concatenate([c[: bins // 2], c[: bins - 1 - bins // 2]])).astype(np.float32) for c in cuts]
+    rbin = np.stack([assign_bins(R[:, d], cuts[d]) for d in range(k)], axis=1)          # n x k
+    R64, Q64 = R.astype(np.float64), Q.astype(np.float64)
+    for qi in range(m):
+        tabs = [gap_table(Q[qi, d], cuts[d]) for d in range(k)]
+        # the kernel's arithmetic: squared terms rounded down to float32, summed in float64, rounded down again
+        terms = np.stack([round_down_f32(tabs[d][rbin[:, d]] ** 2) for d in range(k)], axis=1).astype(np.float64)
+        lb = round_down_f32(terms.sum(axis=1)).astype(np.float64)
+        d2 = ((R64 - Q64[qi]) ** 2).sum(axis=1)                                        # exact enough: float64 of floats
+        assert (lb <= d2 * (1 + 1e-12) + 1e-300).all(), (kind, qi, float((lb - d2).max()))
+        # and the bound is not vacuous: rows of the query's own cell have bound 0
+        qbin = np.array([assign_bins(Q[qi:qi + 1, d], cuts[d])[0] for d in range(k)])
+        own = (rbin == qbin).all(axis=1)
+        assert (lb[own] == 0).all()
+
+
+def test_cell_code_layout_matches_the_build_rules():
+    """bits per dimension = B / k rounded up for the first B % k dimensions; the low pruning table ends at the last
+    dimension boundary at or below bit 8 and must cover >= 64 entries (knn_cells_build)."""
+    def plan(k, bits):
+        nb = [bits // k + (1 if d < bits % k else 0) for d in range(k)]
+        pos, sa, shift = 0, 0, []
+        for d in range(k):
+            shift.append(pos)
+            if pos <= 8:
+                sa = pos
+            pos += nb[d]
+        if pos <= 8:
+            sa = pos
+        return nb, shift, sa
+    for k in range(3, 17):
+        for bits in range(9, min(16, 4 * k) + 1):
+            nb, shift, sa = plan(k, bits)
+            assert sum(nb) == bits and max(nb) <= 4
+            assert sa <= 8 and bits - sa <= 10
+            if sa >= 6:                                   # else the build declines the cells
+                low = [d for d in range(k) if nb[d] and shift[d] < sa]
+                assert sum(nb[d] for d in low) == sa      # the low table holds whole dimensions only
