@@ -226,3 +226,23 @@ def test_two_batches_in_flight_on_their_own_slots_and_streams(oracle):
             np.testing.assert_array_equal(outs[i].cpu().numpy(), oracle.v0(k, Qs[i], R, threads=THREADS), err_msg=f"slot {i}")
     finally:
         ix.close()
+
+
+def test_c3_full_shape_every_query_against_the_oracle(oracle):
+    """BASELINE config C3 (k = 16, m = 1024, n = 2^24) on the path bench.py measures: ALL 1024 answers against the
+    CPU oracle over all 2^24 references (2.7e11 multiply-adds on the host's threads), cells by library policy."""
+    k, m, n = 16, 1024, 1 << 24
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
+    pkg.synth_fill_device(r_d.data_ptr(), n * k, 1001, device=0, stream=stream)
+    torch.cuda.synchronize()
+    Q = oracle.synth(m * k, 1000).reshape(m, k)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True, stream=stream)
+    try:
+        got, st = _query(ix, Q)
+    finally:
+        ix.close()
+    assert st[0] == 4 and st[2] == 0, st
+    want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
+    np.testing.assert_array_equal(got, want)
