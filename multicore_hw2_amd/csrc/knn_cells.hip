@@ -613,13 +613,12 @@ void knn_cells_free(CellIndex *&c)
     c = nullptr;
 }
 
-
 // Sorts the shard into cells (see the head of this file).  *out stays null when the shard is too small, the
 // dimension does not suit, or the cuts leave the cells badly unbalanced.  samp: the strided host sample
 // of the build (samples x k).  Synchronous.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
-                              long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                              unsigned **fill_out)
+                           long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
+                           unsigned **fill_out)
 {
     *out = nullptr;
     *code_out = nullptr;
@@ -636,7 +635,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     c->bits = bits;
     c->ncells = 1u << bits;
     // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
-    // in 16 dimensions keeps ~36 of 1024), every query of a batch at <= 2^13 cells
+    // in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
     c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
     int pos = 0, sa = 0;
     for (int d = 0; d < k; ++d) {
@@ -771,7 +770,7 @@ void knn_cells_workspace_free(FilterWorkspace &w)
     w.cell_m_cap = 0;
 }
 
-// ---- cell-pruned scan: host side --------------------------------------------------------------
+// ---- per batch ---------------------------------------------------------------------------------
 
 static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m)
 {
@@ -796,17 +795,11 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
         FTRY(KNN_DEV_ALLOC((void **)&w.hi_tab, (size_t)m_padded * ((size_t)1 << (c.bits - c.sa)) * sizeof(float)));
         w.cell_m_cap = m_padded;
     }
-    if ((size_t)m_padded > w.umin_cap) {
-        (void)KNN_DEV_FREE(w.umin);
-        w.umin = nullptr;
-        w.umin_cap = 0;
-        FTRY(KNN_DEV_ALLOC((void **)&w.umin, (size_t)m_padded * sizeof(float)));
-        w.umin_cap = (size_t)m_padded;
-    }
     return hipSuccess;
 }
 
-// One batch of <= kCellBatch queries (already prepared by prep_queries): seed, thresholds, match, scan.
+// One batch of <= KNN_CELL_BATCH queries (their fragments already written by the filter's query-fragment kernel):
+// seed + thresholds, match, scan.
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, int num_cu, bool timed,
                            hipStream_t s)
 {
@@ -821,8 +814,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     memcpy(g.nb, c.nb, 16);
     memcpy(g.shift, c.shift, 16);
     unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
-    if (gx * CELL_SCAN_WAVES > c.ncells)   // (a wave per cell at least; holding the grid to 4 cells per wave left a third
-        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);   //  of the CUs idle at 2^13 cells: 0.049 -> see profiles)
+    if (gx * CELL_SCAN_WAVES > c.ncells)   // a wave per cell at least (holding the grid to 4 cells per wave left a third of
+        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);   // the CUs without a block at 2^13 cells: scan alone 0.052 -> 0.035 ms)
     w.nlists = gx * CELL_SCAN_WAVES;
     w.slice = w.rec_cap / w.nlists;
     w.has_rows = false;
