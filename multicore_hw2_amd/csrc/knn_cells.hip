@@ -358,9 +358,9 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
 // Cell-major matching: a block of 8 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
 // low-table entries).  Pass 1 (queries on the lanes, an eighth of the batch per wave): which queries get past
 // the high table alone — about a third for uniform data — compacted into an LDS queue.  Pass 2 (cells on
-// the lanes, the queue dealt round-robin to the waves): the low-table entry of each queued query, 16 loads in
-// flight per wave; survivors are appended to the cell's list under an LDS counter.  cell_counts[c] = queries
-// that could not rule cell c out, lists[c][0..) = their numbers (any order).  No global atomics: per-cell
+// the lanes, the queue cut into one run per wave): the low-table entry of each queued query, 16 loads in
+// flight per wave; survivors go to the cell's list at offsets prefix-summed over the waves.  cell_counts[c] = queries
+// that could not rule cell c out, lists[c][0..) = their numbers.  No global atomics: per-cell
 // appends with returning atomics ran at 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
 template <int CELL_MATCH_WAVES>   // 8, or 16 for shards of few cells (one block per 64 cells: 128 blocks at 2^13 cells)
 __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 {
     __shared__ unsigned short s_q[1024];
     __shared__ float s_hv[1024], s_dq[1024];
-    __shared__ unsigned s_npass, s_cnt[64];
+    __shared__ unsigned s_npass, s_wcnt[CELL_MATCH_WAVES][64];
     // lists of up to 128 entries are put together in LDS (row stride 65 dwords: lanes appending at the same
     // depth hit different banks) and written out as whole 256-byte rows; longer ones (few, large cells) go
     // straight to memory
@@ -387,8 +387,6 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const float *__restrict__ hrow = hi_tab + (size_t)h * m_padded;
     if (threadIdx.x == 0)
         s_npass = 0u;
-    if (threadIdx.x < 64)
-        s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     {   // pass 1: this wave's share of the batch (m <= 1024: 16 chunks of 64 queries over the waves)
         constexpr int U = 16 / CELL_MATCH_WAVES;
@@ -423,39 +421,73 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const unsigned npass = s_npass;
     const bool staged = cap <= 128u;
     unsigned short *__restrict__ my = staged ? &s_list[lane][0] : lists + (size_t)cell * cap;
-    constexpr int INFLIGHT = 16;   // low-table loads a wave has outstanding (32: 15 -> 23 us at C3, 22 -> 19 us at 2^21 rows)
-    for (unsigned e0 = (unsigned)wib * INFLIGHT; e0 < npass; e0 += INFLIGHT * CELL_MATCH_WAVES) {
+    // pass 2: the queue in contiguous runs, one per wave (<= 1024 / WAVES entries); a lane keeps "my cell could not
+    // rule entry j out" as bit j of a mask, the waves' counts are prefix-summed through LDS, and the second sweep
+    // writes every survivor to its final place — no LDS atomics (16 waves adding to the same 64 counters cost
+    // more than the table loads at 2^13 cells, where a list holds ~125 of 1024 queries), lists in query order.
+    constexpr int EPW = 1024 / CELL_MATCH_WAVES, INFLIGHT = 16;   // entries per wave; low-table loads outstanding
+    const unsigned per = (npass + CELL_MATCH_WAVES - 1u) / CELL_MATCH_WAVES;
+    const unsigned e_begin = min((unsigned)wib * per, npass), e_end = min(e_begin + per, npass);
+    u64 keep[EPW / 64];
+#pragma unroll
+    for (int w64 = 0; w64 < EPW / 64; ++w64)
+        keep[w64] = 0ull;
+    for (unsigned e0 = e_begin; e0 < e_end; e0 += INFLIGHT) {
         float lo[INFLIGHT];
 #pragma unroll
         for (int u = 0; u < INFLIGHT; ++u) {
-            const unsigned e = min(e0 + (unsigned)u, npass - 1u);
+            const unsigned e = min(e0 + (unsigned)u, e_end - 1u);
             lo[u] = lo_tab[(size_t)s_q[e] * nl + l];
         }
 #pragma unroll
         for (int u = 0; u < INFLIGHT; ++u) {
             const unsigned e = e0 + (unsigned)u;
-            if (e < npass) {
+            if (e < e_end) {
                 const float lb = lo[u] + s_hv[e];
+                const unsigned j = e - e_begin;
                 if (!(lb > s_dq[e])) {
-                    const unsigned pos = atomicAdd(&s_cnt[lane], 1u);
-                    if (pos < cap)
-                        my[pos] = s_q[e];
+#pragma unroll
+                    for (int w64 = 0; w64 < EPW / 64; ++w64)
+                        if ((int)(j >> 6) == w64)
+                            keep[w64] |= 1ull << (j & 63u);
                 }
             }
         }
     }
+    unsigned mine = 0u;
+#pragma unroll
+    for (int w64 = 0; w64 < EPW / 64; ++w64)
+        mine += (unsigned)__popcll(keep[w64]);
+    s_wcnt[wib][lane] = mine;
     __syncthreads();
+    unsigned pos = 0u, total = 0u;
+    for (int w = 0; w < CELL_MATCH_WAVES; ++w) {
+        const unsigned v = s_wcnt[w][lane];
+        pos += w < wib ? v : 0u;
+        total += v;
+    }
+#pragma unroll
+    for (int w64 = 0; w64 < EPW / 64; ++w64)
+        for (u64 bits = keep[w64]; bits != 0ull; bits &= bits - 1ull) {
+            const unsigned e = e_begin + (unsigned)w64 * 64u + (unsigned)__builtin_ctzll(bits);
+            if (pos < cap)
+                my[pos] = s_q[e];
+            ++pos;
+        }
     if (wib == 0) {
-        const unsigned cnt = s_cnt[lane];
-        cell_counts[cell] = cnt;
-        if (cnt > cap) {
+        cell_counts[cell] = total;
+        if (total > cap) {
             ctl[KNN_CTL_FALLBACK] = 1u;  // a list is cut short: the gated exact scan answers this batch
             *cells_off = 1u;
         }
     }
+    __syncthreads();
     if (staged) {
         for (int j = wib; j < 64; j += CELL_MATCH_WAVES) {
-            const unsigned cj = min(s_cnt[j], cap);
+            unsigned cj = 0u;
+            for (int w = 0; w < CELL_MATCH_WAVES; ++w)
+                cj += s_wcnt[w][j];
+            cj = min(cj, cap);
             if ((unsigned)lane * 2u < cj)
                 ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[lane] = ((const unsigned *)&s_list[j][0])[lane];
         }
