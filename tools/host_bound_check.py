@@ -2,7 +2,7 @@
 """Is the pipelined step bound by the host's launch rate?  Enqueues 600 steps (keys init -> query -> unpack, three
 streams / workspace slots) and reports how long the host needed to enqueue them against how long the GPU needed to
 finish them.  Round 2, one MI355X: n = 2^21: host 23.6 us per step, GPU 47.3; n = 2^24: host 27.7, GPU 119.9 —
-the GPU is the bound at both sizes (a hipGraph per slot would not help)."""
+the host's launch rate is not what limits the step at either size."""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
