@@ -382,6 +382,15 @@ def main():
         roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or (chain == 0 and not long_scan)))
         if path_taken == 4 and "hbm_frac_physical" in roof and alone_n:
             roof["hbm_frac_physical_alone"] = roof["hbm_frac_physical"] * kern_avg_ms / (alone_ms / alone_n)
+        if path_taken == 4:
+            # What the bytes allow: a bare reader of this kernel's access pattern (one 9 KiB cell + its norms and list per
+            # wave request, 12-wave blocks, the LDS fill) reaches 6.5 TB/s on the box (tools/read_probe2.hip; plain
+            # streams 6.9), i.e. 0.81 of the 8 TB/s peak is the most a launch can show for its physical bytes.
+            phys_bytes = roof.get("traffic") or roof["physical_bytes_per_launch_estimate"]
+            roof["ceiling"] = {
+                "what": "HBM read rate a bare reader of the same access pattern reaches on this chip",
+                "GBps": 6500.0, "ms_for_this_launch": phys_bytes / 6500e9 * 1e3,
+                "source": "tools/read_probe2.hip, tools/read_probe.hip (profiles/r02_cells_probes.txt), DESIGN 4.5"}
         if roof["launches_overlap"]:
             roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
                            "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \
