@@ -162,7 +162,9 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^20 rows (k = 13 .. 16); never for the
  *             one-shot cudaCallback (one batch does not repay the sort).  1 = every index of >= 2^17 rows,
  *             cudaCallback's shards included; 2 = never.  Read when an index is created; 2 also makes
- *             existing indexes use the full scan.  Results are bit-exact either way
+ *             existing indexes use the full scan.  A batch the cells cannot hold (e.g. a thousand copies of
+ *             one query) is answered by the exact scan and sends the index to full scans for its next 256
+ *             calls.  Results are bit-exact either way
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

@@ -31,7 +31,7 @@
 // 1/25 of the MFMA work of the full scan, and the fragments are read once: the scan is HBM-bound.
 // Anything that does not fit (a list overflows, a query's seed cells are empty) raises the FALLBACK
 // flag for this batch — the gated exact scan answers it — and the host-visible `cells_off` word, after
-// which the index goes back to the full scan with the strided sample.
+// which the index goes back to the full scan with the strided sample for 256 calls.
 // ------------------------------------------------------------------------------------------
 #define CELL_MAX_BINS 16
 #define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts

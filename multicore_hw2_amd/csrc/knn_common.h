@@ -99,7 +99,8 @@ struct CellIndex {
     unsigned *tile_start = nullptr;  // device [ncells + 1]: first 32-row tile of each cell in the layout
     unsigned *perm = nullptr;        // device [ntiles * 32]: row held by each layout position (~0u = padding)
     unsigned max_cell_rows = 0;
-    bool off = false;                // a batch did not fit (list overflow, empty seed cells): full scans from now on
+    bool off = false;                // a batch did not fit (list overflow, empty seed cells): full scans for a while
+    int off_calls = 0;               // query calls answered by full scans since (the cells are retried after 256)
 };
 
 struct FilterState {

@@ -1715,8 +1715,18 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     const long long positions = st.cells ? st.ntiles * 32 : st.n;
     // a batch the cells did not fit (reported through the pinned word, read here without waiting for anything)
     // sends this index back to full scans for good
-    if (st.cells && !st.cells->off && w.cells_off && *(volatile unsigned *)w.cells_off != 0u)
+    if (st.cells && !st.cells->off && w.cells_off && *(volatile unsigned *)w.cells_off != 0u) {
         st.cells->off = true;
+        st.cells->off_calls = 0;
+    }
+    // ... but not for ever: one odd batch (a thousand copies of one query) should not cost every later one the
+    // pruned scan.  After 256 calls on full scans the cells get another try.
+    if (st.cells && st.cells->off && ++st.cells->off_calls > 256) {
+        st.cells->off = false;
+        for (FilterWorkspace &ws : st.ws)
+            if (ws.cells_off)
+                *(volatile unsigned *)ws.cells_off = 0u;
+    }
     const bool cells = st.cells && !st.cells->off && st.cells_policy != 2 && st.kt == 1;
     w.last_used_cells = cells;
     w.ev_begin = ev_begin;

@@ -126,7 +126,7 @@ def test_batches_longer_than_one_pass_and_single_queries(oracle):
 def test_a_batch_the_cells_cannot_hold_is_answered_exactly_and_switches_the_index_to_full_scans(oracle):
     """1024 copies of one query want the same ~4 % of the cells: their lists (128 entries per cell at 2^16
     cells) overflow.  The batch must come back exact (device-side fallback), and the index must stop using
-    the cells afterwards (the pinned flag), still exact."""
+    the cells afterwards (the pinned flag), still exact — and pick them up again 256 calls later."""
     k, n, m = 16, 1 << 24, 1024
     dev = torch.device("cuda:0")
     r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
@@ -151,6 +151,10 @@ def test_a_batch_the_cells_cannot_hold_is_answered_exactly_and_switches_the_inde
         got, st = _query(ix, Qv)                                # afterwards: full scans
         assert st[0] == 2 and st[2] == 0, st
         np.testing.assert_array_equal(got[sel], want_var)
+        for _ in range(256):                                    # ... for 256 calls, then the cells get another try
+            got, st = _query(ix, Qv[:32])
+        assert st[0] == 4 and st[2] == 0, st
+        np.testing.assert_array_equal(got[:8], want_var[:8])
     finally:
         ix.close()
 
