@@ -46,13 +46,17 @@ def parse_args():
     ap.add_argument("--filter-qt", type=int, default=0, help="tuning: query tiles per filter wave (0 auto)")
     ap.add_argument("--filter-rounds", type=int, default=0, help="tuning: filter blocks per resident slot (0 default)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="batches in flight (1..4), each on its own stream / workspace slot; 0 = 2 for shards of "
-                         ">= 16M references (scans chained), 3 below (scans free to overlap)")
+                    help="batches in flight (1..8), each on its own stream / workspace slot; 0 = 2 for full scans of "
+                         ">= 16M references (chained), 3 otherwise (free to overlap)")
     ap.add_argument("--filter-chain", type=int, default=0, help="0 auto, 1 scans of different slots chained, 2 free")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every N-th launch of the dominant kernel with HIP events (roofline.kernel_avg_ms)")
     ap.add_argument("--deepk", type=int, default=0, help="A/B: deep-K LDS-tiled scan, 0 = 4 waves per block, 1 = 8 waves per block")
     ap.add_argument("--cells", type=int, default=0, help="A/B: cell-sorted layouts, 0 = library policy, 1 = always (k <= 16), 2 = never")
+    ap.add_argument("--cells-variant", type=int, default=0,
+                    help="A/B: kernels of the cell-pruned path, 0 = prep + sweep, 1 = the round-2 chain, 2 = prep + round-2 match / scan")
+    ap.add_argument("--separate-init", action="store_true",
+                    help="A/B: start the keys with a knn_keys_init launch per step instead of KNN_QUERY_INIT_KEYS")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
@@ -175,6 +179,8 @@ def main():
         pkg.set_option("deepk", args.deepk)
     if args.cells:
         pkg.set_option("cells", args.cells)
+    if args.cells_variant:
+        pkg.set_option("cells_variant", args.cells_variant)
 
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)
@@ -194,7 +200,7 @@ def main():
     cells_from = {0: (1 << 19) if k <= 12 else (1 << 20), 1: 1 << 17}.get(pkg.get_option("cells"))   # the library's policy
     cells_expected = k <= 16 and cells_from is not None and n_local >= cells_from and pkg.get_option("path") in (0, 2)
     inflight = args.inflight if args.inflight > 0 else (2 if long_scan and not cells_expected else 3)
-    nbuf = 1 if args.serial else max(1, min(4, inflight))
+    nbuf = 1 if args.serial else max(1, min(8, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.
     keys_all = torch.empty((2, nbuf, m), dtype=torch.int64, device=dev)
     outs_all = torch.empty((2, nbuf, m), dtype=torch.int32, device=dev)
@@ -243,8 +249,10 @@ def main():
                 kb, ob = keys_all[g, b], outs_all[g, b]
             else:
                 g, kb, ob = 0, keys[b], outs[b]
-            pkg.keys_init(kb.data_ptr(), m, device=local_rank, stream=st.cuda_stream)
-            index.query_keys(m, q_d.data_ptr(), kb.data_ptr(), stream=st.cuda_stream, slot=b)
+            if args.separate_init:
+                pkg.keys_init(kb.data_ptr(), m, device=local_rank, stream=st.cuda_stream)
+            index.query_keys(m, q_d.data_ptr(), kb.data_ptr(), stream=st.cuda_stream, slot=b,
+                             init_keys=not args.separate_init)
             if dist is not None:
                 batch_done[b] = st.record_event()
             else:
@@ -287,13 +295,23 @@ def main():
     torch.cuda.synchronize()
     alone_n, alone_ms = 0, 0.0
     index.timing(1)
-    if nstreams > 1:
-        for _ in range(5):
+    serial_step_ms = None
+    if True:
+        for _ in range(20):
             with torch.cuda.stream(streams[0]):
-                pkg.keys_init(keys[0].data_ptr(), m, device=local_rank, stream=streams[0].cuda_stream)
-                index.query_keys(m, q_d.data_ptr(), keys[0].data_ptr(), stream=streams[0].cuda_stream, slot=0)
+                index.query_keys(m, q_d.data_ptr(), keys[0].data_ptr(), stream=streams[0].cuda_stream, slot=0, init_keys=True)
             torch.cuda.synchronize()
         alone_n, alone_ms = index.timing_read()
+        # the whole chain of one batch with nothing else in flight (what a latency-bound caller sees)
+        index.timing(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            with torch.cuda.stream(streams[0]):
+                index.query_keys(m, q_d.data_ptr(), keys[0].data_ptr(), stream=streams[0].cuda_stream, slot=0, init_keys=True)
+                pkg.keys_to_indices(keys[0].data_ptr(), m, outs[0].data_ptr(), device=local_rank, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        serial_step_ms = (time.perf_counter() - t1) * 1e3 / 50
     index.timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -305,46 +323,55 @@ def main():
     result_idx = outs_all[state["last"][0], state["last"][1]].cpu().numpy()
 
     if rank == 0:
-        kern_avg_ms = kern_ms / max(launches, 1)
-        alg_bytes = 4.0 * k * n_local + 4.0 * k * m + 8.0 * m
-        hbm_gbps = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        # Roofline of the dominant kernel.  Basis: the bytes (or flops) the kernel has to move,
+        # divided by the duration of a SINGLE launch with the GPU to itself (HIP events on its stream, 20 launches after
+        # the timed region) — so frac <= 1 by construction and reproducible from the serial kernel trace under profiles/.
+        # The north_star's figure — SURVEY 8(d)'s algorithmic bytes over the step time — is kept under its own name.
+        kern_avg_ms = kern_ms / max(launches, 1)                  # a launch inside the pipelined timed region
+        kern_ms_alone = alone_ms / max(alone_n, 1)                # the same kernel, nothing else on the GPU
+        alg_bytes = 4.0 * k * n_local + 4.0 * k * m + 8.0 * m      # the fp32 rows once, queries, keys
         path_taken = int(stats[0])
+        roof = {}
         if path_taken == 2:
             flops = 2.0 * k * m * n_local
-            ach = flops / (kern_avg_ms * 1e-3) / 1e12
+            ach = flops / (kern_ms_alone * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "knn_filter (f16 MFMA 32x32x16 + exact re-rank)",
-                    "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / HBM_PEAK_GBPS}
+                    "kernel": "knn_filter (f16 MFMA 32x32x16 over every pair + exact re-rank)",
+                    "flops_per_launch": flops}
         elif path_taken == 4:
-            # cell-pruned scan: ~4 % of the pairs are scored (MFMA work is no longer the bound); the kernel reads the
-            # fp16 fragments + norms of the shard once (36 B per row against the 64 B of the fp32 row the algorithmic
-            # figure counts), so `achieved` can exceed what the wires carry: hbm_frac_physical is the wire rate
-            phys = 36.0 * n_local * 1.04 + 2.0 * 128 * (n_local / 256.0)   # layout (4 % padding) + the per-cell lists
-            roof = {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": hbm_gbps / HBM_PEAK_GBPS, "traffic": None,
-                    "kernel": "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out + exact re-rank)",
-                    "physical_bytes_per_launch_estimate": phys,
-                    "hbm_frac_physical": phys / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            # cell-pruned scan: ~4 % of the pairs are scored; the kernel reads the cell-sorted fp16 layout once —
+            # 32 B of fragment + 4 B of norm per position, cells padded to whole tiles (~4 %)
+            phys = 36.0 * n_local * 1.04
+            roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
+                    "kernel": {0: "knn_cells_sweep (match + scan: f16 MFMA 32x32x16 over the cells each query could not rule out)",
+                               1: "knn_cells_scan (round-2 kernel, LDS norms)",
+                               2: "knn_cells_scan (round-2 kernel, MFMA norms)"}[args.cells_variant],
+                    "bytes_per_launch": phys, "bytes_source": "layout size (36 B per position, 4 % padding)"}
         else:
-            lane_ops = (3.0 * k + 3.0) * m * n_local
-            roof = {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": hbm_gbps / HBM_PEAK_GBPS, "traffic": None,
+            roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
                     "kernel": "knn_grid_query (uniform-grid ring search, one wave per query: latency-bound, touches a few "
                               "hundred rows per query instead of n)" if path_taken == 3 else
-                              "knn_exact (VALU-bound at this m: see valu_frac)",
-                    "valu_lane_ops_per_s": lane_ops / (kern_avg_ms * 1e-3),
-                    "valu_frac": lane_ops / (kern_avg_ms * 1e-3) / VALU_LANE_OPS_PEAK}
+                              "knn_exact (fp32 VALU scan of the rows; HBM-bound only for m <~ 10)",
+                    "bytes_per_launch": alg_bytes if path_taken != 3 else None,
+                    "bytes_source": "the fp32 rows once (SURVEY 8d)" if path_taken != 3 else
+                                    "not a streaming kernel: no byte model (see kernel_ms)"}
+            if path_taken == 1:
+                lane_ops = (3.0 * k + 3.0) * m * n_local
+                roof["valu_frac"] = lane_ops / (kern_ms_alone * 1e-3) / VALU_LANE_OPS_PEAK
         # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
         # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json).  Quoted only when the profile
         # was taken on the kernel source that is running now (the profile records the sha256 of
         # the filter / cells / exact sources); a stale profile is named, not used.
-        pmc_path = os.path.join(ROOT, "profiles", "r02_c3_pmc_traffic.json")
+        pmc_name = "r03_c3_pmc_traffic.json"
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if wname == "C3" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc_doc = json.load(f)
             if pmc_doc.get("kernel_source_sha256") == kernel_source_sha():
-                kname = {2: "_Z17knn_filter", 4: "_Z21knn_cells_scan"}.get(path_taken, "void knn_exact_qreg<16, 2>")
+                kname = {2: ("_Z17knn_filter", "void knn_filter_kernel"),
+                         4: ("_Z22knn_cells_sweep", "void knn_cells_sweep_kernel", "_Z21knn_cells_scan", "void knn_cells_scan_kernel")
+                         }.get(path_taken, ("void knn_exact_qreg<16, 2>",))
                 best = None
                 for name, ent in pmc_doc["kernels"].items():
                     if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
@@ -352,50 +379,39 @@ def main():
                             best = ent
                 if best is not None:
                     roof["traffic"] = best["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r02_c3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
-                                             "separate passes; read bytes = 2 x FETCH_SIZE KiB, gfx950); same kernel source"
-                    roof["hbm_frac_physical"] = best["hbm_bytes_per_launch"] / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                    roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; " \
+                                             "read bytes = 2 x FETCH_SIZE KiB, gfx950); same kernel source" % pmc_name
+                    if path_taken == 4:
+                        roof["bytes_per_launch"] = best["hbm_bytes_per_launch"]
+                        roof["bytes_source"] = "PMC (traffic)"
             else:
-                roof["traffic_source"] = "profiles/r02_c3_pmc_traffic.json is from another build of the kernels: not quoted"
+                roof["traffic_source"] = "profiles/%s is from another build of the kernels: not quoted" % pmc_name
+        if roof.get("bound") == "hbm":
+            bpl = roof.get("bytes_per_launch")
+            roof["achieved"] = bpl / (kern_ms_alone * 1e-3) / 1e9 if bpl else None
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS if bpl else None
+        roof["kernel_ms"] = kern_ms_alone
+        roof["kernel_ms_basis"] = "HIP events around the kernel on its stream, %d single launches, nothing else on the GPU" % alone_n
+        roof["kernel_in_pipeline_ms"] = kern_avg_ms           # a launch that shares the GPU with the other batches in flight
+        roof["kernel_launches_timed_in_pipeline"] = launches
+        roof["algorithmic_bytes_per_launch"] = alg_bytes
+        roof["algorithmic_frac_per_step"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        roof["algorithmic_frac_note"] = "SURVEY 8(d) bytes (the fp32 rows once) / ms_per_step / 8 TB/s: the north_star's figure; " \
+                                        "can exceed what the wires carry because the scan reads the fp16 layout (36 B per row, not 64)"
+        roof["serial_step_ms"] = serial_step_ms
         if path_taken == 2 and k <= 16:
-            # Where this kernel's ceiling is (profiles/r02_filter_probe.txt, r02_cvt_probe.txt): one MFMA
-            # 32x32x16 per (32 refs x 32 queries) tile pair leaves 16 fp32 scores per lane whose reduction
-            # takes 8 v_min3_f32; hand-scheduled, one wave per SIMD, that stream runs at 50-54 shader
-            # cycles per tile pair (the min3 issue at ~5 cycles each, the MFMA's issue + C-tile fetch
-            # ~10-14; the matrix pipe itself needs 32) and the chip holds ~1.8 GHz under it.
             pairs_per_simd = (n_local / 32.0) * ((m + 31) // 32) / (256 * 4)
             roof["ceiling"] = {
                 "what": "vector-issue floor of 'score every pair' at k <= 16: 1 MFMA + 8 v_min3_f32 per 32x32 tile pair",
                 "cycles_per_tile_pair": 50.0, "tile_pairs_per_simd": pairs_per_simd,
                 "ms_at_2.4GHz": pairs_per_simd * 50.0 / 2.4e9 * 1e3,
                 "ms_at_measured_clock_1.8GHz": pairs_per_simd * 50.0 / 1.8e9 * 1e3,
-                "matrix_pipe_ms_at_2.4GHz": pairs_per_simd * 32.0 / 2.4e9 * 1e3,
-                "source": "profiles/r02_filter_probe.txt (variants 21-39), profiles/r02_cvt_probe.txt",
-                "note": "the north_star's 0.70 of HBM roofline (0.19 ms) is below this floor: not reachable by a "
-                        "kernel that scores every (query, reference) pair at m = 1024, k = 16"}
-        if alone_n:
-            roof["kernel_alone_ms"] = alone_ms / alone_n      # same kernel, nothing else on the GPU
-            roof["frac_alone"] = roof["frac"] * kern_avg_ms / (alone_ms / alone_n)
-        roof["kernel_avg_ms"] = kern_avg_ms
-        roof["kernel_launches_timed"] = launches
-        chain = pkg.get_option("filter_chain") if hasattr(pkg, "get_option") else 0
-        roof["launches_overlap"] = bool(nstreams > 1 and (path_taken != 2 or chain == 2 or (chain == 0 and not long_scan)))
-        if path_taken == 4 and "hbm_frac_physical" in roof and alone_n:
-            roof["hbm_frac_physical_alone"] = roof["hbm_frac_physical"] * kern_avg_ms / (alone_ms / alone_n)
+                "source": "profiles/r02_filter_probe.txt (variants 21-39), profiles/r02_cvt_probe.txt"}
         if path_taken == 4:
-            # What the bytes allow: a bare reader of this kernel's access pattern (one 9 KiB cell + its norms and list per
-            # wave request, 12-wave blocks, the LDS fill) reaches 6.5 TB/s on the box (tools/read_probe2.hip; plain
-            # streams 6.9), i.e. 0.81 of the 8 TB/s peak is the most a launch can show for its physical bytes.
-            phys_bytes = roof.get("traffic") or roof["physical_bytes_per_launch_estimate"]
             roof["ceiling"] = {
                 "what": "HBM read rate a bare reader of the same access pattern reaches on this chip",
-                "GBps": 6500.0, "ms_for_this_launch": phys_bytes / 6500e9 * 1e3,
+                "GBps": 6500.0, "ms_for_this_launch": roof["bytes_per_launch"] / 6500e9 * 1e3,
                 "source": "tools/read_probe2.hip, tools/read_probe.hip (profiles/r02_cells_probes.txt), DESIGN 4.5"}
-        if roof["launches_overlap"]:
-            roof["note"] = "scans of consecutive batches run concurrently at this shard size: kernel_avg_ms is the " \
-                           "duration of a launch that shares the GPU with its neighbours; kernel_alone_ms / frac_alone " \
-                           "are the same kernel with the GPU to itself"
-        roof["algorithmic_bytes_per_launch"] = alg_bytes
 
         cpu = None
         cpu_all = None
@@ -409,7 +425,7 @@ def main():
             parity = parity_spot_check(k, m, n, 8, result_idx)
 
         line = {
-            "metric": "queries/sec (brute-force 1-NN, bit-exact vs v0), m=%d n=%d k=%d" % (m, n, k),
+            "metric": "queries/sec (exact 1-NN, bit-exact vs v0), m=%d n=%d k=%d" % (m, n, k),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 results (f16 MFMA filter + f32 exact re-rank)" if path_taken in (2, 4) else "f32", "data": "synthetic",
@@ -419,13 +435,15 @@ def main():
                                                      4: "cell_pruned_mfma_filter+exact_rerank"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "batches_in_flight": nstreams, "setup_steps": SETUP_STEPS,
+                       "cells_variant": args.cells_variant if path_taken == 4 else None,
+                       "keys_init": "separate launch" if args.separate_init else "inside the query (KNN_QUERY_INIT_KEYS)",
                        "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %
                                       ("gloo (one-GPU rehearsal)" if rehearse else "rccl", nbuf, m, nbuf))
                        if dist is not None else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu_all is not None:
-            line["cpu_baseline_all_cores"] = cpu_all
+            line["cpu_baseline_16_threads"] = cpu_all
         if parity:
             line["parity_spot_check"] = parity
         sys.stdout.flush()
@@ -505,7 +523,8 @@ def cpu_baseline_all_cores(k, m, n, serial_qps, gpu_idx):
     dt = time.perf_counter() - t0
     if not (want == gpu_idx[:q]).all():
         raise SystemExit("PARITY FAILURE: GPU indices differ from the CPU oracle on the all-cores sample")
-    return {"value": q / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+    return {"value": q / dt, "unit": "queries/s", "cores": cores, "kind": "port", "host_cpus": os.cpu_count(),
+            "note": "threads = min(affinity, 16): a one-GPU box's CPU share, not every core of the host",
             "sample": "first %d of %d queries against all %d refs, oracle with OpenMP over queries on %d threads, %.1f s; "
                       "GPU indices identical on the sample" % (q, m, n, cores, dt)}
 

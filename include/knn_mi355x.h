@@ -101,14 +101,21 @@ int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream)
 int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
                          unsigned long long *keys_dev, void *stream);
 
-/* Same, using query workspace `slot` (0 .. 3) of the index.  The index owns four independent
- * workspaces, so up to four batches may be in flight at once on their own streams (e.g. batch
+/* Same, using query workspace `slot` (0 .. 7) of the index.  The index owns eight independent
+ * workspaces, so up to eight batches may be in flight at once on their own streams (e.g. batch
  * i+1's small preparation kernels beside batch i's scan); calls that share a slot must be
  * stream-ordered, and one index must not be driven from two host threads at once (its event and
- * statistics bookkeeping is not locked).  A slot outside 0 .. 3 is KNN_EINVAL.
+ * statistics bookkeeping is not locked).  A slot outside 0 .. 7 is KNN_EINVAL.
  * knn_index_query_keys == slot 0. */
 int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
                               unsigned long long *keys_dev, void *stream);
+
+/* Same, with flags.  KNN_QUERY_INIT_KEYS: the call WRITES the keys — (+INF, 0) min-folded with this shard's
+ * answer — instead of folding into what keys_dev holds: the caller needs no knn_keys_init launch in front (the
+ * cell-pruned path sets the keys inside its first kernel; the other paths issue the fill themselves). */
+#define KNN_QUERY_INIT_KEYS 1u
+int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *queries_dev,
+                            unsigned long long *keys_dev, void *stream, unsigned flags);
 
 /* The path's one exchange step, for callers that keep one index per GPU in ONE process: min-reduce the
  * GPUs' key arrays with RCCL — ncclAllReduce(ncclUint64, ncclMin) per device inside
@@ -162,9 +169,13 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^20 rows (k = 13 .. 16); never for the
  *             one-shot cudaCallback (one batch does not repay the sort).  1 = every index of >= 2^17 rows,
  *             cudaCallback's shards included; 2 = never.  Read when an index is created; 2 also makes
- *             existing indexes use the full scan.  A batch the cells cannot hold (e.g. a thousand copies of
- *             one query) is answered by the exact scan and sends the index to full scans for its next 256
- *             calls.  Results are bit-exact either way
+ *             existing indexes use the full scan.  A batch the pruned path cannot bound (non-finite or
+ *             far-away queries, no reference row found to bound a query with) is answered by the exact scan;
+ *             the next batch is back on the pruned path.  Results are bit-exact either way
+ *   "cells_variant" A/B of the pruned path's kernels: 0 = prep + sweep (two launches: one wave per query for
+ *             fragments, seed scores, thresholds and pruning tables; match + scan fused, norms out of an extra
+ *             MFMA), 1 = the round-2 chain (query fragments, seed, match, scan with LDS-staged norms),
+ *             2 = prep + round-2 match / scan with MFMA norms
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the
@@ -180,6 +191,12 @@ long long knn_get_option(const char *name);
  *   [2] != 0: the device fell back to the exact scan   [3] reference rows outside the filter's
  *   robust box (scanned exactly on every query) */
 int knn_index_last_stats(knn_index *idx, long long stats[4]);
+
+/* Test / development hook: counters of the most recent batch on the cell-pruned path (call after synchronising; all 0
+ * on other paths): [0] queries whose seed cells held no reference row (their bound came from a strided sample of the
+ * layout), [1] cells whose query list outgrew its on-chip room (scored against the whole batch instead),
+ * [2] cells of the index, [3] rows of its largest cell. */
+int knn_index_debug_counters(knn_index *idx, long long out[4]);
 
 /* Test hook for the filter's error bound: raw MFMA filter scores S[m][n_local] (row-major,
  * device) for a query batch, the fp32 squared norms M[m] of the fp16 query rows (device), and

@@ -28,7 +28,9 @@ EXPORTED_SYMBOLS = [
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
     "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim", "knn_keys_allreduce_min",
+    "knn_index_query_keys_ex", "knn_index_debug_counters",
 ]
+QUERY_INIT_KEYS = 1   # KNN_QUERY_INIT_KEYS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KNN_MI355X_LIB: A/B hook — load another build of the same C-ABI (e.g. a previous commit's .so)
@@ -70,6 +72,7 @@ def lib():
     L.knn_keys_init.argtypes = [c_int, c_vp, c_int, c_vp]
     L.knn_index_query_keys.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     L.knn_index_query_keys_slot.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp]
+    L.knn_index_query_keys_ex.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint]
     L.knn_keys_to_indices.argtypes = [c_int, c_vp, c_int, c_vp, c_vp]
     L.knn_index_query_host.argtypes = [c_vp, c_int, c_vp, c_vp]
     L.knn_set_option.argtypes = [ctypes.c_char_p, c_ll]
@@ -164,11 +167,16 @@ class KnnIndex:
                                       1 if refs_on_device else 0, self.base, ctypes.c_void_p(stream)))
         self._keep = None
 
-    def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0):
+    def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0, init_keys=False):
         """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m].
-        slot 0..3 picks one of the index's four independent query workspaces."""
-        _check(lib().knn_index_query_keys_slot(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
-                                               ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream)))
+        slot 0..7 picks one of the index's eight independent query workspaces.  init_keys: the call starts the
+        keys at (+INF, 0) itself (KNN_QUERY_INIT_KEYS) instead of folding into what keys_dev holds."""
+        if init_keys:
+            _check(lib().knn_index_query_keys_ex(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
+                                                 ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream), QUERY_INIT_KEYS))
+        else:
+            _check(lib().knn_index_query_keys_slot(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
+                                                   ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream)))
 
     def query(self, queries):
         """Synchronous host-in/host-out query of this shard alone."""
@@ -183,6 +191,14 @@ class KnnIndex:
         st = (ctypes.c_longlong * 4)()
         _check(lib().knn_index_last_stats(self._h, st))
         return list(st)
+
+    def debug_counters(self):
+        """[seed cells empty, dense cells, cells, rows of the largest cell] of the last cell-pruned batch."""
+        out = (ctypes.c_longlong * 4)()
+        f = lib().knn_index_debug_counters
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+        _check(f(self._h, out))
+        return list(out)
 
     def debug_filter_scores(self, m, queries_dev, scores_dev, qnorm_dev):
         """Test hook (knn_debug_filter_scores): returns the 8 bound constants."""

@@ -70,6 +70,7 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_deepk{0};
+std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pruned path (0 prep + sweep, 1 round-2 chain, 2 prep + round-2 match / scan with MFMA norms)
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
@@ -335,6 +336,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_deepk = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "cells_variant")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: cells_variant must be 0, 1 or 2");
+        g_opt_cells_variant = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "cells")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: cells must be 0 (library policy), 1 (always) or 2 (never)");
@@ -382,6 +389,8 @@ long long knn_get_option(const char *name)
         return g_opt_ingest;
     if (name && !strcmp(name, "cells"))
         return g_opt_cells;
+    if (name && !strcmp(name, "cells_variant"))
+        return g_opt_cells_variant;
     if (name && !strcmp(name, "deepk"))
         return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -567,13 +576,26 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
 int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
                               unsigned long long *keys_dev, void *stream)
 {
-    if (!idx || m < 0 || slot < 0 || slot >= KNN_SLOTS || (m > 0 && (!queries_dev || !keys_dev)))
+    return knn_index_query_keys_ex(idx, slot, m, queries_dev, keys_dev, stream, 0u);
+}
+
+int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *queries_dev,
+                            unsigned long long *keys_dev, void *stream, unsigned flags)
+{
+    if (!idx || m < 0 || slot < 0 || slot >= KNN_SLOTS || (m > 0 && (!queries_dev || !keys_dev)) ||
+        (flags & ~(unsigned)KNN_QUERY_INIT_KEYS) != 0u)
         return fail(KNN_EINVAL, "knn_index_query_keys: bad arguments");
-    if (m == 0 || idx->n == 0)
+    if (m == 0)
         return KNN_OK;
     DeviceGuard guard(idx->device);
     if (!guard.ok)
         return fail(KNN_EHIP, "knn_index_query_keys: hipSetDevice failed");
+    const bool init_keys = (flags & KNN_QUERY_INIT_KEYS) != 0u;
+    if (idx->n == 0) {   // an empty shard leaves (+INF, 0)
+        if (init_keys)
+            HIP_TRY(knn_keys_fill_launch((u64 *)keys_dev, m, (hipStream_t)stream));
+        return KNN_OK;
+    }
     idx->stats[0] = 1;
     idx->stats[1] = 0;
     idx->stats[2] = 0;
@@ -589,6 +611,12 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         ev = &idx->events[idx->events_used++];
     }
     const long long path = g_opt_path;
+    const bool cells_live = idx->filter.cells && g_opt_cells != 2;
+    const bool use_filter = idx->filter.usable && !(idx->grid && (path == 0 || path == 3)) &&
+                            (path == 2 || (path == 0 && (m >= 5 || cells_live) && (idx->n >= 65536 || idx->filter_wanted)));
+    // the filter paths start the keys themselves when asked to (the cell-pruned one inside its first kernel)
+    if (init_keys && !use_filter)
+        HIP_TRY(knn_keys_fill_launch((u64 *)keys_dev, m, s));
     if (idx->grid && (path == 0 || path == 3)) {
         // k <= 4 spatial index: one wave per query walks the grid rings; the brute-force scan behind it is
         // gated on the "some query gave up" word (far-outside queries, empty regions)
@@ -604,9 +632,6 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         return KNN_OK;
     }
     // (with a cell-sorted layout even one query is served faster by the pruned scan than by reading the shard)
-    const bool cells_live = idx->filter.cells && !idx->filter.cells->off && g_opt_cells != 2;
-    const bool use_filter = idx->filter.usable &&
-                            (path == 2 || (path == 0 && (m >= 5 || cells_live) && (idx->n >= 65536 || idx->filter_wanted)));
     if (use_filter) {
         // the event pair brackets the MFMA filter kernel alone (the dominant kernel)
         idx->stats[0] = 2;
@@ -615,9 +640,10 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
         idx->filter.chain_policy = (int)g_opt_filter_chain;
         idx->filter.deepk_variant = (int)g_opt_deepk;
         idx->filter.cells_policy = (int)g_opt_cells;
+        idx->filter.cells_variant = (int)g_opt_cells_variant;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
-                                 idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr));
+                                 idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys));
         if (idx->filter.ws[slot].last_used_cells)
             idx->stats[0] = 4;
         return KNN_OK;
@@ -680,7 +706,7 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
     if ((idx->stats[0] == 2 || idx->stats[0] == 4) && w.ctl) {
         DeviceGuard guard(idx->device);
         unsigned ctl[KNN_CTL_WORDS];
-        HIP_TRY(hipMemcpy(ctl, w.ctl, sizeof ctl, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ctl, w.ctl_cur ? w.ctl_cur : w.ctl, sizeof ctl, hipMemcpyDeviceToHost));
         std::vector<unsigned> counts(w.nlists);
         if (!counts.empty())
             HIP_TRY(hipMemcpy(counts.data(), w.counts, counts.size() * sizeof(unsigned),
@@ -693,6 +719,24 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
         idx->stats[3] = idx->filter.n_outliers;
     }
     memcpy(stats, idx->stats, sizeof idx->stats);
+    return KNN_OK;
+}
+
+int knn_index_debug_counters(knn_index *idx, long long out[4])
+{
+    if (!idx || !out)
+        return fail(KNN_EINVAL, "knn_index_debug_counters: bad arguments");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    const FilterWorkspace &w = idx->filter.ws[idx->last_slot];
+    if (idx->stats[0] == 4 && w.ctl_cur) {
+        DeviceGuard guard(idx->device);
+        unsigned ctl[KNN_CTL_WORDS];
+        HIP_TRY(hipMemcpy(ctl, w.ctl_cur, sizeof ctl, hipMemcpyDeviceToHost));
+        out[0] = ctl[KNN_CTL_WIDE_SEEDS];
+        out[1] = ctl[KNN_CTL_DENSE_CELLS];
+        out[2] = idx->filter.cells ? idx->filter.cells->ncells : 0;
+        out[3] = idx->filter.cells ? idx->filter.cells->max_cell_rows : 0;
+    }
     return KNN_OK;
 }
 
@@ -1065,17 +1109,40 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         release_dev_keys();
         die(__FILE__, __LINE__, KNN_ENOMEM, "malloc(results)");
     }
+    bool merged_on_gpus = false;
     if (use_rccl) {
         // Final reduce on the GPUs: ncclAllReduce(uint64, min) over the shards' keys, one D2H from shard 0's device.
+        // The reduction writes to scratch buffers, never to the keys: if RCCL fails at run time (communicator
+        // creation on a node it does not like, a failed collective) and the option is 0 = "RCCL where possible", the
+        // shards' keys are still what the scans left and the host merge below takes over; `rccl` = 1 insists.
         std::vector<int> devs((size_t)shards);
         for (long long g = 0; g < shards; ++g)
             devs[(size_t)g] = (int)(g % ndev);
         std::string err;
         std::vector<u64> merged((size_t)m);
-        int rc = knn_rccl_allreduce_min((int)shards, devs.data(), shard_dev_keys.data(), m, nullptr, err);
+        std::vector<u64 *> scratch((size_t)shards, nullptr);
+        int rc = 0;
+        for (long long g = 0; g < shards && rc == 0; ++g) {
+            DeviceGuard guard(devs[(size_t)g]);
+            const hipError_t e = guard.ok ? pool_get(devs[(size_t)g], (size_t)m * sizeof(u64), (void **)&scratch[(size_t)g])
+                                          : hipErrorInvalidDevice;
+            if (e != hipSuccess) {
+                err = std::string("scratch keys for the reduction: ") + hipGetErrorString(e);
+                rc = -1;
+            }
+        }
+        // (test hook: a run-time RCCL failure, and — a one-GPU box can only reach this code with `rccl` = 1 — the
+        // fallback of the automatic mode with it)
+        const bool test_fail = getenv("KNN_MI355X_TEST_RCCL_FAIL") != nullptr;
+        if (rc == 0 && test_fail) {
+            err = "KNN_MI355X_TEST_RCCL_FAIL is set";
+            rc = -1;
+        }
+        if (rc == 0)
+            rc = knn_rccl_allreduce_min((int)shards, devs.data(), shard_dev_keys.data(), m, nullptr, err, scratch.data());
         if (rc == 0) {
             DeviceGuard guard(devs[0]);
-            const hipError_t e = hipMemcpy(merged.data(), shard_dev_keys[0], (size_t)m * sizeof(u64), hipMemcpyDeviceToHost);
+            const hipError_t e = hipMemcpy(merged.data(), scratch[0], (size_t)m * sizeof(u64), hipMemcpyDeviceToHost);
             if (e != hipSuccess) {
                 err = std::string("D2H of the reduced keys: ") + hipGetErrorString(e);
                 rc = -1;
@@ -1084,17 +1151,44 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         for (long long g = 0; g < shards; ++g) {   // nothing may still be reading the buffers going back to the pool
             DeviceGuard guard(devs[(size_t)g]);
             (void)hipStreamSynchronize(nullptr);
+            if (scratch[(size_t)g])
+                pool_put(devs[(size_t)g], scratch[(size_t)g], (size_t)m * sizeof(u64));
+        }
+        if (rc != 0 && (g_opt_rccl == 0 || test_fail)) {
+            // host merge of the (untouched) per-shard keys
+            static bool warned = false;
+            if (!warned) {
+                warned = true;
+                fprintf(stderr, "knn_mi355x: RCCL key reduction failed (%s); merging the shards' keys on the host\n", err.c_str());
+            }
+            (void)hipGetLastError();
+            for (long long g = 0; g < shards && rc != 0; ++g) {
+                DeviceGuard guard(devs[(size_t)g]);
+                shard_keys[(size_t)g].assign((size_t)m, kKeyInit);
+                const hipError_t e = hipMemcpy(shard_keys[(size_t)g].data(), shard_dev_keys[(size_t)g], (size_t)m * sizeof(u64),
+                                               hipMemcpyDeviceToHost);
+                if (e != hipSuccess) {
+                    err += std::string("; D2H of shard keys: ") + hipGetErrorString(e);
+                    rc = -2;
+                }
+            }
+            if (rc == -1)
+                rc = 1;   // keys are on the host: merge below
         }
         release_dev_keys();
-        if (rc != 0) {
+        if (rc < 0) {
             free(out);
             fail(KNN_EHIP, "cudaCallback: RCCL key reduction", err.c_str());
             die(__FILE__, __LINE__, KNN_EHIP, g_err.c_str());
         }
-        ++g_rccl_reductions;
-        for (int j = 0; j < m; ++j)
-            out[j] = (int)(unsigned)(merged[(size_t)j] & 0xFFFFFFFFull);
-    } else {
+        if (rc == 0) {
+            merged_on_gpus = true;
+            ++g_rccl_reductions;
+            for (int j = 0; j < m; ++j)
+                out[j] = (int)(unsigned)(merged[(size_t)j] & 0xFFFFFFFFull);
+        }
+    }
+    if (!merged_on_gpus) {
         // Host merge: unsigned min of packed keys == lexicographic (distance, global index).
         for (int j = 0; j < m; ++j) {
             u64 best = kKeyInit;

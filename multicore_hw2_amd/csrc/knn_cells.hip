@@ -1,12 +1,13 @@
 // knn_cells.hip — the cell-pruned form of the MFMA filter (k <= 16, resident shards; gfx950 / MI355X).
 // knn_filter.hip holds the filter it prunes: the fp16 layouts, the error bound, the full scan, the query
-// entry point that picks between the two.  Here: the cell index (build), and per batch the seed / match / scan
-// kernels that score a query only against the cells it cannot rule out.
+// entry point that picks between the two.  Here: the cell index (build), and per batch the kernels that
+// score a query only against the cells it cannot rule out.
 #include "knn_filter_dev.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------
@@ -14,24 +15,36 @@
 // cycles per 32x32 tile pair whatever the schedule, so the only way under it is not to
 // score most pairs.  The index sorts the rows into 2^B cells — every dimension cut into 2^nb[d] bins at
 // sample quantiles, cell = the tuple of bin numbers — and lays the fp16 fragments out cell by cell (each
-// cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch:
-//   seed    : every query scores its own cell and the 3 cells next to it (MFMA, same scores as the scan):
-//             the minimum is a score of a real reference, which is all knn_threshold needs.  The same
-//             kernel tabulates the query's squared gap to every bin of every dimension and, from the minimum,
-//             derives thr_q for the scores and Dup_q = the largest real (scaled) squared distance any
-//             candidate for the answer can have (knn_threshold, knn_filter_dev.h).
-//   match   : a row of cell c differs from the query by at least gap_d(bin_d(c)) in every dimension, so
-//             LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of the cell, and LB > Dup_q rules the whole
-//             cell out (ties included: a row that ties with the answer obeys the Dup bound too).  LB is separable:
-//             lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  Cell-major, no global atomics: a block owns
-//             64 consecutive cells and appends the surviving queries to their lists.
-//   scan    : a wave walks its cells; per cell it gathers the listed queries' B operands from LDS (32 per
-//             block of columns) and runs the usual MFMA + min3 tree + threshold test over the cell's tiles.
-// Uniform data in 16 dimensions, n = 2^24: ~1600 of 65536 cells survive per query, 25 queries per cell —
-// 1/25 of the MFMA work of the full scan, and the fragments are read once: the scan is HBM-bound.
-// Anything that does not fit (a list overflows, a query's seed cells are empty) raises the FALLBACK
-// flag for this batch — the gated exact scan answers it — and the host-visible `cells_off` word, after
-// which the index goes back to the full scan with the strided sample for 256 calls.
+// cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch, TWO kernels
+// (round 3; the round-2 chain was query fragments -> seed -> match -> scan, four dependent launches):
+//   prep    : one WAVE per query.  The wave rounds the query to its fp16 B operand, scores the query's own cell and
+//             the 3 cells across its two nearest cuts with the MFMA (all their tiles in flight at once) — the
+//             minimum is a score of a real reference, which is all knn_threshold needs — derives thr_q for the
+//             scores and Dup_q = the largest real (scaled) squared distance any candidate for the answer can have,
+//             and tabulates the separable halves of the cell lower bound: a row of cell c differs from the query by
+//             at least gap_d(bin_d(c)) in every dimension, so LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of
+//             the cell = lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  LB > Dup_q rules the whole cell
+//             out, ties included (a row that ties with the answer obeys the Dup bound too).  The kernel also starts
+//             the batch's keys at (+INF, 0) when asked to and clears the control words of the NEXT batch.
+//   sweep   : match + scan in one kernel.  A block owns C consecutive cells.  Phase A (the old match kernel):
+//             which queries cannot rule the cells out — queries on the lanes against the high table, survivors
+//             against 64-byte runs of the low table — appended to per-cell lists that live in LDS (a list longer
+//             than its LDS room turns the cell `dense`: every query of the batch is scored against it, which is
+//             what a list that long asks for anyway — no overflow, no fallback).  Phase B (the old scan kernel): a
+//             wave walks its cells; per cell it gathers the listed queries' B operands from LDS (32 per block of
+//             columns) and runs MFMA + min3 tree + threshold test over the cell's tiles; the first cell's tiles are
+//             requested before phase A so that HBM latency hides under it.
+// The C operand (reference norms along the query axis) no longer comes through LDS — four broadcast
+// ds_read_b128 per tile and block of queries were what bound the round-2 scan next to its bytes (12k LDS
+// instructions per CU at C3, 4k per CU for the 2^21-row shards of an 8-GPU run) — but out of the matrix core: the
+// layout keeps every norm as two fp16 halves (ref_norms2: N ~ hi + mid 2^-11, exact to 2^-22 N, folded into rho),
+// lanes 0..31 hold their row's pair as K-slots 0 and 1 of an otherwise zero A operand, and one extra MFMA against
+// the constant B operand {1, 2^-11, 0 ...} leaves N_row in every column of the accumulator the scoring MFMA
+// then continues from.  The matrix pipe has the room: the pruned scan issues 4 % of the full scan's MFMAs.
+// Uniform data in 16 dimensions, n = 2^24: ~1600 of 65536 cells survive per query, 25 queries per cell.
+// What still raises the FALLBACK flag for a batch (the gated exact scan answers it): non-finite or far-away
+// queries, a query for which neither its seed cells nor a strided sample of the layout held a single row, and a
+// wave's record slice overflowing.  Nothing switches the cells off for later batches.
 // ------------------------------------------------------------------------------------------
 #define CELL_MAX_BINS 16
 #define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts
@@ -49,6 +62,48 @@ __device__ __forceinline__ unsigned cell_bin(const float *__restrict__ bnd, int 
     for (int j = 0; j < nbins - 1; ++j)   // ascending cuts: bin b <=> bnd[b-1] <= x < bnd[b]; NaN -> bin 0
         b += x >= bnd[j] ? 1u : 0u;
     return b;
+}
+
+// ---- the norm as two fp16 halves ------------------------------------------------------------------
+// word = fp16(N) | fp16((N - fp16(N)) * 2^11) << 16.  N - fp16(N) is exact in fp32 (both are fp32 values of about
+// the same exponent), the scaled remainder keeps 11 more bits: hi + mid 2^-11 = N to within 2^-22 N, or 2^-25
+// absolute where the scaled remainder falls into fp16's subnormal range (< 2^-14) and the matrix core flushes it.
+// knn_bound_consts carries both in rho.  +INF (padding, rows outside the box) -> (+INF, 0).
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_norm22(float n)
+{
+    if (!(n < INFINITY))
+        return 0x00007C00u;
+    const _Float16 hi = (_Float16)n;
+    const float rem = n - (float)hi;
+    const _Float16 mid = (_Float16)(rem * 2048.0f);
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, mid) << 16);
+}
+
+// A operand whose rows carry (hi, mid) in K-slots 0 and 1 (nw: the row's word on lanes 0..31, ZERO on lanes 32..63,
+// which hold K-slots 8..15), and the B operand that sums them: every column = {1, 2^-11, 0, ...}.
+__device__ __forceinline__ h8 norm_a_operand(unsigned nw)
+{
+    const u4v t = {nw, 0u, 0u, 0u};
+    return __builtin_bit_cast(h8, t);
+}
+__device__ __forceinline__ h8 norm_b_operand()
+{
+    const u4v t = {0x10003C00u, 0u, 0u, 0u};   // fp16 1.0 = 0x3C00, fp16 2^-11 = 0x1000
+    return __builtin_bit_cast(h8, t);
+}
+__device__ __forceinline__ f16v zero_acc()
+{
+    return (f16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
+
+// LDS written by some lanes of a wave, read by others of the SAME wave: order the two without a block barrier.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__restrict__ R, long long n, CellGeom g,
@@ -70,16 +125,16 @@ __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__rest
 // Scatter + layout in one pass (k <= 16): row i, read in row order, goes to the next free position of its
 // cell as an fp16 fragment + norm — what knn_frag_kernel would write there (same arithmetic, same outlier
 // rule), without a second pass that gathers 64-byte rows in cell order (8.8 ms for 2^24 rows, against 1.1).
-// frag / norms / perm arrive pre-filled with the padding values (0, +INF, ~0u); out[] as in knn_frag_kernel.
+// frag / norms / norms2 / perm arrive pre-filled with the padding values (0, +INF, (+INF, 0), ~0u); out[] as in
+// knn_frag_kernel.
 __global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
     const float *__restrict__ R, long long n, int k, const unsigned *__restrict__ code,
     const unsigned *__restrict__ tile_start, unsigned *__restrict__ fill, const float *__restrict__ center, float sigma,
-    h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ perm, unsigned *__restrict__ out,
-    unsigned *__restrict__ olist, unsigned ocap)
+    h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ norms2, unsigned *__restrict__ perm,
+    unsigned *__restrict__ out, unsigned *__restrict__ olist, unsigned ocap)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float vmax = 0.0f, nrm = 0.0f;
-    unsigned bad = 0;
     if (i < n) {
         const float *__restrict__ x = R + (size_t)i * k;
         bool real = true;
@@ -111,6 +166,7 @@ __global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
         frag[(pos >> 5) * 64 + (pos & 31)] = v[0];
         frag[(pos >> 5) * 64 + 32 + (pos & 31)] = v[1];
         norms[pos] = real ? nrm : INFINITY;
+        norms2[pos] = pack_norm22(real ? nrm : INFINITY);
         perm[pos] = (unsigned)i;
     }
     vmax = wave_max_f(vmax);
@@ -125,8 +181,8 @@ __global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
         guarded_atomic_max(&out[0], __float_as_uint(fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]))));
         guarded_atomic_max(&out[1], __float_as_uint(fmaxf(fmaxf(s_n[0], s_n[1]), fmaxf(s_n[2], s_n[3]))));
     }
-    if (bad)
-        atomicAdd(&out[2], bad);
+    // (out[2], knn_frag_kernel's count of values beyond fp16's range, stays 0 here: such rows fail the |x| <= 1
+    // test above and are on the exact list)
 }
 
 __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
@@ -150,7 +206,7 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
     // thresholds (what knn_thr_kernel does for the full scan, here per block = per query)
     const float *__restrict__ qnorm, const float *__restrict__ qamax, const unsigned *__restrict__ qpart, int qblocks,
     int kt, float sigma, float bmax, float nmax, float amax_limit, float *__restrict__ thr, float *__restrict__ dup_out,
-    unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off, unsigned *__restrict__ counts, unsigned nlists)
+    unsigned *__restrict__ ctl, unsigned *__restrict__ counts, unsigned nlists)
 {
     __shared__ float s_gap[16][CELL_MAX_BINS];
     __shared__ f4v s_nrm[4][CELL_TILES_PER_PASS * 8];
@@ -331,10 +387,8 @@ __global__ __launch_bounds__(256) void knn_cells_seed_kernel(
         }
         bool bad = qbad != 0u || !(amax <= amax_limit);
         float t = -INFINITY, dupf = -INFINITY;
-        if (!bad && !(u < INFINITY)) {
+        if (!bad && !(u < INFINITY))
             bad = true;        // the seed cells held no row of the filter: cannot bound
-            *cells_off = 1u;   // the strided sample of the full scan will serve the next batches
-        }
         if (!bad) {
             const BoundConsts cst = knn_bound_consts(g.k, kt, sigma, pre_qamax, bmax, nmax);
             double dup = 0.0;
@@ -366,17 +420,19 @@ template <int CELL_MATCH_WAVES>   // 8, or 16 for shards of few cells (one block
 __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
     int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
-    unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl, unsigned *__restrict__ cells_off)
+    unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl)
 {
     __shared__ unsigned short s_q[1024];
     __shared__ float s_hv[1024], s_dq[1024];
-    __shared__ unsigned s_npass, s_wcnt[CELL_MATCH_WAVES][64];
+    __shared__ unsigned s_npass, s_flag, s_wcnt[CELL_MATCH_WAVES][64];
     // lists of up to 128 entries are put together in LDS (row stride 65 dwords: lanes appending at the same
     // depth hit different banks) and written out as whole 256-byte rows; longer ones (few, large cells) go
     // straight to memory
     __shared__ unsigned short s_list[64][130];
-    if (ctl[KNN_CTL_FALLBACK] != 0u)
-        return;
+    // (the flag is read ONCE per block: other blocks of this launch may raise it, and threads of one block must not
+    // disagree about leaving before the barriers below)
+    if (threadIdx.x == 0)
+        s_flag = ctl[KNN_CTL_FALLBACK];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned c0 = blockIdx.x * 64u;
@@ -388,6 +444,8 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     if (threadIdx.x == 0)
         s_npass = 0u;
     __syncthreads();
+    if (s_flag != 0u)
+        return;
     {   // pass 1: this wave's share of the batch (m <= 1024: 16 chunks of 64 queries over the waves)
         constexpr int U = 16 / CELL_MATCH_WAVES;
         float hv[U], dq[U];
@@ -476,10 +534,8 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
         }
     if (wib == 0) {
         cell_counts[cell] = total;
-        if (total > cap) {
+        if (total > cap)
             ctl[KNN_CTL_FALLBACK] = 1u;  // a list is cut short: the gated exact scan answers this batch
-            *cells_off = 1u;
-        }
     }
     __syncthreads();
     if (staged) {
@@ -494,21 +550,480 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     }
 }
 
-// The scan.  A block's waves share the batch's B operands and thresholds in LDS; wave w walks cells
-// [ncells w / W, ncells (w+1) / W).  Only ~4 % of the full scan's MFMA work is left (25 listed queries per
-// cell at C3), so what bounds the kernel is getting the fragments out of HBM: per cell a wave issues every
-// load it needs at once (tiles, norms, list: one round trip), and the kernel is written lean (~80 VGPRs, 12
-// waves per block) so that 5-6 waves per SIMD each have a cell in flight — ~50 MB outstanding chip-wide.
-// (Measured alternatives, C3, kernel alone: 4-wave blocks without any prefetch 0.151 ms; the next cell
-// prefetched into a second register set, 162 VGPRs / 3 waves per SIMD 0.145; that plus the C tile read once per
-// tile for up to 4 blocks of queries, 212 VGPRs / 2 waves per SIMD 0.171 — more registers per wave bought less
-// than they cost in waves.)
+// The scan (round-2 form, kept as the A/B arm `cells_variant` 1 / 2).  A block's waves share the batch's B operands
+// and thresholds in LDS; wave w takes cells w, w + W, ...  Per cell a wave issues every load it needs at once (tiles,
+// norms, list: one round trip), and the kernel is written lean (~80 VGPRs, 12 waves per block) so that 5-6 waves per
+// SIMD each have a cell in flight.
+//   NORM_MFMA = false: the C tile (norms) goes through a per-wave LDS window, four broadcast ds_read_b128 per tile
+//                      and block of queries (round 2: 0.113 ms at C3, the LDS pipe busy 0.081 ms of it)
+//   NORM_MFMA = true : the C tile comes out of one extra MFMA on the split norms (see the head of this file)
 #define CELL_SCAN_WAVES 12
 
-// (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512 — at 81, with ten
-// tiles per pass, the second block of a CU waited for the first to finish and the kernel took two rounds)
+// One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
+template <bool NORM_MFMA>
+__device__ __forceinline__ u64 cell_tile_step(const h8 &a, unsigned nw, const f4v *__restrict__ my_nrm, int p, int half,
+                                              const h8 &b, float th)
+{
+    f16v c;
+    if constexpr (NORM_MFMA) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw), norm_b_operand(), zero_acc(), 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f4v v = my_nrm[p * 8 + 2 * gq + half];
+            c[4 * gq + 0] = v[0];
+            c[4 * gq + 1] = v[1];
+            c[4 * gq + 2] = v[2];
+            c[4 * gq + 3] = v[3];
+        }
+    }
+    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    const float mn = min_tree16(d, th);
+    return __ballot(mn < th);
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 3, kernel 1 of 2: everything a batch needs before its cells can be matched — one wave per query.
+// Replaces knn_frag_kernel (queries) + knn_cells_seed_kernel + the keys-fill launch.  No block barrier: the waves of
+// a block share nothing (each has its own slice of LDS), so a wave is free to leave early.
+// ------------------------------------------------------------------------------------------
+#define CELL_PREP_WAVES 4
+#define CELL_PREP_TILES 32    // seed tiles a wave requests at once (1024 waves on 1024 SIMDs: registers are free)
+
+__global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
+    const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
+    const float *__restrict__ center, float sigma, const unsigned *__restrict__ tile_start, long long ntiles,
+    const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
+    float *__restrict__ hi_tab, float bmax, float nmax, float amax_limit, float *__restrict__ thr,
+    float *__restrict__ dup_out, unsigned *__restrict__ ctl, unsigned *__restrict__ ctl_next,
+    unsigned *__restrict__ counts, unsigned nlists, u64 *__restrict__ keys_init)
+{
+#pragma clang fp contract(off)
+    __shared__ float s_gap_all[CELL_PREP_WAVES][16][CELL_MAX_BINS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = blockIdx.x * CELL_PREP_WAVES + wib;
+    float(*s_gap)[CELL_MAX_BINS] = s_gap_all[wib];
+    // housekeeping folded in here to save launches: the record counters of the sweep, the control words of the NEXT
+    // batch on this slot (calls on a slot are stream-ordered; this batch's own words were cleared by the previous one)
+    for (unsigned i = blockIdx.x * (64u * CELL_PREP_WAVES) + (unsigned)tid; i < nlists; i += gridDim.x * (64u * CELL_PREP_WAVES))
+        counts[i] = 0u;
+    if (blockIdx.x == 0 && tid == 0) {
+        ctl_next[KNN_CTL_FALLBACK] = 0u;
+        ctl_next[KNN_CTL_RECORDS] = 0u;
+        ctl_next[KNN_CTL_WIDE_SEEDS] = 0u;
+        ctl_next[KNN_CTL_DENSE_CELLS] = 0u;
+    }
+    if (qi >= m_padded)
+        return;
+    const int half = lane >> 5;
+    const size_t frag_at = (size_t)(qi >> 5) * 64 + (size_t)half * 32 + (size_t)(qi & 31);
+    if (qi >= m) {   // padding query of the last tile: never listed, never passes
+        if ((lane & 31) == 0)
+            qfg[frag_at] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (lane == 0) {
+            thr[qi] = -INFINITY;
+            dup_out[qi] = -INFINITY;
+        }
+        return;
+    }
+    if (keys_init && lane == 0)
+        keys_init[qi] = kKeyInit;
+
+    // ---- the query as an fp16 B operand (what knn_frag_kernel writes for a query row: centred, scaled, rounded,
+    // times -2), its norm and largest coordinate.  Every lane does the whole row: the loads are wave-uniform.
+    const float *__restrict__ qrow = Q + (size_t)qi * g.k;
+    float nrm = 0.0f, amax = 0.0f;
+    bool qbad = false;
+    h8 bq;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        float sc = 0.0f;
+        if (d < g.k)
+            sc = (qrow[d] - center[d]) * sigma;   // fp32 subtract, exact power-of-two scale
+        const _Float16 hval = (_Float16)sc;       // round to nearest even
+        const float back = (float)hval;
+        qbad = qbad || !(fabsf(back) < INFINITY);
+        amax = fmaxf(amax, fabsf(back));
+        nrm = nrm + back * back;                  // exact products, fp32 sum in dimension order
+        const _Float16 v = (_Float16)(back * -2.0f);
+        qbad = qbad || !(fabsf((float)v) < INFINITY);
+        if ((d >> 3) == half)
+            bq[d & 7] = v;
+    }
+    if ((lane & 31) == 0)
+        qfg[frag_at] = bq;   // for the sweep (lanes 0 and 32 hold the two halves)
+
+    // ---- squared gaps to every bin of every dimension (scaled units, rounded down)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = lane + 64 * j;
+        const int d = e >> 4, b = e & 15;
+        float v = 0.0f;
+        if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
+            const int nbins = 1 << g.nb[d];
+            const float *__restrict__ bnd = bounds + d * (CELL_MAX_BINS - 1);
+            const double q = (double)qrow[d];
+            double gap = 0.0;
+            if (b > 0 && (double)bnd[b - 1] > q)
+                gap = (double)bnd[b - 1] - q;        // rows of the bin have x >= bnd[b-1] > q
+            if (b < nbins - 1 && q > (double)bnd[b])
+                gap = q - (double)bnd[b];            // rows of the bin have x < bnd[b] < q
+            v = __double2float_rd(gap * gap * sigma2);
+        }
+        s_gap[d][b] = v;
+    }
+    // ---- seed cells: dimensions on the lanes — the query's own bin and the neighbouring bin nearest to it
+    unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
+    float ag = INFINITY;
+    if (lane < g.k) {
+        nbl = g.nb[lane];
+        shl = g.shift[lane];
+    }
+    if (nbl) {
+        const int nbins = 1 << nbl;
+        const float *__restrict__ bnd = bounds + lane * (CELL_MAX_BINS - 1);
+        const float q = qrow[lane];
+        bin = cell_bin(bnd, nbins, q);
+        if (bin > 0u) {
+            alt = bin - 1u;
+            ag = q - bnd[bin - 1];
+        }
+        if (bin + 1u < (unsigned)nbins && !(bnd[bin] - q >= ag)) {
+            alt = bin + 1u;
+            ag = bnd[bin] - q;
+        }
+        if (!(ag >= 0.0f))
+            ag = 0.0f;
+    }
+    unsigned own = bin << shl;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+        own |= (unsigned)__shfl_xor((int)own, off, KNN_WAVE);
+    own = (unsigned)__shfl((int)own, 0, KNN_WAVE);
+    int pick[CELL_SEED_DIMS];
+    u64 key = alt != 0xFFFFFFFFu ? ((u64)__float_as_uint(ag) << 32) | (u64)lane : ~0ull;
+#pragma unroll
+    for (int j = 0; j < CELL_SEED_DIMS; ++j) {
+        u64 best = key;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 o = __shfl_xor(best, off, KNN_WAVE);
+            best = o < best ? o : best;
+        }
+        pick[j] = best == ~0ull ? -1 : (int)(best & 0xFFFFFFFFull);
+        if (lane == pick[j])
+            key = ~0ull;
+    }
+    unsigned code = own;
+    bool ok = lane < CELL_SEEDS;
+#pragma unroll
+    for (int j = 0; j < CELL_SEED_DIMS; ++j) {
+        const int pj = pick[j] < 0 ? 0 : pick[j];
+        const unsigned pa = (unsigned)__shfl((int)alt, pj, KNN_WAVE), pn = (unsigned)__shfl((int)nbl, pj, KNN_WAVE),
+                       ps = (unsigned)__shfl((int)shl, pj, KNN_WAVE);
+        if ((lane >> j) & 1) {
+            if (pick[j] < 0)
+                ok = false;
+            else
+                code = (code & ~(((1u << pn) - 1u) << ps)) | (pa << ps);
+        }
+    }
+    unsigned v_tb = 0u, v_nt = 0u;
+    if (lane < CELL_SEEDS) {   // tile range of seed cell `lane` (requested now, used after the tables)
+        v_tb = tile_start[code];
+        v_nt = ok ? tile_start[code + 1] - v_tb : 0u;
+    }
+    wave_lds_sync();   // s_gap is complete
+    // ---- the tables: double sums of the rounded-down gaps, rounded down again
+    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);
+    for (int e = lane; e < nl + nh; e += 64) {
+        const bool low = e < nl;
+        const unsigned ecode = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
+        double sum = 0.0;
+        for (int d = 0; d < g.k; ++d)
+            if (g.nb[d] && ((int)g.shift[d] < g.sa) == low)
+                sum += (double)s_gap[d][(ecode >> g.shift[d]) & ((1u << g.nb[d]) - 1u)];
+        const float v = __double2float_rd(sum);
+        if (low)
+            lo_tab[(size_t)qi * nl + e] = v;
+        else
+            hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
+    }
+    // ---- seed scores: the tiles of the four cells as ONE run, CELL_PREP_TILES requested per round trip
+    unsigned tb[CELL_SEEDS], tend[CELL_SEEDS];   // first tile of seed cell c; where its tiles end in the run
+    unsigned total = 0u;
+#pragma unroll
+    for (int c = 0; c < CELL_SEEDS; ++c) {
+        tb[c] = (unsigned)__builtin_amdgcn_readlane((int)v_tb, c);
+        total += (unsigned)__builtin_amdgcn_readlane((int)v_nt, c);
+        tend[c] = total;
+    }
+    float um = INFINITY;
+    // strided != 0: the run is every strided-th tile of the whole layout instead (the seed cells held nothing)
+    auto score_run = [&](unsigned run_tiles, unsigned strided) {
+        for (unsigned v0 = 0u; v0 < run_tiles; v0 += CELL_PREP_TILES) {
+            h8 ar[CELL_PREP_TILES];
+            unsigned nw[CELL_PREP_TILES];
+#pragma unroll
+            for (int p = 0; p < CELL_PREP_TILES; ++p) {
+                const unsigned v = v0 + (unsigned)p;   // wave-uniform
+                nw[p] = 0u;
+                if (v < run_tiles) {
+                    unsigned tile;
+                    if (strided)
+                        tile = v * strided;
+                    else {
+                        tile = tb[0] + v;
+#pragma unroll
+                        for (int c = 1; c < CELL_SEEDS; ++c)
+                            if (v >= tend[c - 1])
+                                tile = tb[c] + (v - tend[c - 1]);
+                    }
+                    ar[p] = rf[(size_t)tile * 64 + lane];
+                    if (lane < 32)
+                        nw[p] = rn2[(size_t)tile * 32 + lane];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < CELL_PREP_TILES; ++p)
+                if (v0 + (unsigned)p < run_tiles) {
+                    const f16v c = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw[p]), norm_b_operand(), zero_acc(), 0, 0, 0);
+                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], bq, c, 0, 0, 0);
+                    um = min_tree16(d, um);
+                }
+        }
+    };
+    score_run(total, 0u);
+    um = fminf(um, __shfl_xor(um, 32, KNN_WAVE));   // every column is this query: the halves hold different rows
+    if (!(um < INFINITY) && ntiles > 0) {
+        // nothing in the seed cells (a query in an empty corner of a clustered set): any real row gives a valid, if
+        // loose, bound — look at 64 tiles spread over the whole layout
+        const unsigned stride = (unsigned)(ntiles > 64 ? ntiles / 64 : 1);
+        const unsigned run = (unsigned)(ntiles > 64 ? 64 : ntiles);
+        score_run(run, stride);
+        um = fminf(um, __shfl_xor(um, 32, KNN_WAVE));
+        if (lane == 0)
+            atomicAdd(&ctl[KNN_CTL_WIDE_SEEDS], 1u);   // rare; statistics only
+    }
+    if (lane == 0) {
+        bool bad = qbad || !(amax <= amax_limit);
+        float t = -INFINITY, dupf = -INFINITY;
+        if (!bad && !(um < INFINITY))
+            bad = true;        // no row of the filter seen: cannot bound
+        if (!bad) {
+            const BoundConsts cst = knn_bound_consts(g.k, 1, sigma, amax, bmax, nmax);
+            double dup = 0.0;
+            t = knn_threshold(cst, um, nrm, &dup);
+            if (!(t < INFINITY))
+                bad = true;
+            else {
+                dup *= 1.0 + 1e-6;
+                dupf = (float)dup;
+                if ((double)dupf < dup)
+                    dupf = nextafterf(dupf, INFINITY);
+            }
+        }
+        thr[qi] = bad ? -INFINITY : t;
+        dup_out[qi] = bad ? -INFINITY : dupf;
+        if (bad)
+            ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 3, kernel 2 of 2: match + scan.  Block b owns cells [b C, (b + 1) C), C = 2^cshift <= 64 consecutive cells
+// (one entry of the high table, C consecutive entries of the low table).
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64 * W, 2) void knn_cells_sweep_kernel(
+    const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, const unsigned *__restrict__ tile_start, int cshift,
+    const h8 *__restrict__ qfg, const float *__restrict__ thrg, const float *__restrict__ dupg, int m, int m_padded,
+    const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, int sa, unsigned lcap,
+    u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
+{
+    extern __shared__ unsigned char s_dyn[];
+    // [m_padded / 32][64] B operands | [m_padded] thresholds | queue: [m_padded] hi value, [m_padded] Dup, [m_padded] query
+    // | [C][lcap] lists
+    h8 *s_qf = (h8 *)s_dyn;
+    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);
+    float *s_hv = s_thr + m_padded;
+    float *s_dq = s_hv + m_padded;
+    unsigned short *s_q = (unsigned short *)(s_dq + m_padded);
+    unsigned short *s_list = s_q + m_padded;
+    __shared__ unsigned s_cnt[64], s_npass, s_flag;
+    const int C = 1 << cshift;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned c0 = blockIdx.x << cshift;
+    if (tid == 0) {
+        s_flag = ctl[KNN_CTL_FALLBACK];   // ONCE per block: other blocks may raise it while this one runs
+        s_npass = 0u;
+    }
+    if (tid < 64)
+        s_cnt[tid] = 0u;
+    // ---- the tile ranges of this wave's cells (cell c0 + wib + W i on lane i), and the first cell's tiles on their
+    // way before the matching starts
+    const int my_cells = (C - wib + W - 1) / W;   // wave-uniform, may be 0
+    unsigned v_tb = 0u, v_te = 0u;
+    if (lane < my_cells) {
+        const unsigned cell = c0 + (unsigned)wib + (unsigned)W * (unsigned)lane;
+        v_tb = tile_start[cell];
+        v_te = tile_start[cell + 1u];
+    }
+    h8 ar[CELL_TILES_PER_PASS];
+    unsigned nw[CELL_TILES_PER_PASS];
+    auto request = [&](unsigned t0, int nt) {
+#pragma unroll
+        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+            nw[p] = 0u;
+            if (p < nt) {
+                ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
+                if (lane < 32)
+                    nw[p] = __builtin_nontemporal_load(&rn2[(size_t)(t0 + (unsigned)p) * 32 + lane]);
+            }
+        }
+    };
+    const unsigned first_tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, 0);
+    const unsigned first_te = (unsigned)__builtin_amdgcn_readlane((int)v_te, 0);
+    request(first_tb, (int)min((unsigned)CELL_TILES_PER_PASS, first_te - first_tb));
+
+    // ---- phase A.  Staging + pass 1: queries on the threads against the block's ONE high-table entry
+    for (int i = tid; i < m_padded * 2; i += 64 * W)
+        s_qf[i] = qfg[i];
+    for (int i = tid; i < m_padded; i += 64 * W)
+        s_thr[i] = thrg[i];
+    __syncthreads();   // s_npass, s_cnt, s_flag
+    if (s_flag != 0u)
+        return;        // block-uniform
+    const int nl = 1 << sa;
+    const float *__restrict__ hrow = hi_tab + (size_t)(c0 >> sa) * m_padded;
+    for (int q0 = wib * 64; q0 < m; q0 += 64 * W) {   // wave-uniform trip count
+        const int q = q0 + lane;
+        const float hv = q < m ? hrow[q] : INFINITY;
+        const float dq = q < m ? dupg[q] : -INFINITY;
+        const bool pass = q < m && !(hv > dq);
+        const u64 mask = __ballot(pass);
+        if (mask != 0ull) {
+            unsigned base = 0u;
+            if (lane == 0)
+                base = atomicAdd(&s_npass, (unsigned)__popcll(mask));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (pass) {
+                const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                s_q[pos] = (unsigned short)q;
+                s_hv[pos] = hv;
+                s_dq[pos] = dq;
+            }
+        }
+    }
+    __syncthreads();
+    // pass 2: queue entries on the lanes, the block's C low-table entries of an entry = one contiguous run (16 cells =
+    // 64 bytes per load); a cell's survivors are appended to its LDS list under an LDS counter, a ballot at a time
+    const unsigned npass = s_npass;
+    const unsigned l0 = c0 & (unsigned)(nl - 1);
+    for (unsigned e0 = (unsigned)wib * 64u; e0 < npass; e0 += 64u * W) {
+        const unsigned e = e0 + (unsigned)lane;
+        const bool live = e < npass;
+        const unsigned q = live ? s_q[e] : 0u;
+        const float hv = live ? s_hv[e] : INFINITY;
+        const float dq = live ? s_dq[e] : -INFINITY;
+        const f4v *__restrict__ lrow = (const f4v *)(lo_tab + (size_t)q * nl + l0);
+        for (int cc = 0; cc < C; cc += 16) {
+            f4v v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = (cc + 4 * j < C) ? lrow[cc / 4 + j] : (f4v){INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool pass = live && cc + j < C && !(v[j >> 2][j & 3] + hv > dq);
+                const u64 mask = __ballot(pass);
+                if (mask != 0ull) {   // wave-uniform
+                    unsigned base = 0u;
+                    if (lane == 0)
+                        base = atomicAdd(&s_cnt[cc + j], (unsigned)__popcll(mask));
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    if (pass) {
+                        const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (pos < lcap)
+                            s_list[(unsigned)(cc + j) * lcap + pos] = (unsigned short)q;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: this wave's cells
+    const unsigned wave = blockIdx.x * (unsigned)W + (unsigned)wib;
+    u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
+    unsigned cnt = 0u;
+    const int col = lane & 31, half = lane >> 5;
+    for (int i = 0; i < my_cells; ++i) {
+        const int ci = wib + W * i;
+        const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, i);
+        const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, i);
+        unsigned nq = s_cnt[ci];
+        const bool dense = nq > lcap;   // the list did not fit its LDS room: score every query of the batch
+        if (dense) {
+            nq = (unsigned)m;
+            if (lane == 0)
+                atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
+        }
+        if (nq == 0u)
+            continue;   // (a prefetched first cell nobody needs: its loads are dropped)
+        const unsigned short *list = s_list + (unsigned)ci * lcap;
+        for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
+            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
+            if (i != 0 || t0 != tb)
+                request(t0, nt);
+            for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
+                const unsigned idx = q0 + (unsigned)col;
+                const bool valid = idx < nq;
+                const unsigned qid = dense ? (valid ? idx : 0u) : (unsigned)list[valid ? idx : 0u];
+                const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
+                const float th = valid ? s_thr[qid] : -INFINITY;
+                u64 any = 0ull;
+                u64 masks[CELL_TILES_PER_PASS];
+#pragma unroll
+                for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                    masks[p] = 0ull;
+                    if (p < nt) {
+                        masks[p] = cell_tile_step<true>(ar[p], nw[p], nullptr, p, half, b, th);
+                        any |= masks[p];
+                    }
+                }
+                if (__builtin_expect(any != 0ull, 0)) {
+                    const u64 me = 1ull << lane;
+#pragma unroll
+                    for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                        const u64 mask = masks[p];
+                        if (mask != 0ull) {
+                            if (mask & me) {
+                                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                if (pos < slice)
+                                    my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
+                            }
+                            cnt += (unsigned)__popcll(mask);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        counts[wave] = cnt;
+        if (cnt > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;
+    }
+}
+
+// (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512)
+template <bool NORM_MFMA>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel(
-    const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ tile_start, unsigned ncells,
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ rn2,
+    const unsigned *__restrict__ tile_start, unsigned ncells,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
     u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
@@ -516,9 +1031,10 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
     extern __shared__ unsigned char s_dyn[];
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
-    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
-    if (ctl[KNN_CTL_FALLBACK] != 0u)
-        return;
+    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8] (LDS norms only)
+    __shared__ unsigned s_flag;
+    if (threadIdx.x == 0)
+        s_flag = ctl[KNN_CTL_FALLBACK];   // read once per block: see knn_cells_match_kernel
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (int i = threadIdx.x; i < m_padded * 2; i += 64 * CELL_SCAN_WAVES)
@@ -526,20 +1042,20 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
     for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
         s_thr[i] = thrg[i];
     __syncthreads();
+    if (s_flag != 0u)
+        return;
     f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
 
     const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
     unsigned cnt = 0u;
     const int col = lane & 31, half = lane >> 5;
-    const bool interleave = true;   // wave w takes cells w, w + W, ...: all waves read one moving window of the layout (contiguous ranges per wave: +6 %)
+    // wave w takes cells w, w + W, ...: all waves read one moving window of the layout (contiguous ranges per wave: +6 %)
     const unsigned per_wave = (ncells + nwaves - 1u) / nwaves;
-    const unsigned cbeg = interleave ? 0u : (unsigned)((u64)ncells * wave / nwaves);
-    const unsigned cend = interleave ? per_wave : (unsigned)((u64)ncells * (wave + 1u) / nwaves);
-    for (unsigned g0 = cbeg; g0 < cend; g0 += 64u) {
+    for (unsigned g0 = 0u; g0 < per_wave; g0 += 64u) {
         // counts and tile ranges of up to 64 cells, one per lane
-        const unsigned mine = interleave ? (g0 + (unsigned)lane) * nwaves + wave : g0 + (unsigned)lane;
-        const bool in = interleave ? (g0 + (unsigned)lane < per_wave && mine < ncells) : mine < cend;
+        const unsigned mine = (g0 + (unsigned)lane) * nwaves + wave;
+        const bool in = g0 + (unsigned)lane < per_wave && mine < ncells;
         unsigned v_nq = in ? cell_counts[mine] : 0u;
         const unsigned v_tb = in ? tile_start[mine] : 0u;
         const unsigned v_te = in ? tile_start[mine + 1u] : 0u;
@@ -550,27 +1066,33 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
             const unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
             const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
             const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, j);
-            const unsigned cellj = interleave ? (g0 + (unsigned)j) * nwaves + wave : g0 + (unsigned)j;
+            const unsigned cellj = (g0 + (unsigned)j) * nwaves + wave;
             const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
             // the first two blocks of the list travel with the tiles (one round trip per cell)
             const unsigned l0 = list[min((unsigned)lane, nq - 1u)];
             for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
                 const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
                 h8 ar[CELL_TILES_PER_PASS];
+                unsigned nw[CELL_TILES_PER_PASS];
 #pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                    if (p < nt)
+                for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                    nw[p] = 0u;
+                    if (p < nt) {
                         ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
-                const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
-                const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
-                const f4v n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
-                __builtin_amdgcn_wave_barrier();   // the previous pass's reads of the window are done
-                my_nrm[lane] = n0;
-                if (lane < CELL_TILES_PER_PASS * 8 - 64)
-                    my_nrm[64 + lane] = n1;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (NORM_MFMA && lane < 32)
+                            nw[p] = __builtin_nontemporal_load(&rn2[(size_t)(t0 + (unsigned)p) * 32 + lane]);
+                    }
+                }
+                if constexpr (!NORM_MFMA) {
+                    const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
+                    const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
+                    const f4v n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
+                    __builtin_amdgcn_wave_barrier();   // the previous pass's reads of the window are done
+                    my_nrm[lane] = n0;
+                    if (lane < CELL_TILES_PER_PASS * 8 - 64)
+                        my_nrm[64 + lane] = n1;
+                    wave_lds_sync();
+                }
                 for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
                     const unsigned idx = q0 + (unsigned)col;
                     const bool valid = idx < nq;
@@ -589,18 +1111,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
                     for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
                         masks[p] = 0ull;
                         if (p < nt) {
-                            f16v c;
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                const f4v v = my_nrm[p * 8 + 2 * gq + half];
-                                c[4 * gq + 0] = v[0];
-                                c[4 * gq + 1] = v[1];
-                                c[4 * gq + 2] = v[2];
-                                c[4 * gq + 3] = v[3];
-                            }
-                            const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b, c, 0, 0, 0);
-                            const float mn = min_tree16(d, th);
-                            masks[p] = __ballot(mn < th);
+                            masks[p] = cell_tile_step<NORM_MFMA>(ar[p], nw[p], my_nrm, p, half, b, th);
                             any |= masks[p];
                         }
                     }
@@ -780,9 +1291,10 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
     const long long rows_padded = st.ntiles * 32;
     FTRY(hipMemsetAsync(st.ref_frags, 0, (size_t)st.ntiles * 64 * 16, s));
     FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms, 0x7F800000, (size_t)rows_padded, s));
+    FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms2, 0x00007C00, (size_t)rows_padded, s));
     hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
-                       st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.cells->perm, out,
-                       st.outliers, ocap);
+                       st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,
+                       st.cells->perm, out, st.outliers, ocap);
     return hipGetLastError();
 }
 
@@ -793,27 +1305,22 @@ void knn_cells_workspace_free(FilterWorkspace &w)
     (void)KNN_DEV_FREE(w.dup);
     (void)KNN_DEV_FREE(w.lo_tab);
     (void)KNN_DEV_FREE(w.hi_tab);
-    if (w.cells_off)
-        (void)hipHostFree(w.cells_off);
     w.cell_counts = nullptr;
     w.cell_lists = nullptr;
     w.dup = w.lo_tab = w.hi_tab = nullptr;
-    w.cells_off = nullptr;
     w.cell_m_cap = 0;
 }
 
 // ---- per batch ---------------------------------------------------------------------------------
 
-static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m)
+static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m, bool lists_in_memory)
 {
     const CellIndex &c = *st.cells;
-    if (!w.cell_counts)
-        FTRY(KNN_DEV_ALLOC((void **)&w.cell_counts, (size_t)c.ncells * sizeof(unsigned)));
-    if (!w.cell_lists)
-        FTRY(KNN_DEV_ALLOC((void **)&w.cell_lists, (size_t)c.ncells * c.cap * sizeof(unsigned short)));
-    if (!w.cells_off) {
-        FTRY(hipHostMalloc((void **)&w.cells_off, sizeof(unsigned), hipHostMallocDefault));
-        *w.cells_off = 0u;
+    if (lists_in_memory) {   // the round-2 kernels (A/B arms) hand the lists over through memory
+        if (!w.cell_counts)
+            FTRY(KNN_DEV_ALLOC((void **)&w.cell_counts, (size_t)c.ncells * sizeof(unsigned)));
+        if (!w.cell_lists)
+            FTRY(KNN_DEV_ALLOC((void **)&w.cell_lists, (size_t)c.ncells * c.cap * sizeof(unsigned short)));
     }
     const int m_padded = (m + 31) / 32 * 32;
     if (m_padded > w.cell_m_cap) {
@@ -830,12 +1337,44 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
     return hipSuccess;
 }
 
-// One batch of <= KNN_CELL_BATCH queries (their fragments already written by the filter's query-fragment kernel):
-// seed + thresholds, match, scan.
-hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, int num_cu, bool timed,
-                           hipStream_t s)
+// Sweep geometry: cells per block (a power of two, 8 .. 64, dividing the low table) and list entries per cell in LDS
+// (16384 u16 entries = 32 KiB per block in all: a list can hold the whole batch up to 2^13 cells — 16 cells per
+// block — and 256 queries at 64 cells per block, ten times what uniform data lists at 2^16 cells).
+static void sweep_geometry(const CellIndex &c, int *cshift, unsigned *lcap)
 {
-    FTRY(ensure_cells_workspace(st, w, m));
+    int cs = c.ncells >= (1u << 15) ? 6 : c.ncells >= (1u << 14) ? 5 : c.ncells >= (1u << 11) ? 4 : 3;
+    cs = std::min(cs, c.sa);
+    *cshift = cs;
+    *lcap = std::min(1024u, 16384u >> cs);
+}
+
+template <int W>
+static hipError_t launch_sweep(FilterState &st, FilterWorkspace &w, int m, int m_padded, int cshift, unsigned lcap, hipStream_t s)
+{
+    const CellIndex &c = *st.cells;
+    const size_t lds = (size_t)m_padded * 32 + (size_t)m_padded * 4 * 3 + (size_t)m_padded * 2 + ((size_t)lcap << cshift) * 2;
+    // (dynamic LDS beyond the default limit must be asked for, per device: remembered so that the call is made once)
+    static std::atomic<size_t> lds_allowed[64];
+    int dev = 0;
+    FTRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || lds > lds_allowed[dev].load(std::memory_order_relaxed)) {
+        FTRY(hipFuncSetAttribute((const void *)knn_cells_sweep_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64)
+            lds_allowed[dev].store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(knn_cells_sweep_kernel<W>, dim3(c.ncells >> cshift), dim3(64 * W), lds, s, (const h8 *)st.ref_frags,
+                       st.ref_norms2, c.tile_start, cshift, (const h8 *)w.qry_frags, w.thr, w.dup, m, m_padded, w.lo_tab, w.hi_tab,
+                       c.sa, lcap, w.records, w.counts, w.ctl_cur, w.slice);
+    return hipGetLastError();
+}
+
+// One batch of <= KNN_CELL_BATCH queries: prep (fragments, seed scores, thresholds, tables) + sweep (match + scan);
+// records in w, as the full scan leaves them.  `cells_variant` 1 / 2 run the round-2 kernels instead (A/B).
+hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, int num_cu, bool timed,
+                           hipStream_t s, u64 *keys_init)
+{
+    const int variant = st.cells_variant;
+    FTRY(ensure_cells_workspace(st, w, m, variant != 0));
     const CellIndex &c = *st.cells;
     const int m_padded = (m + 31) / 32 * 32;
     CellGeom g;
@@ -845,52 +1384,76 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     g.sa = c.sa;
     memcpy(g.nb, c.nb, 16);
     memcpy(g.shift, c.shift, 16);
-    unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
-    if (gx * CELL_SCAN_WAVES > c.ncells)   // a wave per cell at least (holding the grid to 4 cells per wave left a third of
-        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);   // the CUs without a block at 2^13 cells: scan alone 0.052 -> 0.035 ms)
-    w.nlists = gx * CELL_SCAN_WAVES;
-    w.slice = w.rec_cap / w.nlists;
     w.has_rows = false;
     w.pieces = RerankPieces();
+    const double sigma2 = (double)st.sigma * (double)st.sigma;
 
-    hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds,
-                       (double)st.sigma * (double)st.sigma, c.tile_start, (const h8 *)st.ref_frags, st.ref_norms,
-                       (const h8 *)w.qry_frags, w.lo_tab, w.hi_tab, m_padded, w.qry_norms, w.qry_amax, w.qpart,
-                       (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup, w.ctl, w.cells_off,
-                       w.counts, w.nlists);
-    FTRY(hipGetLastError());
+    if (variant == 1) {
+        // round 2: the caller has run the query-fragment kernel (which also reset block 0 of the control words)
+        w.ctl_cur = w.ctl;
+        unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
+        if (gx * CELL_SCAN_WAVES > c.ncells)
+            gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
+        w.nlists = gx * CELL_SCAN_WAVES;
+        w.slice = w.rec_cap / w.nlists;
+        hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds, sigma2, c.tile_start,
+                           (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.lo_tab, w.hi_tab, m_padded,
+                           w.qry_norms, w.qry_amax, w.qpart, (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax,
+                           kAmaxLimit, w.thr, w.dup, w.ctl, w.counts, w.nlists);
+        FTRY(hipGetLastError());
+    } else {
+        // the control words of this batch were cleared by the previous batch on this slot (or at allocation)
+        const unsigned parity = w.cell_batches++ & 1u;
+        w.ctl_cur = w.ctl + KNN_CTL_WORDS * (1u + parity);
+        unsigned *ctl_next = w.ctl + KNN_CTL_WORDS * (2u - parity);
+        int cshift = 0;
+        unsigned lcap = 0;
+        sweep_geometry(c, &cshift, &lcap);
+        if (variant == 0) {
+            w.nlists = (c.ncells >> cshift) * 8u;
+        } else {
+            unsigned gx = (unsigned)num_cu * 2u;
+            if (gx * CELL_SCAN_WAVES > c.ncells)
+                gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
+            w.nlists = gx * CELL_SCAN_WAVES;
+        }
+        w.slice = w.rec_cap / w.nlists;
+        hipLaunchKernelGGL(knn_cells_prep_kernel, dim3((unsigned)(m_padded / CELL_PREP_WAVES)), dim3(64 * CELL_PREP_WAVES), 0, s, q, m,
+                           m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
+                           st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
+                           w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+        FTRY(hipGetLastError());
+        if (variant == 0) {
+            if (timed && w.ev_begin)
+                FTRY(hipEventRecord(w.ev_begin, s));
+            FTRY(launch_sweep<8>(st, w, m, m_padded, cshift, lcap, s));
+            if (timed && w.ev_end)
+                FTRY(hipEventRecord(w.ev_end, s));
+            return hipSuccess;
+        }
+    }
+    // round-2 match + scan (variants 1 and 2)
     if (c.ncells <= 16384u)
         hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
-                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
+                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
     else
         hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
-                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl, w.cells_off);
+                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
     FTRY(hipGetLastError());
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
+    const unsigned gx = w.nlists / CELL_SCAN_WAVES;
     const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
-    hipLaunchKernelGGL(knn_cells_scan_kernel, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, st.ref_norms,
-                       c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded, w.cell_counts, w.cell_lists, c.cap,
-                       w.records, w.counts, w.ctl, w.slice);
+    if (variant == 1)
+        hipLaunchKernelGGL(knn_cells_scan_kernel<false>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
+                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded,
+                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice);
+    else
+        hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
+                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded,
+                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice);
     FTRY(hipGetLastError());
     if (timed && w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));
-    if (getenv("KNN_MI355X_TRACE_CELLS")) {   // development aid: how long the lists of this batch are (synchronises)
-        std::vector<unsigned> hc((size_t)c.ncells);
-        FTRY(hipStreamSynchronize(s));
-        FTRY(hipMemcpy(hc.data(), w.cell_counts, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        unsigned long long sum = 0, blocks = 0, groups = 0;
-        unsigned mx = 0, nz = 0;
-        for (unsigned v : hc) {
-            sum += v;
-            blocks += (v + 31) / 32;
-            groups += (v + 127) / 128;
-            mx = std::max(mx, v);
-            nz += v != 0;
-        }
-        fprintf(stderr, "[knn cells] m %d: %u cells, %u non-empty, %llu (cell, query) pairs = %.1f per cell, longest list %u, "
-                        "%llu blocks of 32, %llu groups of 128\n", m, c.ncells, nz, sum, (double)sum / c.ncells, mx, blocks, groups);
-    }
     return hipSuccess;
 }
-

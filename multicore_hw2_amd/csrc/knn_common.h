@@ -57,10 +57,12 @@ enum {
     KNN_CTL_QNMAX = 3,     // float bits: max fp32 squared norm of the fp16 query rows
     KNN_CTL_QBAD = 4,      // != 0: a query coordinate is non-finite or out of fp16 range
     KNN_CTL_CELLS = 5,     // != 0: this batch went through the cell-pruned scan
+    KNN_CTL_WIDE_SEEDS = 6,  // cell-pruned path: queries whose seed cells held no row (bounded by a strided sample instead)
+    KNN_CTL_DENSE_CELLS = 7, // cell-pruned path: cells whose query list outgrew its LDS room (scored against the whole batch)
     KNN_CTL_WORDS = 8
 };
 
-#define KNN_SLOTS 4  // independent query workspaces per index: up to four batches may be in flight
+#define KNN_SLOTS 8  // independent query workspaces per index: up to eight batches may be in flight
 
 // Per-batch scratch of the filter path (one per slot).
 struct FilterWorkspace {
@@ -69,7 +71,12 @@ struct FilterWorkspace {
     float *qry_norms = nullptr;// device [qtiles*32]
     float *qry_amax = nullptr; // device [qtiles*32]: max |scaled fp16 coordinate| of each query
     float *thr = nullptr;      // device [qtiles*32]
-    unsigned *ctl = nullptr;   // device [KNN_CTL_WORDS]
+    unsigned *ctl = nullptr;   // device [3][KNN_CTL_WORDS]: block 0 = the full-scan path (reset by its fragment kernel);
+                               // blocks 1, 2 alternate between the batches of the cell-pruned path, whose first
+                               // kernel clears the block the NEXT batch will use (no reset launch, no race with
+                               // the flags its own waves raise)
+    unsigned *ctl_cur = nullptr; // the block the most recent batch on this slot used (statistics)
+    unsigned cell_batches = 0; // cell-pruned batches issued on this slot (picks the ctl block)
     u64 *records = nullptr;    // device [rec_cap]: nlists slices of `slice` records, one per wave
     RerankPieces pieces;
     bool has_rows = false;     // the last scan wrote a row mask next to every record
@@ -86,7 +93,6 @@ struct FilterWorkspace {
     float *dup = nullptr;                  // device [m_cap]: largest scaled squared distance a candidate can have
     float *lo_tab = nullptr, *hi_tab = nullptr;  // device [m_cap][2^sa], [2^(bits-sa)][m_cap]
     int cell_m_cap = 0;
-    unsigned *cells_off = nullptr;         // pinned host word the kernels set when the cells did not fit the batch
     bool last_used_cells = false;
 };
 
@@ -99,8 +105,6 @@ struct CellIndex {
     unsigned *tile_start = nullptr;  // device [ncells + 1]: first 32-row tile of each cell in the layout
     unsigned *perm = nullptr;        // device [ntiles * 32]: row held by each layout position (~0u = padding)
     unsigned max_cell_rows = 0;
-    bool off = false;                // a batch did not fit (list overflow, empty seed cells): full scans for a while
-    int off_calls = 0;               // query calls answered by full scans since (the cells are retried after 256)
 };
 
 struct FilterState {
@@ -114,6 +118,9 @@ struct FilterState {
     float *center = nullptr;   // device [16*kt]
     void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
     float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
+    unsigned *ref_norms2 = nullptr; // cell-sorted layouts only, device [ntiles*32]: the same norms as two fp16 halves
+                               // (hi | mid * 2^11 << 16) — the scan rebuilds its C tile from them with one extra MFMA
+                               // instead of four LDS reads (knn_cells.hip)
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
     int force_rounds = 0;      // tuning hook: filter blocks per resident slot (0 = default)
     int chain_policy = 0;      // scans of different slots: 0 auto (chained when long), 1 always chained, 2 never
@@ -122,6 +129,8 @@ struct FilterState {
     unsigned n_outliers = 0;
     CellIndex *cells = nullptr;   // non-null: the layout is cell-sorted (ntiles counts its padded tiles)
     int cells_policy = 0;         // per call: 0 use the cells when present, 2 full scan
+    int cells_variant = 0;        // A/B hook: 0 = prep + fused match/scan (default), 1 = round-2 kernels (fragments, seed,
+                                  // match, scan with LDS norms), 2 = prep + match + scan with MFMA norms
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
     // 15 % slower than back to back; only the small preparation kernels are meant to overlap.
@@ -145,8 +154,9 @@ void knn_cells_free(CellIndex *&c);
 void knn_cells_workspace_free(FilterWorkspace &w);
 // One batch of <= KNN_CELL_BATCH queries already prepared by the filter's query-fragment kernel: seed, thresholds,
 // match, scan (records in w, as the full scan leaves them).  Asynchronous.
+// keys_init (nullable): the batch's keys, set to (+INF, 0) by the first kernel of the chain (variants 0 and 2).
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q_dev, int num_cu, bool timed,
-                           hipStream_t s);
+                           hipStream_t s, u64 *keys_init);
 
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
 // (and returns hipSuccess) when the data rules the filter out.
@@ -174,7 +184,7 @@ void knn_grid_info(const GridState *gs, long long info[4]);
 int knn_rccl_available(std::string *why);
 int knn_rccl_version();
 int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m, const hipStream_t *streams,
-                           std::string &err);
+                           std::string &err, u64 *const *recv = nullptr);
 #endif
 
 // want_cells != 0: also sort the layout into cells (k <= 16, large shards; see CellIndex).
@@ -185,9 +195,10 @@ hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float
                                       hipStream_t copy, hipStream_t compute);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.
+// init_keys: the keys are written from scratch ((+INF, 0) first) instead of min-folded into what they hold.
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q_dev, const float *r_dev,
                             long long base, u64 *keys_dev, int num_cu, hipStream_t stream,
-                            hipEvent_t ev_begin, hipEvent_t ev_end);
+                            hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys = false);
 // Test hook: raw filter scores S[m][n] (row-major) and the per-query thresholds for a query
 // batch, plus {sigma, eta, rho, amax, bmax}.  Synchronous.
 hipError_t knn_filter_debug(FilterState &st, int m, const float *q_dev, const float *r_dev,

@@ -361,8 +361,7 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
                                                       unsigned *__restrict__ ctl,
                                                       const unsigned *__restrict__ qpart, int qblocks,
                                                       unsigned *__restrict__ counts, unsigned nlists,
-                                                      float *__restrict__ dup_out = nullptr,
-                                                      unsigned *__restrict__ cells_off = nullptr)
+                                                      float *__restrict__ dup_out = nullptr)
 {
     __shared__ float s_part[THR_PARTS][32];
     // housekeeping folded in here to save launches: zero the record counters of the filter pass
@@ -395,11 +394,8 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
     float t = -INFINITY;  // padding queries never pass
     float dupf = -INFINITY;
     if (i < m) {
-        if (!(u < INFINITY)) {
+        if (!(u < INFINITY))
             bad = true;  // no finite sample score: cannot bound
-            if (cells_off && qbad == 0u && amax <= amax_limit)
-                *cells_off = 1u;  // the query's seed cells were empty: the strided sample will serve the next batches
-        }
         if (!bad) {
             // the error bound of THIS query: its own coordinate magnitude, not the batch maximum
             // (one far-away query must not loosen everybody's threshold)
@@ -906,6 +902,7 @@ void knn_filter_free(FilterState &st)
     (void)KNN_DEV_FREE(st.center);
     (void)KNN_DEV_FREE(st.ref_frags);
     (void)KNN_DEV_FREE(st.ref_norms);
+    (void)KNN_DEV_FREE(st.ref_norms2);
     (void)KNN_DEV_FREE(st.outliers);
     if (st.scan_done)
         (void)hipEventDestroy(st.scan_done);
@@ -1117,6 +1114,8 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
     if (e == hipSuccess)
         e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+    if (e == hipSuccess && st.cells)
+        e = KNN_DEV_ALLOC((void **)&st.ref_norms2, (size_t)ntiles * 32 * sizeof(unsigned));
     const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);  // more outliers than this: no filter
     if (e == hipSuccess)
         e = KNN_DEV_ALLOC((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
@@ -1357,8 +1356,12 @@ hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float
 
 static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
 {
-    if (!w.ctl)
-        FTRY(KNN_DEV_ALLOC((void **)&w.ctl, KNN_CTL_WORDS * sizeof(unsigned)));
+    if (!w.ctl) {
+        // three blocks of control words (FilterWorkspace::ctl); the cell-pruned path wants its two cleared once
+        FTRY(KNN_DEV_ALLOC((void **)&w.ctl, 3 * KNN_CTL_WORDS * sizeof(unsigned)));
+        FTRY(hipMemset(w.ctl, 0, 3 * KNN_CTL_WORDS * sizeof(unsigned)));
+        w.ctl_cur = w.ctl;
+    }
     if (!w.records) {
         // 8-byte records followed by their 2-byte row masks (written by the deep-K kernel only)
         FTRY(KNN_DEV_ALLOC((void **)&w.records, (size_t)kRecordCapacity * (sizeof(u64) + sizeof(unsigned short))));
@@ -1708,45 +1711,42 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
 }
 
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
-                            u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end)
+                            u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys)
 {
     FilterWorkspace &w = st.ws[slot];
     const unsigned *perm = st.cells ? st.cells->perm : nullptr;
     const long long positions = st.cells ? st.ntiles * 32 : st.n;
-    // a batch the cells did not fit (reported through the pinned word, read here without waiting for anything)
-    // sends this index back to full scans for good
-    if (st.cells && !st.cells->off && w.cells_off && *(volatile unsigned *)w.cells_off != 0u) {
-        st.cells->off = true;
-        st.cells->off_calls = 0;
-    }
-    // ... but not for ever: one odd batch (a thousand copies of one query) should not cost every later one the
-    // pruned scan.  After 256 calls on full scans the cells get another try.
-    if (st.cells && st.cells->off && ++st.cells->off_calls > 256) {
-        st.cells->off = false;
-        for (FilterWorkspace &ws : st.ws)
-            if (ws.cells_off)
-                *(volatile unsigned *)ws.cells_off = 0u;
-    }
-    const bool cells = st.cells && !st.cells->off && st.cells_policy != 2 && st.kt == 1;
+    // Every batch decides for itself: one the cells cannot serve (a query nothing bounds, a record slice overflowing)
+    // raises its own FALLBACK flag on the device and is answered by the gated exact scan; the next batch is back on
+    // the pruned path.  (Round 2 sent the whole index to full scans for 256 calls after such a batch, on a pinned
+    // host word read here whenever the host happened to get to it.)
+    const bool cells = st.cells && st.cells_policy != 2 && st.kt == 1;
     w.last_used_cells = cells;
     w.ev_begin = ev_begin;
     w.ev_end = ev_end;
     if (cells) {
         FTRY(ensure_workspace(st, w, std::min(m, KNN_CELL_BATCH)));
+        const bool prep_inits = st.cells_variant != 1;   // the prep kernel starts the keys itself
+        if (init_keys && !prep_inits)
+            FTRY(knn_keys_fill_launch(keys, m, s));
         for (int q0 = 0; q0 < m; q0 += KNN_CELL_BATCH) {
             const int mb = std::min(KNN_CELL_BATCH, m - q0);
             const float *qb = q + (size_t)q0 * st.k;
             u64 *kb = keys + q0;
-            FTRY(prep_queries(st, w, mb, qb, s));
-            FTRY(knn_cells_query(st, w, mb, qb, num_cu, q0 == 0, s));
-            FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl,
+            if (st.cells_variant == 1)
+                FTRY(prep_queries(st, w, mb, qb, s));
+            FTRY(knn_cells_query(st, w, mb, qb, num_cu, q0 == 0, s, init_keys && prep_inits ? kb : nullptr));
+            FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl_cur,
                                    kb, w.pieces, s, perm));
             FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
-            FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl + KNN_CTL_FALLBACK, s));
+            FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
         }
         return hipSuccess;
     }
     FTRY(ensure_workspace(st, w, m));
+    w.ctl_cur = w.ctl;
+    if (init_keys)
+        FTRY(knn_keys_fill_launch(keys, m, s));
     FTRY(prep_queries(st, w, m, q, s));
     const int qtiles = (m + 31) / 32;
     switch (st.kt) {

@@ -92,6 +92,9 @@ __host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double si
     c.gam = (kp + 2.0) * u;
     const double mmax = kp * amax * amax;
     c.rho = (omega + 2.0 * c.gam) * 2.0 * (nmax + mmax) + kp * 0x1p-27;
+    // the cell-pruned scan takes the C operand from norms kept as two fp16 halves (knn_cells.hip): off by at most
+    // 2^-22 N, or 2^-25 where the low half is flushed; twice that is allowed for (always: it is a 2^-4 of omega's share)
+    c.rho += 0x1p-21 * nmax + 0x1p-24;
     c.g2 = (k + 3.0) * u * 1.0001;
     c.tau = k * 0x1p-125;
     c.sigma2 = sigma * sigma;

@@ -35,6 +35,7 @@ struct GridGeom {
     float lo[4];         // lower corner of the box
     float inv_w[4];      // cells per unit length (0 when the dimension is degenerate)
     double dlo[4], w[4]; // the same corner / cell width in double, for the stop rule
+    double slack[4];     // what a face gives away to the fp32 rounding of the rows' cell assignment (see the stop rule)
 };
 
 __device__ __forceinline__ unsigned grid_cell_of(const GridGeom &gg, const float *x, int c_out[4])
@@ -302,7 +303,12 @@ __global__ __launch_bounds__(GRID_BLOCK) void knn_grid_query_kernel(const float 
         best = mine < best ? mine : best;
         // stop rule: rows not yet seen are outside the block of rings 0..r; along the axis where they leave
         // it they are at least `lb` from the query (faces beyond the grid bound nothing: no rows out there).
-        // 1e-3 of a cell width per face covers the rounding of the rows' own cell assignment.
+        // A row's cell comes from fp32 arithmetic, t = fl(fl(x - lo) * inv_w): a row of a cell below face F
+        // (an integer) has t < F, hence x < lo + F w (1 + 2^-22) — two roundings and the rounding of inv_w itself —
+        // and a row of a cell at or above F has x >= lo + F w (1 - 2^-21).  The error grows with the face's distance
+        // from the corner, at most g w 2^-21: gg.slack[d] = (1e-3 + g 2^-21) w covers it (knn_grid_build keeps
+        // g <= 2^19 so that this stays a quarter of a cell; the 1e-3 w alone, the round-2 form, was short of it
+        // from g ~ 4000 up on a single live axis).
         double lb = INFINITY;
         bool covers_all = true;
 #pragma unroll
@@ -310,12 +316,12 @@ __global__ __launch_bounds__(GRID_BLOCK) void knn_grid_query_kernel(const float 
             if (c[d] - r > 0) {
                 covers_all = false;
                 const double face = gg.dlo[d] + (double)(c[d] - r) * gg.w[d];
-                lb = fmin(lb, (double)q[d] - face - 1e-3 * gg.w[d]);
+                lb = fmin(lb, (double)q[d] - face - gg.slack[d]);
             }
             if (c[d] + r < gg.g[d] - 1) {
                 covers_all = false;
                 const double face = gg.dlo[d] + (double)(c[d] + r + 1) * gg.w[d];
-                lb = fmin(lb, face - (double)q[d] - 1e-3 * gg.w[d]);
+                lb = fmin(lb, face - (double)q[d] - gg.slack[d]);
             }
         }
         if (covers_all) {
@@ -355,7 +361,7 @@ struct GridState {
     unsigned *orig = nullptr;    // device [n]: shard-local row number of pts[i]
     unsigned max_cell = 0;
     unsigned *giveup = nullptr;  // device [KNN_SLOTS][2]: != 0 after a query batch = some query left the grid search
-    mutable unsigned calls[KNN_SLOTS] = {0, 0, 0, 0};   // batches issued per slot (picks the slot's flag word)
+    mutable unsigned calls[KNN_SLOTS] = {};   // batches issued per slot (picks the slot's flag word)
 };
 
 void knn_grid_free(GridState *&gs)
@@ -418,7 +424,8 @@ hipError_t knn_grid_build(GridState **out, int k, long long n, const float *r, h
     if (live == 0)
         return hipSuccess;       // all rows identical
     int g = (int)floor(pow((double)n / 3.0, 1.0 / live));
-    const int gcap = live == 1 ? (1 << 22) : live == 2 ? 2048 : live == 3 ? 160 : 45;   // <= ~4M cells
+    // <= ~4M cells; one live axis: <= 2^19 so that the stop rule's rounding slack (g 2^-21 cells) stays a quarter of a cell
+    const int gcap = live == 1 ? (1 << 19) : live == 2 ? 2048 : live == 3 ? 160 : 45;
     g = g < 1 ? 1 : g > gcap ? gcap : g;
     unsigned cells = 1u;
     for (int d = 0; d < 4; ++d) {
@@ -432,6 +439,7 @@ hipError_t knn_grid_build(GridState **out, int k, long long n, const float *r, h
         gg.lo[d] = (float)lo[d];
         gg.dlo[d] = lo[d];
         gg.w[d] = hi[d] > lo[d] ? (hi[d] - lo[d]) / gg.g[d] : 1.0;
+        gg.slack[d] = (1e-3 + (double)gg.g[d] * 0x1p-21) * gg.w[d];
         gg.inv_w[d] = hi[d] > lo[d] ? (float)((double)gg.g[d] / (hi[d] - lo[d])) : 0.0f;
         if (!(gg.inv_w[d] < INFINITY))
             return hipSuccess;

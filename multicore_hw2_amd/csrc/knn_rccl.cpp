@@ -99,10 +99,11 @@ int knn_rccl_version()
     return 0;
 }
 
-// keys[g] (m packed keys on devices[g]) <- elementwise unsigned minimum over g, in place, enqueued on
-// streams[g] (null = the device's default stream).  Returns 0, or -1 with a message in err.
+// recv[g] (null array: keys[g] itself, in place) <- elementwise unsigned minimum over g of keys[g] (m packed keys on
+// devices[g]), enqueued on streams[g] (null = the device's default stream).  Returns 0, or -1 with a message in err;
+// with a separate recv the keys are never written, so a caller can still merge them another way after a failure.
 int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m, const hipStream_t *streams,
-                           std::string &err)
+                           std::string &err, u64 *const *recv)
 {
     if (ndev < 1 || !devices || !keys || m < 0) {
         err = "knn_rccl_allreduce_min: bad arguments";
@@ -135,7 +136,7 @@ int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m
             r = ncclUnhandledCudaError;
             break;
         }
-        r = g_api.AllReduce(keys[g], keys[g], (size_t)m, ncclUint64, ncclMin, comms[(size_t)g],
+        r = g_api.AllReduce(keys[g], recv ? recv[g] : keys[g], (size_t)m, ncclUint64, ncclMin, comms[(size_t)g],
                             streams ? streams[g] : (hipStream_t) nullptr);
     }
     const ncclResult_t rend = g_api.GroupEnd();

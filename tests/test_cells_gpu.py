@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells"):
+    for name in ("path", "shards", "cells", "cells_variant"):
         pkg.set_option(name, 0)
 
 
@@ -123,10 +123,33 @@ def test_batches_longer_than_one_pass_and_single_queries(oracle):
         ix.close()
 
 
-def test_a_batch_the_cells_cannot_hold_is_answered_exactly_and_switches_the_index_to_full_scans(oracle):
-    """1024 copies of one query want the same ~4 % of the cells: their lists (128 entries per cell at 2^16
-    cells) overflow.  The batch must come back exact (device-side fallback), and the index must stop using
-    the cells afterwards (the pinned flag), still exact — and pick them up again 256 calls later."""
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("k,dist", [(16, "uniform"), (16, "lattice"), (5, "copies"), (12, "queries_outside"), (8, "skewed")])
+def test_ab_arms_of_the_pruned_path_are_bit_exact_too(oracle, variant, k, dist):
+    """`cells_variant` 1 (the round-2 chain) and 2 (prep + round-2 match / scan with MFMA norms) stay selectable for
+    A/B timing: they must answer like the default."""
+    m, n = 700, (1 << 17) + 99
+    rng = np.random.default_rng(k * 77 + variant)
+    Q, R = _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("cells_variant", variant)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("cells_variant", 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"variant {variant} {dist} k={k} stats={st}")
+    assert st[0] == 4, st
+
+
+def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle):
+    """1024 copies of one query want the same ~4 % of the cells, with all 1024 on each of their lists: far beyond a
+    list's on-chip room (256 entries at 2^16 cells).  Round 2 answered such a batch with the exact scan and sent the
+    index to full scans for its next 256 calls; now the crowded cells are scored `dense` — against the whole batch,
+    which is what their lists asked for — the batch stays on the pruned path with no fallback, and so does the next."""
     k, n, m = 16, 1 << 24, 1024
     dev = torch.device("cuda:0")
     r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
@@ -142,21 +165,72 @@ def test_a_batch_the_cells_cannot_hold_is_answered_exactly_and_switches_the_inde
         R = oracle.synth(n * k, 1001)
         want_same = oracle.v0(k, Q[sel], R, threads=THREADS)
         want_var = oracle.v0(k, Qv[sel], R, threads=THREADS)
-        got, st = _query(ix, Qv)                                # a normal batch first: cells, no fallback
+        got, st = _query(ix, Qv)                                # a normal batch first
         assert st[0] == 4 and st[2] == 0, st
+        assert ix.debug_counters()[1] == 0
         np.testing.assert_array_equal(got[sel], want_var)
-        got, st = _query(ix, Q)                                 # the overflowing batch
-        assert st[0] == 4 and st[2] == 1, st
+        got, st = _query(ix, Q)                                 # the crowded batch
+        assert st[0] == 4 and st[2] == 0, st
+        assert ix.debug_counters()[1] > 0                       # some cells went dense
         assert (got == want_same[0]).all()
-        got, st = _query(ix, Qv)                                # afterwards: full scans
-        assert st[0] == 2 and st[2] == 0, st
-        np.testing.assert_array_equal(got[sel], want_var)
-        for _ in range(256):                                    # ... for 256 calls, then the cells get another try
-            got, st = _query(ix, Qv[:32])
+        got, st = _query(ix, Qv)                                # the batch after it: nothing to recover from
         assert st[0] == 4 and st[2] == 0, st
-        np.testing.assert_array_equal(got[:8], want_var[:8])
+        assert ix.debug_counters()[1] == 0
+        np.testing.assert_array_equal(got[sel], want_var)
     finally:
         ix.close()
+
+
+def test_queries_whose_seed_cells_are_empty_are_bounded_by_a_strided_sample(oracle):
+    """A hole in the data: no row has more than six of its first nine coordinates above 0.45, queries sit deep
+    inside the hole (their own cell and the cells across their nearest cuts hold nothing).  Round 2 raised the
+    fallback for such a batch (exact scan) and switched the index's cells off; now the wave looks at 64 tiles spread
+    over the layout for a (loose) bound and the batch is served by the cells."""
+    k, m, n = 16, 300, 1 << 18
+    rng = np.random.default_rng(9)
+    R = rng.random((int(n * 1.3), k), dtype=np.float32)
+    R = R[(R[:, :9] > 0.45).sum(axis=1) <= 6][:n]
+    assert len(R) == n
+    Q = rng.random((m, k), dtype=np.float32)
+    Q[:200, :9] = (0.8 + 0.19 * rng.random((200, 9))).astype(np.float32)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        wide = ix.debug_counters()[0]
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+    np.testing.assert_array_equal(got, want)
+    assert st[0] == 4 and st[2] == 0, st
+    assert wide >= 100, wide
+
+
+def test_init_keys_flag_replaces_the_keys_init_launch(oracle):
+    """KNN_QUERY_INIT_KEYS: the query starts the keys itself (inside the pruned path's first kernel; by a fill launch on
+    the other paths) — whatever the buffer held before."""
+    k, m = 16, 777
+    dev = torch.device("cuda:0")
+    for n, cells in ((1 << 18, 1), (1 << 18, 2), (5000, 0)):
+        R = oracle.synth(n * k, 71).reshape(n, k)
+        Q = oracle.synth(m * k, 72).reshape(m, k)
+        want = oracle.v0(k, Q, R, threads=THREADS)
+        pkg.set_option("cells", cells)
+        try:
+            ix = pkg.KnnIndex(k, R, base_index=10)
+        finally:
+            pkg.set_option("cells", 0)
+        try:
+            q_d = torch.from_numpy(Q).to(dev)
+            keys = torch.zeros(m, dtype=torch.int64, device=dev)          # (distance 0, index 0): would win every min
+            out = torch.empty(m, dtype=torch.int32, device=dev)
+            ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), init_keys=True)
+            pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy() - 10, want, err_msg=f"n={n} cells={cells}")
+        finally:
+            ix.close()
 
 
 def test_non_finite_queries_take_the_exact_scan_for_their_batch_only(oracle):

@@ -85,3 +85,27 @@ def test_cell_code_layout_matches_the_build_rules():
             if sa >= 6:                                   # else the build declines the cells
                 low = [d for d in range(k) if nb[d] and shift[d] < sa]
                 assert sum(nb[d] for d in low) == sa      # the low table holds whole dimensions only
+
+
+def test_norm_kept_as_two_fp16_halves_is_within_the_allowance_rho_carries():
+    """knn_cells.hip pack_norm22: N ~ fp16(N) + fp16((N - fp16(N)) * 2^11) * 2^-11, summed exactly by the matrix core.
+    knn_bound_consts allows 2^-21 Nmax + 2^-24 for it; restated in numpy over the range a norm can take (k <= 16
+    coordinates of magnitude <= 1), including the case where the matrix core flushes a subnormal low half."""
+    rng = np.random.default_rng(4)
+    n = np.concatenate([rng.random(200000) * 16.0, rng.random(200000) * 1e-3, 2.0 ** -rng.integers(0, 40, 1000),
+                        np.array([0.0, 16.0, 1.0, 2.0 ** -14, 2.0 ** -24])]).astype(np.float32)
+    hi = n.astype(np.float16)
+    rem = (n - hi.astype(np.float32)).astype(np.float32)
+    assert (rem.astype(np.float64) == n.astype(np.float64) - hi.astype(np.float64)).all()   # the subtraction is exact
+    mid = (rem * np.float32(2048.0)).astype(np.float16)
+    back = hi.astype(np.float64) + mid.astype(np.float64) * 2.0 ** -11
+    err = np.abs(back - n.astype(np.float64))
+    assert (err <= 2.0 ** -22 * n + 2.0 ** -35).all()
+    flushed = np.where(np.abs(mid.astype(np.float64)) < 2.0 ** -14, 0.0, mid.astype(np.float64))
+    err_flush = np.abs(hi.astype(np.float64) + flushed * 2.0 ** -11 - n.astype(np.float64))
+    assert (err_flush <= 2.0 ** -22 * n + 2.0 ** -25).all()
+    # the sum of the two products is exact in fp32: it fits 24 bits
+    s32 = (hi.astype(np.float32) + (mid.astype(np.float32) * np.float32(2.0 ** -11))).astype(np.float32)
+    assert (s32.astype(np.float64) == back).all()
+    # what rho allows
+    assert (np.maximum(err, err_flush) <= 2.0 ** -21 * 16.0 + 2.0 ** -24).all()

@@ -388,7 +388,7 @@ def test_workspace_slots_run_concurrent_batches_on_their_own_streams(oracle, cha
     with pytest.raises(pkg.KnnError):
         ix2 = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
         try:
-            ix2.query_keys(8, q_d[0].data_ptr(), keys[0].data_ptr(), slot=4)
+            ix2.query_keys(8, q_d[0].data_ptr(), keys[0].data_ptr(), slot=8)
         finally:
             ix2.close()
 
