@@ -54,7 +54,8 @@ def parse_args():
     ap.add_argument("--deepk", type=int, default=0, help="A/B: deep-K LDS-tiled scan, 0 = 4 waves per block, 1 = 8 waves per block")
     ap.add_argument("--cells", type=int, default=0, help="A/B: cell-sorted layouts, 0 = library policy, 1 = always (k <= 16), 2 = never")
     ap.add_argument("--cells-variant", type=int, default=0,
-                    help="A/B: kernels of the cell-pruned path, 0 = prep + sweep, 1 = the round-2 chain, 2 = prep + round-2 match / scan")
+                    help="A/B: kernels of the cell-pruned path, 0 = prep + match + scan, 1 = the round-2 chain, 2 = as 0 with MFMA norms, "
+                         "3 = prep + sweep (one persistent kernel)")
     ap.add_argument("--separate-init", action="store_true",
                     help="A/B: start the keys with a knn_keys_init launch per step instead of KNN_QUERY_INIT_KEYS")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
@@ -344,9 +345,10 @@ def main():
             # 32 B of fragment + 4 B of norm per position, cells padded to whole tiles (~4 %)
             phys = 36.0 * n_local * 1.04
             roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
-                    "kernel": {0: "knn_cells_sweep (match + scan: f16 MFMA 32x32x16 over the cells each query could not rule out)",
-                               1: "knn_cells_scan (round-2 kernel, LDS norms)",
-                               2: "knn_cells_scan (round-2 kernel, MFMA norms)"}[args.cells_variant],
+                    "kernel": {0: "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",
+                               1: "knn_cells_scan (round-2 chain in front of it)",
+                               2: "knn_cells_scan (norm tile out of an extra MFMA)",
+                               3: "knn_cells_sweep (match + scan + re-rank in one persistent kernel)"}[args.cells_variant],
                     "bytes_per_launch": phys, "bytes_source": "layout size (36 B per position, 4 % padding)"}
         else:
             roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,

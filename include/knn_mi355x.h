@@ -172,10 +172,10 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             existing indexes use the full scan.  A batch the pruned path cannot bound (non-finite or
  *             far-away queries, no reference row found to bound a query with) is answered by the exact scan;
  *             the next batch is back on the pruned path.  Results are bit-exact either way
- *   "cells_variant" A/B of the pruned path's kernels: 0 = prep + sweep (two launches: one wave per query for
- *             fragments, seed scores, thresholds and pruning tables; match + scan fused, norms out of an extra
- *             MFMA), 1 = the round-2 chain (query fragments, seed, match, scan with LDS-staged norms),
- *             2 = prep + round-2 match / scan with MFMA norms
+ *   "cells_variant" A/B of the pruned path's kernels: 0 = prep (one block per query: fragments, seed scores,
+ *             thresholds, pruning tables, keys) + match + scan; 1 = the round-2 chain (query fragments, seed, match,
+ *             scan); 2 = as 0 with the scan's norm tile out of an extra MFMA instead of LDS; 3 = prep + sweep
+ *             (match, scan and exact re-rank in one persistent kernel; an experiment, slower than 0)
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

@@ -337,8 +337,8 @@ int knn_set_option(const char *name, long long value)
         return KNN_OK;
     }
     if (!strcmp(name, "cells_variant")) {
-        if (value < 0 || value > 2)
-            return fail(KNN_EINVAL, "knn_set_option: cells_variant must be 0, 1 or 2");
+        if (value < 0 || value > 3)
+            return fail(KNN_EINVAL, "knn_set_option: cells_variant must be 0 .. 3");
         g_opt_cells_variant = value;
         return KNN_OK;
     }
@@ -714,6 +714,8 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
         long long records = 0;
         for (unsigned c : counts)
             records += c < w.slice ? c : w.slice;
+        if (idx->stats[0] == 4)   // + the shared overflow area (variant 3: the sweep re-ranks its hits itself and counts them here)
+            records += w.nlists == 0 ? ctl[KNN_CTL_RECORDS] : (ctl[KNN_CTL_RECORDS] < w.ovf_cap ? ctl[KNN_CTL_RECORDS] : w.ovf_cap);
         idx->stats[1] = records;
         idx->stats[2] = ctl[KNN_CTL_FALLBACK];
         idx->stats[3] = idx->filter.n_outliers;

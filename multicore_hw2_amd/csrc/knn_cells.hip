@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------
@@ -533,9 +534,7 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
             ++pos;
         }
     if (wib == 0) {
-        cell_counts[cell] = total;
-        if (total > cap)
-            ctl[KNN_CTL_FALLBACK] = 1u;  // a list is cut short: the gated exact scan answers this batch
+        cell_counts[cell] = total;   // (> cap: the list is cut short and the scan scores the cell against the whole batch)
     }
     __syncthreads();
     if (staged) {
@@ -583,14 +582,18 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 &a, unsigned nw, const f4
 }
 
 // ------------------------------------------------------------------------------------------
-// Round 3, kernel 1 of 2: everything a batch needs before its cells can be matched — one wave per query.
-// Replaces knn_frag_kernel (queries) + knn_cells_seed_kernel + the keys-fill launch.  No block barrier: the waves of
-// a block share nothing (each has its own slice of LDS), so a wave is free to leave early.
+// Round 3: everything a batch needs before its cells can be matched, in ONE kernel — one block of 4 waves per query.
+// Replaces knn_frag_kernel (queries) + knn_cells_seed_kernel + the keys-fill launch of round 2 (three launches, 26 us
+// back to back at 1024 queries; this one 13).  Every wave rounds the query to its fp16 B operand (cheap, and each needs
+// it), the block tabulates the squared gaps and the two pruning tables with all 256 threads, wave w scores seed cell w
+// (own cell + the cells across the two nearest cuts) with all its tiles in flight at once, and thread 0 turns the best
+// score into thr_q and Dup_q.  (One WAVE per query, the first form of this kernel, took 24 us: 34 seed tiles and 288
+// table entries in one serial stream per query.)
 // ------------------------------------------------------------------------------------------
 #define CELL_PREP_WAVES 4
-#define CELL_PREP_TILES 32    // seed tiles a wave requests at once (1024 waves on 1024 SIMDs: registers are free)
+#define CELL_PREP_TILES 9     // seed tiles a wave requests at once (a cell of 144 .. 288 rows: one round trip)
 
-__global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
+__global__ __launch_bounds__(64 * CELL_PREP_WAVES, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
     const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
     const float *__restrict__ center, float sigma, const unsigned *__restrict__ tile_start, long long ntiles,
     const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
@@ -599,12 +602,12 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
     unsigned *__restrict__ counts, unsigned nlists, u64 *__restrict__ keys_init)
 {
 #pragma clang fp contract(off)
-    __shared__ float s_gap_all[CELL_PREP_WAVES][16][CELL_MAX_BINS];
+    __shared__ float s_gap[16][CELL_MAX_BINS];
+    __shared__ float s_red[CELL_PREP_WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qi = blockIdx.x * CELL_PREP_WAVES + wib;
-    float(*s_gap)[CELL_MAX_BINS] = s_gap_all[wib];
-    // housekeeping folded in here to save launches: the record counters of the sweep, the control words of the NEXT
+    const int qi = blockIdx.x;
+    // housekeeping folded in here to save launches: the record counters of the scan, the control words of the NEXT
     // batch on this slot (calls on a slot are stream-ordered; this batch's own words were cleared by the previous one)
     for (unsigned i = blockIdx.x * (64u * CELL_PREP_WAVES) + (unsigned)tid; i < nlists; i += gridDim.x * (64u * CELL_PREP_WAVES))
         counts[i] = 0u;
@@ -614,20 +617,18 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
         ctl_next[KNN_CTL_WIDE_SEEDS] = 0u;
         ctl_next[KNN_CTL_DENSE_CELLS] = 0u;
     }
-    if (qi >= m_padded)
-        return;
     const int half = lane >> 5;
     const size_t frag_at = (size_t)(qi >> 5) * 64 + (size_t)half * 32 + (size_t)(qi & 31);
-    if (qi >= m) {   // padding query of the last tile: never listed, never passes
-        if ((lane & 31) == 0)
+    if (qi >= m) {   // padding query of the last tile (block-uniform): never listed, never passes
+        if (wib == 0 && (lane & 31) == 0)
             qfg[frag_at] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (lane == 0) {
+        if (tid == 0) {
             thr[qi] = -INFINITY;
             dup_out[qi] = -INFINITY;
         }
         return;
     }
-    if (keys_init && lane == 0)
+    if (keys_init && tid == 0)
         keys_init[qi] = kKeyInit;
 
     // ---- the query as an fp16 B operand (what knn_frag_kernel writes for a query row: centred, scaled, rounded,
@@ -651,14 +652,12 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
         if ((d >> 3) == half)
             bq[d & 7] = v;
     }
-    if ((lane & 31) == 0)
-        qfg[frag_at] = bq;   // for the sweep (lanes 0 and 32 hold the two halves)
+    if (wib == 0 && (lane & 31) == 0)
+        qfg[frag_at] = bq;   // for the scan (lanes 0 and 32 hold the two halves)
 
-    // ---- squared gaps to every bin of every dimension (scaled units, rounded down)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = lane + 64 * j;
-        const int d = e >> 4, b = e & 15;
+    // ---- squared gaps to every bin of every dimension (scaled units, rounded down): one entry per thread
+    {
+        const int d = tid >> 4, b = tid & 15;
         float v = 0.0f;
         if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
             const int nbins = 1 << g.nb[d];
@@ -673,7 +672,8 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
         }
         s_gap[d][b] = v;
     }
-    // ---- seed cells: dimensions on the lanes — the query's own bin and the neighbouring bin nearest to it
+    // ---- seed cells (every wave works them out; wave w then takes cell w): dimensions on the lanes — the query's own
+    // bin and the neighbouring bin nearest to it
     unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
     float ag = INFINITY;
     if (lane < g.k) {
@@ -734,34 +734,35 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
         v_tb = tile_start[code];
         v_nt = ok ? tile_start[code + 1] - v_tb : 0u;
     }
-    wave_lds_sync();   // s_gap is complete
-    // ---- the tables: double sums of the rounded-down gaps, rounded down again
-    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);
-    for (int e = lane; e < nl + nh; e += 64) {
-        const bool low = e < nl;
+    __syncthreads();   // s_gap is complete
+    // ---- the tables: double sums of the rounded-down gaps, rounded down again.  (Bits and positions of the dimensions
+    // come from the lanes that hold them — nbl, shl above — as wave-uniform values: indexing the geometry struct with a
+    // run-time d is a dependent scalar load from the kernel arguments per dimension and entry.)
+    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);   // nl >= 64: a wave's entries are all low or all high
+    for (int e0 = 64 * wib; e0 < nl + nh; e0 += 64 * CELL_PREP_WAVES) {
+        const int e = e0 + lane;
+        const bool low = e0 < nl;   // wave-uniform
         const unsigned ecode = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
         double sum = 0.0;
-        for (int d = 0; d < g.k; ++d)
-            if (g.nb[d] && ((int)g.shift[d] < g.sa) == low)
-                sum += (double)s_gap[d][(ecode >> g.shift[d]) & ((1u << g.nb[d]) - 1u)];
-        const float v = __double2float_rd(sum);
-        if (low)
-            lo_tab[(size_t)qi * nl + e] = v;
-        else
-            hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
-    }
-    // ---- seed scores: the tiles of the four cells as ONE run, CELL_PREP_TILES requested per round trip
-    unsigned tb[CELL_SEEDS], tend[CELL_SEEDS];   // first tile of seed cell c; where its tiles end in the run
-    unsigned total = 0u;
 #pragma unroll
-    for (int c = 0; c < CELL_SEEDS; ++c) {
-        tb[c] = (unsigned)__builtin_amdgcn_readlane((int)v_tb, c);
-        total += (unsigned)__builtin_amdgcn_readlane((int)v_nt, c);
-        tend[c] = total;
+        for (int d = 0; d < 16; ++d) {
+            const unsigned nbd = (unsigned)__builtin_amdgcn_readlane((int)nbl, d);
+            const unsigned shd = (unsigned)__builtin_amdgcn_readlane((int)shl, d);
+            if (nbd != 0u && ((int)shd < g.sa) == low)   // wave-uniform
+                sum += (double)s_gap[d][(ecode >> shd) & ((1u << nbd) - 1u)];
+        }
+        const float v = __double2float_rd(sum);
+        if (e < nl + nh) {
+            if (low)
+                lo_tab[(size_t)qi * nl + e] = v;
+            else
+                hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
+        }
     }
+    // ---- seed scores: wave w scores the tiles of seed cell w, CELL_PREP_TILES requested per round trip
     float um = INFINITY;
-    // strided != 0: the run is every strided-th tile of the whole layout instead (the seed cells held nothing)
-    auto score_run = [&](unsigned run_tiles, unsigned strided) {
+    // stride != 0: tiles first, first + stride, ... instead of a contiguous run
+    auto score_run = [&](unsigned first, unsigned run_tiles, unsigned stride) __attribute__((always_inline)) {
         for (unsigned v0 = 0u; v0 < run_tiles; v0 += CELL_PREP_TILES) {
             h8 ar[CELL_PREP_TILES];
             unsigned nw[CELL_PREP_TILES];
@@ -770,16 +771,7 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
                 const unsigned v = v0 + (unsigned)p;   // wave-uniform
                 nw[p] = 0u;
                 if (v < run_tiles) {
-                    unsigned tile;
-                    if (strided)
-                        tile = v * strided;
-                    else {
-                        tile = tb[0] + v;
-#pragma unroll
-                        for (int c = 1; c < CELL_SEEDS; ++c)
-                            if (v >= tend[c - 1])
-                                tile = tb[c] + (v - tend[c - 1]);
-                    }
+                    const unsigned tile = first + v * stride;
                     ar[p] = rf[(size_t)tile * 64 + lane];
                     if (lane < 32)
                         nw[p] = rn2[(size_t)tile * 32 + lane];
@@ -794,27 +786,43 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
                 }
         }
     };
-    score_run(total, 0u);
-    um = fminf(um, __shfl_xor(um, 32, KNN_WAVE));   // every column is this query: the halves hold different rows
-    if (!(um < INFINITY) && ntiles > 0) {
+    score_run((unsigned)__builtin_amdgcn_readlane((int)v_tb, wib), (unsigned)__builtin_amdgcn_readlane((int)v_nt, wib), 1u);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)   // (every column is this query; the halves hold different rows)
+        um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
+    if (lane == 0)
+        s_red[wib] = um;
+    __syncthreads();
+    float u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    if (!(u < INFINITY) && ntiles > 0) {   // block-uniform
         // nothing in the seed cells (a query in an empty corner of a clustered set): any real row gives a valid, if
-        // loose, bound — look at 64 tiles spread over the whole layout
+        // loose, bound — look at 64 tiles spread over the whole layout, 16 per wave
+        __syncthreads();   // s_red has been read by everybody
+        const unsigned total = (unsigned)(ntiles > 64 ? 64 : ntiles);
         const unsigned stride = (unsigned)(ntiles > 64 ? ntiles / 64 : 1);
-        const unsigned run = (unsigned)(ntiles > 64 ? 64 : ntiles);
-        score_run(run, stride);
-        um = fminf(um, __shfl_xor(um, 32, KNN_WAVE));
+        const unsigned mine_first = (unsigned)wib * 16u;   // (two passes of CELL_PREP_TILES)
+        um = INFINITY;
+        if (mine_first < total)
+            score_run(mine_first * stride, min(16u, total - mine_first), stride);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
         if (lane == 0)
+            s_red[wib] = um;
+        __syncthreads();
+        u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+        if (tid == 0)
             atomicAdd(&ctl[KNN_CTL_WIDE_SEEDS], 1u);   // rare; statistics only
     }
-    if (lane == 0) {
+    if (tid == 0) {
         bool bad = qbad || !(amax <= amax_limit);
         float t = -INFINITY, dupf = -INFINITY;
-        if (!bad && !(um < INFINITY))
+        if (!bad && !(u < INFINITY))
             bad = true;        // no row of the filter seen: cannot bound
         if (!bad) {
             const BoundConsts cst = knn_bound_consts(g.k, 1, sigma, amax, bmax, nmax);
             double dup = 0.0;
-            t = knn_threshold(cst, um, nrm, &dup);
+            t = knn_threshold(cst, u, nrm, &dup);
             if (!(t < INFINITY))
                 bad = true;
             else {
@@ -832,191 +840,396 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES) void knn_cells_prep_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Round 3, kernel 2 of 2: match + scan.  Block b owns cells [b C, (b + 1) C), C = 2^cshift <= 64 consecutive cells
-// (one entry of the high table, C consecutive entries of the low table).
+// Round 3, kernel 2 of 2: match + scan + exact re-rank.  One block of W waves per CU (or fewer, larger shares on small
+// shards); block b owns C = 2^cshift consecutive cells [b C, (b + 1) C): one entry of the high table, C consecutive
+// entries of the low table.
+//   phase A  pass 1: every query of the batch against the block's high-table entry -> a queue in LDS (about a third
+//            survive on uniform data); pass 2: queue entries on the lanes, the block's low-table entries of an entry
+//            are one contiguous run, 16 cells (64 bytes) per load; survivors are appended to per-cell lists in LDS, the
+//            16 list counters of a run advanced by ONE LDS atomic (16 lanes, one counter each).
+//   phase B  waves take cells from a block-wide counter.  Per cell: tiles + norm words (HBM, once) and the listed
+//            queries' B operands + thresholds (gathered from L2, 32 per block of columns, up to 4 blocks at a time) are
+//            requested together; per tile ONE norm MFMA serves the 4 blocks of queries, each block = one scoring MFMA +
+//            the 8-op min3 tree + one compare.
+//   hits     (rare: ~3 per 1000 tile steps) are re-ranked on the spot: 16 lanes evaluate the 16 rows of the hit with
+//            the exact v0 arithmetic (reference core.cu:44-49) on the original fp32 rows and fold the best into the
+//            query's packed key — no record buffers, no second kernel.
 // ------------------------------------------------------------------------------------------
+#define SWEEP_HITQ 256   // pending hits a wave can hold between two re-rank passes
+#define SWEEP_QB 2   // blocks of 32 listed queries scored per norm MFMA (4: 64 accumulator registers — with the second tile set that is more than 2 waves per SIMD can hold)
+
 template <int W>
-__global__ __launch_bounds__(64 * W, 2) void knn_cells_sweep_kernel(
+__global__ __launch_bounds__(64 * W, (W <= 8 ? 2 : W <= 12 ? 3 : 4)) void knn_cells_sweep_kernel(   // (HIP: the second number is waves per SIMD)
     const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, const unsigned *__restrict__ tile_start, int cshift,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, const float *__restrict__ dupg, int m, int m_padded,
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, int sa, unsigned lcap,
-    u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
+    const float *__restrict__ Q, const float *__restrict__ R, const unsigned *__restrict__ perm, long long npos, int k,
+    long long base, u64 *__restrict__ keys, unsigned *__restrict__ ctl, u64 *__restrict__ stamps, unsigned dbg)
 {
-    extern __shared__ unsigned char s_dyn[];
-    // [m_padded / 32][64] B operands | [m_padded] thresholds | queue: [m_padded] hi value, [m_padded] Dup, [m_padded] query
-    // | [C][lcap] lists
+#pragma clang fp contract(off)
+    // (stamps: development aid, normally null — per wave the 100 MHz wall clock at the phase boundaries)
+#define SWEEP_STAMP(i)                                                                  \
+    do {                                                                                \
+        if (stamps && (threadIdx.x & 63) == 0)                                          \
+            stamps[((size_t)blockIdx.x * W + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+    extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];
+    // [m_padded / 32][64] B operands | [m_padded] thresholds | [C + 1] first tile of each cell | [C] list lengths |
+    // queue: [m_padded] hi value, [m_padded] Dup, [m_padded] query | [W][64] pending hits | [C][lcap] lists
+    const int C = 1 << cshift;
     h8 *s_qf = (h8 *)s_dyn;
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);
-    float *s_hv = s_thr + m_padded;
+    unsigned *s_tile = (unsigned *)(s_thr + m_padded);
+    unsigned *s_cnt = s_tile + (C + 64);
+    unsigned short *s_order = (unsigned short *)(s_cnt + C);   // [C] cells in the order they are handed out
+    float *s_hv = (float *)(s_order + 2 * C);
     float *s_dq = s_hv + m_padded;
-    unsigned short *s_q = (unsigned short *)(s_dq + m_padded);
+    u64 *s_hits = (u64 *)(s_dq + m_padded);
+    u64 *s_mq = s_hits + W * SWEEP_HITQ;   // [W][2 * CELL_TILES_PER_PASS * SWEEP_QB]: (mask, tile << 1 | block) of the steps that had hits
+    unsigned short *s_q = (unsigned short *)(s_mq + W * 2 * CELL_TILES_PER_PASS * SWEEP_QB);
     unsigned short *s_list = s_q + m_padded;
-    __shared__ unsigned s_cnt[64], s_npass, s_flag;
-    const int C = 1 << cshift;
+    __shared__ unsigned s_npass, s_flag, s_next;
+    constexpr int T = 64 * W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned c0 = blockIdx.x << cshift;
+    SWEEP_STAMP(0);
+    const unsigned long long clk0 = stamps ? __builtin_readcyclecounter() : 0ull;   // shader clock (s_memtime)
+    // ---- everything phase A needs from memory, requested at once
     if (tid == 0) {
-        s_flag = ctl[KNN_CTL_FALLBACK];   // ONCE per block: other blocks may raise it while this one runs
+        s_flag = ctl[KNN_CTL_FALLBACK];   // ONCE per block (set by the prep kernel only: bad or unboundable queries)
         s_npass = 0u;
+        s_next = 0u;
     }
-    if (tid < 64)
-        s_cnt[tid] = 0u;
-    // ---- the tile ranges of this wave's cells (cell c0 + wib + W i on lane i), and the first cell's tiles on their
-    // way before the matching starts
-    const int my_cells = (C - wib + W - 1) / W;   // wave-uniform, may be 0
-    unsigned v_tb = 0u, v_te = 0u;
-    if (lane < my_cells) {
-        const unsigned cell = c0 + (unsigned)wib + (unsigned)W * (unsigned)lane;
-        v_tb = tile_start[cell];
-        v_te = tile_start[cell + 1u];
-    }
-    h8 ar[CELL_TILES_PER_PASS];
-    unsigned nw[CELL_TILES_PER_PASS];
-    auto request = [&](unsigned t0, int nt) {
-#pragma unroll
-        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-            nw[p] = 0u;
-            if (p < nt) {
-                ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
-                if (lane < 32)
-                    nw[p] = __builtin_nontemporal_load(&rn2[(size_t)(t0 + (unsigned)p) * 32 + lane]);
-            }
-        }
-    };
-    const unsigned first_tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, 0);
-    const unsigned first_te = (unsigned)__builtin_amdgcn_readlane((int)v_te, 0);
-    request(first_tb, (int)min((unsigned)CELL_TILES_PER_PASS, first_te - first_tb));
-
-    // ---- phase A.  Staging + pass 1: queries on the threads against the block's ONE high-table entry
-    for (int i = tid; i < m_padded * 2; i += 64 * W)
+    for (int i = tid; i <= C; i += T)
+        s_tile[i] = tile_start[c0 + (unsigned)i];
+    for (int i = tid; i < C; i += T)
+        s_cnt[i] = 0u;
+    for (int i = tid; i < m_padded * 2; i += T)   // the batch's B operands and thresholds: gathered per cell below
         s_qf[i] = qfg[i];
-    for (int i = tid; i < m_padded; i += 64 * W)
+    for (int i = tid; i < m_padded; i += T)
         s_thr[i] = thrg[i];
-    __syncthreads();   // s_npass, s_cnt, s_flag
-    if (s_flag != 0u)
-        return;        // block-uniform
     const int nl = 1 << sa;
     const float *__restrict__ hrow = hi_tab + (size_t)(c0 >> sa) * m_padded;
-    for (int q0 = wib * 64; q0 < m; q0 += 64 * W) {   // wave-uniform trip count
-        const int q = q0 + lane;
-        const float hv = q < m ? hrow[q] : INFINITY;
-        const float dq = q < m ? dupg[q] : -INFINITY;
-        const bool pass = q < m && !(hv > dq);
+    constexpr int U = (KNN_CELL_BATCH + T - 1) / T;
+    float hv[U], dq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = u * T + tid;
+        hv[u] = q < m ? hrow[q] : INFINITY;
+        dq[u] = q < m ? dupg[q] : -INFINITY;
+    }
+    __syncthreads();
+    SWEEP_STAMP(1);
+    if (__builtin_amdgcn_readfirstlane((int)s_flag) != 0)
+        return;        // block-uniform: the gated exact scan answers this batch
+    // ---- phase A, pass 1
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = u * T + tid;
+        const bool pass = q < m && !(hv[u] > dq[u]);
         const u64 mask = __ballot(pass);
-        if (mask != 0ull) {
-            unsigned base = 0u;
+        if (mask != 0ull) {   // wave-uniform
+            unsigned at = 0u;
             if (lane == 0)
-                base = atomicAdd(&s_npass, (unsigned)__popcll(mask));
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                at = atomicAdd(&s_npass, (unsigned)__popcll(mask));
+            at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
             if (pass) {
-                const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                const unsigned pos = at + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 s_q[pos] = (unsigned short)q;
-                s_hv[pos] = hv;
-                s_dq[pos] = dq;
+                s_hv[pos] = hv[u];
+                s_dq[pos] = dq[u];
             }
         }
     }
     __syncthreads();
-    // pass 2: queue entries on the lanes, the block's C low-table entries of an entry = one contiguous run (16 cells =
-    // 64 bytes per load); a cell's survivors are appended to its LDS list under an LDS counter, a ballot at a time
-    const unsigned npass = s_npass;
+    SWEEP_STAMP(2);
+    // ---- phase A, pass 2
+    const unsigned npass = (unsigned)__builtin_amdgcn_readfirstlane((int)s_npass);
     const unsigned l0 = c0 & (unsigned)(nl - 1);
     for (unsigned e0 = (unsigned)wib * 64u; e0 < npass; e0 += 64u * W) {
         const unsigned e = e0 + (unsigned)lane;
         const bool live = e < npass;
         const unsigned q = live ? s_q[e] : 0u;
-        const float hv = live ? s_hv[e] : INFINITY;
-        const float dq = live ? s_dq[e] : -INFINITY;
+        const float ehv = live ? s_hv[e] : INFINITY;
+        const float edq = live ? s_dq[e] : -INFINITY;
         const f4v *__restrict__ lrow = (const f4v *)(lo_tab + (size_t)q * nl + l0);
-        for (int cc = 0; cc < C; cc += 16) {
-            f4v v[4];
+        for (int cc = 0; cc < C; cc += 32) {   // C is a multiple of 16; 32 cells = 128 bytes of the entry's run per round trip
+            f4v v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v[j] = (cc + 4 * j < C) ? lrow[cc / 4 + j] : (f4v){INFINITY, INFINITY, INFINITY, INFINITY};
+            for (int j = 0; j < 8; ++j)
+                v[j] = cc + 4 * j < C ? lrow[cc / 4 + j] : (f4v){INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool pass = live && cc + j < C && !(v[j >> 2][j & 3] + hv > dq);
-                const u64 mask = __ballot(pass);
-                if (mask != 0ull) {   // wave-uniform
-                    unsigned base = 0u;
-                    if (lane == 0)
-                        base = atomicAdd(&s_cnt[cc + j], (unsigned)__popcll(mask));
-                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                    if (pass) {
-                        const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (pos < lcap)
-                            s_list[(unsigned)(cc + j) * lcap + pos] = (unsigned short)q;
-                    }
+            for (int hh = 0; hh < 2; ++hh) {
+                if (cc + 16 * hh >= C)   // wave-uniform
+                    break;
+                u64 mk[16];
+                unsigned mycount = 0u;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    mk[j] = __ballot(live && !(v[4 * hh + (j >> 2)][j & 3] + ehv > edq));
+                    if (lane == j)
+                        mycount = (unsigned)__popcll(mk[j]);
                 }
+                unsigned mybase = 0u;
+                if (lane < 16 && mycount != 0u)
+                    mybase = atomicAdd(&s_cnt[cc + 16 * hh + lane], mycount);   // one LDS atomic instruction for the 16 counters
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (mk[j] != 0ull) {   // wave-uniform
+                        const unsigned bj = (unsigned)__builtin_amdgcn_readlane((int)mybase, j);
+                        if ((mk[j] >> lane) & 1ull) {
+                            const unsigned pos = bj + __builtin_amdgcn_mbcnt_hi((unsigned)(mk[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[j], 0u));
+                            if (pos < lcap)
+                                s_list[(unsigned)(cc + 16 * hh + j) * lcap + pos] = (unsigned short)q;
+                        }
+                    }
             }
         }
     }
+    // Longest first: the cells are handed out in descending order of work (listed queries x tiles), so that the last
+    // cells taken are the short ones and the waves of a block finish together (lists run from a few dozen to a few
+    // hundred queries; in index order the slowest wave of a block finished at twice the median)
     __syncthreads();
-
-    // ---- phase B: this wave's cells
-    const unsigned wave = blockIdx.x * (unsigned)W + (unsigned)wib;
-    u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
-    unsigned cnt = 0u;
-    const int col = lane & 31, half = lane >> 5;
-    for (int i = 0; i < my_cells; ++i) {
-        const int ci = wib + W * i;
-        const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, i);
-        const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, i);
-        unsigned nq = s_cnt[ci];
-        const bool dense = nq > lcap;   // the list did not fit its LDS room: score every query of the batch
-        if (dense) {
-            nq = (unsigned)m;
-            if (lane == 0)
-                atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
+    for (int i = tid; i < C; i += T) {
+        const unsigned wi = min(s_cnt[i], lcap + 1u) * (s_tile[i + 1] - s_tile[i]);
+        unsigned rank = 0u;
+        for (int j = 0; j < C; ++j) {
+            const unsigned wj = min(s_cnt[j], lcap + 1u) * (s_tile[j + 1] - s_tile[j]);
+            rank += (wj > wi || (wj == wi && j < i)) ? 1u : 0u;
         }
-        if (nq == 0u)
-            continue;   // (a prefetched first cell nobody needs: its loads are dropped)
-        const unsigned short *list = s_list + (unsigned)ci * lcap;
-        for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
-            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
-            if (i != 0 || t0 != tb)
-                request(t0, nt);
-            for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
-                const unsigned idx = q0 + (unsigned)col;
-                const bool valid = idx < nq;
-                const unsigned qid = dense ? (valid ? idx : 0u) : (unsigned)list[valid ? idx : 0u];
-                const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
-                const float th = valid ? s_thr[qid] : -INFINITY;
-                u64 any = 0ull;
-                u64 masks[CELL_TILES_PER_PASS];
+        s_order[rank] = (unsigned short)i;
+    }
+    __syncthreads();
+    SWEEP_STAMP(3);
+
+    // ---- phase B: work items = (cell, pass of up to CELL_TILES_PER_PASS tiles), cells taken from a block-wide counter
+    const int col = lane & 31, half = lane >> 5;
+    unsigned nhits = 0u;
+    // Hits wait in a per-wave queue — (query << 32) | (tile << 1) | half, the record format of the full scan — and are
+    // re-ranked four at a time (16 lanes each) right after the NEXT item's loads have been requested, so that the two
+    // dependent round trips of a re-rank (position -> row number -> row) run beside a round trip the wave makes anyway.
+    u64 *my_hits = s_hits + wib * SWEEP_HITQ;
+    unsigned pending = 0u;   // wave-uniform
+    u64 *my_mq = s_mq + wib * (2 * CELL_TILES_PER_PASS * SWEEP_QB);
+    auto drain = [&]() {
+        for (unsigned h0 = 0u; h0 < pending; h0 += 4u) {
+            const unsigned h = h0 + ((unsigned)lane >> 4);
+            u64 key = ~0ull;
+            unsigned hq = 0u;
+            if (h < pending) {
+                const u64 e = my_hits[h];
+                hq = (unsigned)(e >> 32);
+                const unsigned lo32 = (unsigned)e, reg = (unsigned)lane & 15u;
+                const size_t pos = (size_t)(lo32 >> 1) * 32 + 8u * (reg >> 2) + 4u * (lo32 & 1u) + (reg & 3u);
+                const unsigned row = (long long)pos < npos && hq < (unsigned)m ? perm[pos] : 0xFFFFFFFFu;   // (belt and braces: a record is never out of range)
+                if (row != 0xFFFFFFFFu) {   // padding positions hold ~0u
+                    const float *__restrict__ qr = Q + (size_t)hq * k;
+                    const float *__restrict__ rr = R + (size_t)row * k;
+                    float acc = 0.0f;
+                    for (int d0 = 0; d0 < k; ++d0) {   // v0: (q - r)^2 summed in dimension order, one rounding per operation
+                        const float diff = qr[d0] - rr[d0];
+                        const float sq = diff * diff;
+                        acc = acc + sq;
+                    }
+                    if (acc < INFINITY)   // false for NaN too: v0 never selects those
+                        key = ((u64)__float_as_uint(acc) << 32) | (u64)(unsigned)(base + (long long)row);
+                }
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const u64 o = __shfl_xor(key, off, KNN_WAVE);
+                key = o < key ? o : key;
+            }
+            // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
+            if ((lane & 15) == 0 && key != ~0ull && key < keys[hq])
+                __hip_atomic_fetch_min(&keys[hq], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        nhits += pending;
+        pending = 0u;
+    };
+    // the operands of the norm MFMA: built once, kept opaque so that they stay in registers (left alone the compiler
+    // puts both together again for every tile: six moves per tile in a loop that is bound by vector issue)
+    u4v norm_a = {0u, 0u, 0u, 0u};
+    h8 norm_b = norm_b_operand();
+    asm volatile("" : "+v"(norm_a), "+v"(norm_b));
+    unsigned long long listed = 0;   // (stamps only)
+    // generator of work items (all wave-uniform)
+    unsigned g_ci = 0u, g_t0 = 0u, g_te = 0u, g_nq = 0u;
+    bool g_dense = false;
+    struct Item {
+        unsigned ci, t0, nq;
+        int nt;
+        bool dense;
+    };
+    auto next_item = [&](Item &it) __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (g_t0 < g_te) {
+                it.ci = g_ci;
+                it.t0 = g_t0;
+                it.nt = (int)min((unsigned)CELL_TILES_PER_PASS, g_te - g_t0);
+                it.nq = g_nq;
+                it.dense = g_dense;
+                g_t0 += CELL_TILES_PER_PASS;
+                return true;
+            }
+            unsigned ci = 0u;
+            if (lane == 0)
+                ci = atomicAdd(&s_next, 1u);
+            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
+            if (ci >= (unsigned)C)
+                return false;
+            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)s_order[ci]);
+            // (values read from LDS are wave-uniform but the compiler cannot know: without the readfirstlane every test on
+            // them below became an exec-mask dance — v_cmp / s_and_saveexec per tile — and tripled the vector instructions)
+            unsigned nq = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[ci]);
+            const bool dense = nq > lcap;   // the list did not fit its LDS room: score every query of the batch
+            if (dense) {
+                nq = (unsigned)m;
+                if (lane == 0)
+                    atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
+            }
+            const unsigned tb = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tile[ci]);
+            const unsigned te = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tile[ci + 1u]);
+            if (nq == 0u || te == tb)
+                continue;
+            listed += nq;
+            g_ci = ci;
+            g_t0 = tb;
+            g_te = te;
+            g_nq = nq;
+            g_dense = dense;
+        }
+    };
+    auto request = [&](const Item &it, h8(&ar)[CELL_TILES_PER_PASS], unsigned(&nw)[CELL_TILES_PER_PASS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+            nw[p] = 0u;
+            if (p < it.nt) {
+                if (dbg & 4u) {   // experiment: no tile loads
+                    ar[p] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+                    continue;
+                }
+                ar[p] = __builtin_nontemporal_load(&rf[(size_t)(it.t0 + (unsigned)p) * 64 + lane]);
+                if (lane < 32)
+                    nw[p] = __builtin_nontemporal_load(&rn2[(size_t)(it.t0 + (unsigned)p) * 32 + lane]);
+            }
+        }
+    };
+    auto process = [&](const Item &it, h8(&ar)[CELL_TILES_PER_PASS], unsigned(&nw)[CELL_TILES_PER_PASS]) __attribute__((always_inline)) {
+        const unsigned short *list = s_list + it.ci * lcap;
+        const unsigned nq = it.nq;
+        const int nt = it.nt;
+        for (unsigned q0 = 0u; q0 < nq; q0 += 32u * SWEEP_QB) {
+            const int nblk = (int)min((unsigned)SWEEP_QB, (nq - q0 + 31u) / 32u);   // wave-uniform
+            unsigned qid[SWEEP_QB];
+            h8 b[SWEEP_QB];
+            float th[SWEEP_QB];
+#pragma unroll
+            for (int j = 0; j < SWEEP_QB; ++j) {
+                const unsigned idx = q0 + 32u * (unsigned)j + (unsigned)col;
+                const bool valid = j < nblk && idx < nq;
+                qid[j] = valid ? (it.dense ? idx : (unsigned)list[idx]) : 0u;
+                b[j] = s_qf[(qid[j] >> 5) * 64u + (unsigned)half * 32u + (qid[j] & 31u)];
+                th[j] = valid ? s_thr[qid[j]] : -INFINITY;
+            }
+            if (pending != 0u)   // wave-uniform; the tile loads of this item are in flight
+                drain();
+            unsigned nmq = 0u;   // wave-uniform: steps of this group that had hits
+            // NB blocks of queries per tile, straight-line; no branch sits between an MFMA and the reader of its result (the
+            // compiler's cross-block wait-state count was short there: DESIGN 4.2, tools/mfma_hazard_audit.py)
+            auto run = [&](auto nb_tag) __attribute__((always_inline)) {
+                constexpr int NB = decltype(nb_tag)::value;
 #pragma unroll
                 for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                    masks[p] = 0ull;
                     if (p < nt) {
-                        masks[p] = cell_tile_step<true>(ar[p], nw[p], nullptr, p, half, b, th);
-                        any |= masks[p];
-                    }
-                }
-                if (__builtin_expect(any != 0ull, 0)) {
-                    const u64 me = 1ull << lane;
+                        norm_a[0] = nw[p];
+                        const f16v cn = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, norm_a), norm_b, zero_acc(), 0, 0, 0);
+                        u64 masks[NB];
+                        u64 any = 0ull;
+                        // all NB scoring MFMAs first, back to back on accumulators of their own (the last one continues
+                        // in the norm tile's registers), THEN the min trees: left to itself the scheduler put each tree
+                        // right behind its MFMA on one shared accumulator — 12 idle wait states per block of queries and
+                        // no MFMA in flight under a tree.  The barrier keeps the two groups apart.
+                        f16v d[NB];
 #pragma unroll
-                    for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                        const u64 mask = masks[p];
-                        if (mask != 0ull) {
-                            if (mask & me) {
-                                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                if (pos < slice)
-                                    my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
-                            }
-                            cnt += (unsigned)__popcll(mask);
+                        for (int j = 0; j < NB; ++j)
+                            d[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b[j], cn, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            const float mn = min_tree16(d[j], th[j]);
+                            masks[j] = __ballot(mn < th[j]);
+                            any |= masks[j];
+                        }
+                        if (__builtin_expect(any != 0ull, 0)) {
+                            // (rare: ~3 per 1000 steps) only the masks are parked here — the hot loop stays small; the hits
+                            // are unpacked below, once per group
+#pragma unroll
+                            for (int j = 0; j < NB; ++j)
+                                if (masks[j] != 0ull) {   // wave-uniform
+                                    if (lane == 0) {
+                                        my_mq[2u * nmq] = masks[j];
+                                        my_mq[2u * nmq + 1u] = ((u64)(it.t0 + (unsigned)p) << 1) | (u64)j;
+                                    }
+                                    ++nmq;
+                                }
                         }
                     }
                 }
+            };
+            if (dbg & 1u) {   // experiment: no scoring at all (loads are still waited for)
+                float keep = 0.f;
+#pragma unroll
+                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
+                    if (p < nt)
+                        keep += (float)ar[p][0] + __uint_as_float(nw[p]);
+                if (keep == 12345.678f)
+                    nmq = 1u;
+            } else if (nblk > 1)
+                run(std::integral_constant<int, SWEEP_QB>());
+            else
+                run(std::integral_constant<int, 1>());
+            if (__builtin_expect(nmq != 0u, 0)) {
+                // hit lane L of a step = (query qid[block] of L, rows 8g + 4 half(L) + i of the tile) -> the pending queue
+                wave_lds_sync();
+                for (unsigned e = 0u; e < nmq; ++e) {
+                    const u64 mask = my_mq[2u * e];
+                    const u64 tj = my_mq[2u * e + 1u];
+                    const unsigned cnt = (unsigned)__popcll(mask);
+                    if (pending + cnt > SWEEP_HITQ)
+                        drain();
+                    if ((mask >> lane) & 1ull) {
+                        const unsigned at = pending + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        const unsigned hq = (tj & 1ull) ? qid[SWEEP_QB - 1] : qid[0];
+                        my_hits[at] = ((u64)hq << 32) | ((tj >> 1) << 1) | (u64)half;
+                    }
+                    pending += cnt;
+                    wave_lds_sync();
+                }
             }
         }
+    };
+    {
+        h8 ar[CELL_TILES_PER_PASS];
+        unsigned nw[CELL_TILES_PER_PASS];
+        Item it;
+        while (next_item(it)) {
+            request(it, ar, nw);
+            process(it, ar, nw);
+        }
     }
-    if (lane == 0) {
-        counts[wave] = cnt;
-        if (cnt > slice)
-            ctl[KNN_CTL_FALLBACK] = 1u;
+    if (pending != 0u)
+        drain();
+    if (lane == 0 && nhits != 0u)
+        atomicAdd(&ctl[KNN_CTL_RECORDS], nhits);   // statistics: candidates re-ranked
+    SWEEP_STAMP(4);
+    if (stamps && lane == 0) {
+        stamps[((size_t)blockIdx.x * W + wib) * 8 + 5] = __builtin_readcyclecounter() - clk0;
+        stamps[((size_t)blockIdx.x * W + wib) * 8 + 6] = (u64)npass | ((u64)__builtin_amdgcn_s_getreg(63492) << 32);   // HW_ID
+        stamps[((size_t)blockIdx.x * W + wib) * 8 + 7] = listed;
     }
+#undef SWEEP_STAMP
 }
 
 // (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512)
@@ -1024,11 +1237,12 @@ template <bool NORM_MFMA>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ rn2,
     const unsigned *__restrict__ tile_start, unsigned ncells,
-    const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m_padded,
+    const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
-    u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice)
+    u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice,
+    unsigned ovf_base, unsigned ovf_cap)
 {
-    extern __shared__ unsigned char s_dyn[];
+    extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
     f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8] (LDS norms only)
@@ -1059,17 +1273,24 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
         unsigned v_nq = in ? cell_counts[mine] : 0u;
         const unsigned v_tb = in ? tile_start[mine] : 0u;
         const unsigned v_te = in ? tile_start[mine + 1u] : 0u;
-        if (v_nq > cap)
-            v_nq = cap;
         for (u64 todo = __ballot(v_nq != 0u && v_te > v_tb); todo != 0ull; todo &= todo - 1ull) {
             const int j = (int)__builtin_ctzll(todo);
-            const unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
+            unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
+            // a list longer than its room (a thousand copies of one query all want the same cells) is cut short by the
+            // match kernel: the cell is then scored `dense`, against every query of the batch — what a list that long
+            // asks for anyway — instead of sending the batch to the exact scan as round 2 did
+            const bool dense = nq > cap;
+            if (dense) {
+                nq = (unsigned)m;
+                if (lane == 0)
+                    atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
+            }
             const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
             const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, j);
             const unsigned cellj = (g0 + (unsigned)j) * nwaves + wave;
             const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
             // the first two blocks of the list travel with the tiles (one round trip per cell)
-            const unsigned l0 = list[min((unsigned)lane, nq - 1u)];
+            const unsigned l0 = dense ? (unsigned)lane : (unsigned)list[min((unsigned)lane, nq - 1u)];
             for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
                 const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
                 h8 ar[CELL_TILES_PER_PASS];
@@ -1101,7 +1322,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
                         const unsigned from = __shfl(l0, (int)idx, KNN_WAVE);
                         qid = valid ? from : __shfl(l0, 0, KNN_WAVE);
                     } else {
-                        qid = list[valid ? idx : 0u];
+                        qid = dense ? (valid ? idx : 0u) : (unsigned)list[valid ? idx : 0u];
                     }
                     const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
                     const float th = valid ? s_thr[qid] : -INFINITY;
@@ -1124,8 +1345,16 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
                                 if (mask & me) {
                                     const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                    const u64 r = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
                                     if (pos < slice)
-                                        my_rec[pos] = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
+                                        my_rec[pos] = r;
+                                    else if (ovf_cap != 0u) {
+                                        // this wave's slice is full (many queries of the batch want the same tile — copies
+                                        // of one query): the record goes to the area all waves share, one atomic each (rare)
+                                        const unsigned op = atomicAdd(&ctl[KNN_CTL_RECORDS], 1u);
+                                        if (op < ovf_cap)
+                                            rec[(size_t)ovf_base + op] = r;   // (beyond: the re-rank sees the count and falls back)
+                                    }
                                 }
                                 cnt += (unsigned)__popcll(mask);
                             }
@@ -1136,8 +1365,8 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
         }
     }
     if (lane == 0) {
-        counts[wave] = cnt;
-        if (cnt > slice)
+        counts[wave] = ovf_cap != 0u ? min(cnt, slice) : cnt;   // what is IN the slice; the rest went to the shared area
+        if (ovf_cap == 0u && cnt > slice)
             ctl[KNN_CTL_FALLBACK] = 1u;
     }
 }
@@ -1337,22 +1566,33 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
     return hipSuccess;
 }
 
-// Sweep geometry: cells per block (a power of two, 8 .. 64, dividing the low table) and list entries per cell in LDS
-// (16384 u16 entries = 32 KiB per block in all: a list can hold the whole batch up to 2^13 cells — 16 cells per
-// block — and 256 queries at 64 cells per block, ten times what uniform data lists at 2^16 cells).
-static void sweep_geometry(const CellIndex &c, int *cshift, unsigned *lcap)
+// Sweep geometry: one block per CU when the shard has the cells for it — cells per block = a power of two between 16
+// and the width of the low table — and list entries per cell in LDS: 32768 u16 entries = 64 KiB per block in all, which
+// is the whole batch per list up to 32 cells per block (2^13 cells on 256 CUs) and 128 queries at 256 cells per block
+// (2^16 cells; uniform data lists 25 there).  A longer list turns its cell `dense`.
+static void sweep_geometry(const CellIndex &c, int num_cu, int *cshift, unsigned *lcap)
 {
-    int cs = c.ncells >= (1u << 15) ? 6 : c.ncells >= (1u << 14) ? 5 : c.ncells >= (1u << 11) ? 4 : 3;
-    cs = std::min(cs, c.sa);
+    int cs = 4;
+    while ((c.ncells >> (cs + 1)) >= (unsigned)num_cu && cs + 1 <= c.sa)
+        ++cs;
     *cshift = cs;
-    *lcap = std::min(1024u, 16384u >> cs);
+    *lcap = std::min((unsigned)KNN_CELL_BATCH, 32768u >> cs);
 }
 
-template <int W>
-static hipError_t launch_sweep(FilterState &st, FilterWorkspace &w, int m, int m_padded, int cshift, unsigned lcap, hipStream_t s)
+#define CELL_SWEEP_WAVES 12
+
+static hipError_t launch_sweep(FilterState &st, FilterWorkspace &w, int m, int m_padded, int cshift, unsigned lcap, const float *q,
+                               const float *r, long long base, u64 *keys, hipStream_t s)
 {
+    constexpr int W = CELL_SWEEP_WAVES;
     const CellIndex &c = *st.cells;
-    const size_t lds = (size_t)m_padded * 32 + (size_t)m_padded * 4 * 3 + (size_t)m_padded * 2 + ((size_t)lcap << cshift) * 2;
+    const size_t C = (size_t)1 << cshift;
+    const size_t lds = (size_t)m_padded * 36 + (C + 64 + C + C) * 4 + (size_t)m_padded * 4 * 2 + (size_t)W * SWEEP_HITQ * 8 + (size_t)W * 2 * CELL_TILES_PER_PASS * SWEEP_QB * 8 + (size_t)m_padded * 2 +
+                       (C * lcap) * 2;
+    static u64 *stamps = nullptr;
+    static const bool want_stamps = getenv("KNN_MI355X_SWEEP_STAMPS") != nullptr;
+    if (want_stamps && !stamps)
+        FTRY(hipMalloc((void **)&stamps, (size_t)65536 * 8 * sizeof(u64)));
     // (dynamic LDS beyond the default limit must be asked for, per device: remembered so that the call is made once)
     static std::atomic<size_t> lds_allowed[64];
     int dev = 0;
@@ -1364,17 +1604,88 @@ static hipError_t launch_sweep(FilterState &st, FilterWorkspace &w, int m, int m
     }
     hipLaunchKernelGGL(knn_cells_sweep_kernel<W>, dim3(c.ncells >> cshift), dim3(64 * W), lds, s, (const h8 *)st.ref_frags,
                        st.ref_norms2, c.tile_start, cshift, (const h8 *)w.qry_frags, w.thr, w.dup, m, m_padded, w.lo_tab, w.hi_tab,
-                       c.sa, lcap, w.records, w.counts, w.ctl_cur, w.slice);
-    return hipGetLastError();
+                       c.sa, lcap, q, r, c.perm, st.ntiles * 32, st.k, base, keys, w.ctl_cur, stamps,
+                       getenv("KNN_MI355X_SWEEP_DBG") ? (unsigned)atoi(getenv("KNN_MI355X_SWEEP_DBG")) : 0u);
+    FTRY(hipGetLastError());
+    if (stamps) {   // development aid (KNN_MI355X_SWEEP_STAMPS=1): synchronises and prints where the waves spent their time
+        const size_t nw = (size_t)(c.ncells >> cshift) * W;
+        std::vector<u64> h(nw * 8);
+        FTRY(hipStreamSynchronize(s));
+        FTRY(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        u64 tmin = ~0ull, tmax = 0;
+        for (size_t i = 0; i < nw; ++i) {
+            tmin = std::min(tmin, h[i * 8]);
+            tmax = std::max(tmax, h[i * 8 + 4]);
+        }
+        const char *names[4] = {"loads + barrier", "pass 1 + barrier", "pass 2 + barrier", "cells scanned"};
+        fprintf(stderr, "[knn sweep] %zu waves, C = %zu, lcap %u, LDS %zu B, first start -> last end %.2f us\n", nw, C, lcap, lds, (tmax - tmin) * 0.01);
+        std::vector<double> v(nw);
+        for (int ph = 0; ph < 4; ++ph) {
+            for (size_t i = 0; i < nw; ++i)
+                v[i] = (double)(h[i * 8 + ph + 1] - h[i * 8 + ph]) * 0.01;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[knn sweep]   %-18s median %7.2f  p90 %7.2f  max %7.2f us\n", names[ph], v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
+        }
+        for (size_t i = 0; i < nw; ++i)
+            v[i] = (double)(h[i * 8] - tmin) * 0.01;
+        std::sort(v.begin(), v.end());
+        double np = 0, tot = 0, mhz = 0;
+        for (size_t i = 0; i < nw; ++i) {
+            np += (double)(h[i * 8 + 6] & 0xFFFFFFFFull);
+            tot += (double)h[i * 8 + 7];
+            mhz += (double)h[i * 8 + 5] / ((double)(h[i * 8 + 4] - h[i * 8]) * 0.01);
+        }
+        fprintf(stderr, "[knn sweep]   shader clock while the waves ran: %.0f MHz\n", mhz / nw);
+        {   // per block: time in phase B (slowest wave) against the queries listed in the block, by XCD (block % 8)
+            const size_t nb = nw / W;
+            double xs[8] = {0}, xl[8] = {0};
+            int xn[8] = {0};
+            std::vector<std::pair<double, double>> bl;
+            for (size_t b = 0; b < nb; ++b) {
+                double t = 0, l = 0;
+                for (int wv = 0; wv < W; ++wv) {
+                    t = std::max(t, (double)(h[(b * W + wv) * 8 + 4] - h[(b * W + wv) * 8 + 3]) * 0.01);
+                    l += (double)h[(b * W + wv) * 8 + 7];
+                }
+                xs[b % 8] += t;
+                xl[b % 8] += l;
+                ++xn[b % 8];
+                bl.push_back({t, l});
+            }
+            std::sort(bl.begin(), bl.end());
+            fprintf(stderr, "[knn sweep]   blocks by phase-B time: fastest %.1f us (%.0f listed)  median %.1f (%.0f)  slowest %.1f (%.0f) %.1f (%.0f)\n",
+                    bl[0].first, bl[0].second, bl[nb / 2].first, bl[nb / 2].second, bl[nb - 2].first, bl[nb - 2].second, bl[nb - 1].first, bl[nb - 1].second);
+            {   // where the hardware put the waves of block 0 .. 2: SIMD of each wave (HW_ID bits 5:4), CU (11:8), SE (15:13)
+                for (size_t b = 0; b < 3 && b < nb; ++b) {
+                    fprintf(stderr, "[knn sweep]   block %zu waves on (se.cu.simd):", b);
+                    for (int wv = 0; wv < W; ++wv) {
+                        const unsigned id = (unsigned)(h[(b * W + wv) * 8 + 6] >> 32);
+                        fprintf(stderr, " %u.%u.%u", (id >> 13) & 7u, (id >> 8) & 15u, (id >> 4) & 3u);
+                    }
+                    fprintf(stderr, "\n");
+                }
+            }
+            fprintf(stderr, "[knn sweep]   by XCD:");
+            for (int x = 0; x < 8; ++x)
+                fprintf(stderr, " %.1f us/%.0f", xs[x] / std::max(xn[x], 1), xl[x] / std::max(xn[x], 1));
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[knn sweep]   wave start after first: median %.2f p90 %.2f max %.2f us; queue %.0f per block, listed queries per wave %.1f\n",
+                v[nw / 2], v[nw * 9 / 10], v[nw - 1], np / nw, tot / nw);
+    }
+    return hipSuccess;
 }
 
-// One batch of <= KNN_CELL_BATCH queries: prep (fragments, seed scores, thresholds, tables) + sweep (match + scan);
-// records in w, as the full scan leaves them.  `cells_variant` 1 / 2 run the round-2 kernels instead (A/B).
-hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, int num_cu, bool timed,
-                           hipStream_t s, u64 *keys_init)
+// One batch of <= KNN_CELL_BATCH queries.  `cells_variant`: 0 = prep + match + scan (the default chain), 1 = the round-2
+// chain (query fragments by the caller, seed, match, scan), 2 = as 0 with the scan's norms out of an extra MFMA instead of
+// LDS, 3 = prep + sweep (match, scan and re-rank in one persistent kernel: an experiment that did not pay).
+// Records in w, as the full scan leaves them (variant 3: none, w.nlists = 0).
+hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, const float *r, long long base,
+                           u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys)
 {
+    u64 *keys_init = init_keys ? keys : nullptr;
     const int variant = st.cells_variant;
-    FTRY(ensure_cells_workspace(st, w, m, variant != 0));
+    FTRY(ensure_cells_workspace(st, w, m, variant != 3));
     const CellIndex &c = *st.cells;
     const int m_padded = (m + 31) / 32 * 32;
     CellGeom g;
@@ -1387,15 +1698,18 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     w.has_rows = false;
     w.pieces = RerankPieces();
     const double sigma2 = (double)st.sigma * (double)st.sigma;
+    unsigned gx = (unsigned)num_cu * 2u;   // scan: two blocks of CELL_SCAN_WAVES waves per CU
+    if (gx * CELL_SCAN_WAVES > c.ncells)
+        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
+    w.nlists = gx * CELL_SCAN_WAVES;
+    // the last quarter of the record buffer is shared by all waves: what a wave's own slice cannot hold goes there
+    w.ovf_cap = w.rec_cap / 4u;
+    w.ovf_base = w.rec_cap - w.ovf_cap;
+    w.slice = (w.rec_cap - w.ovf_cap) / w.nlists;
 
     if (variant == 1) {
         // round 2: the caller has run the query-fragment kernel (which also reset block 0 of the control words)
         w.ctl_cur = w.ctl;
-        unsigned gx = (unsigned)num_cu * 2u;   // two blocks of CELL_SCAN_WAVES waves per CU
-        if (gx * CELL_SCAN_WAVES > c.ncells)
-            gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
-        w.nlists = gx * CELL_SCAN_WAVES;
-        w.slice = w.rec_cap / w.nlists;
         hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds, sigma2, c.tile_start,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.lo_tab, w.hi_tab, m_padded,
                            w.qry_norms, w.qry_amax, w.qpart, (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax,
@@ -1406,33 +1720,27 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         const unsigned parity = w.cell_batches++ & 1u;
         w.ctl_cur = w.ctl + KNN_CTL_WORDS * (1u + parity);
         unsigned *ctl_next = w.ctl + KNN_CTL_WORDS * (2u - parity);
-        int cshift = 0;
-        unsigned lcap = 0;
-        sweep_geometry(c, &cshift, &lcap);
-        if (variant == 0) {
-            w.nlists = (c.ncells >> cshift) * 8u;
-        } else {
-            unsigned gx = (unsigned)num_cu * 2u;
-            if (gx * CELL_SCAN_WAVES > c.ncells)
-                gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
-            w.nlists = gx * CELL_SCAN_WAVES;
+        if (variant == 3) {
+            w.nlists = 0u;   // no record lists: the sweep re-ranks its hits itself
+            w.slice = w.ovf_base = w.ovf_cap = 0u;
         }
-        w.slice = w.rec_cap / w.nlists;
-        hipLaunchKernelGGL(knn_cells_prep_kernel, dim3((unsigned)(m_padded / CELL_PREP_WAVES)), dim3(64 * CELL_PREP_WAVES), 0, s, q, m,
+        hipLaunchKernelGGL(knn_cells_prep_kernel, dim3((unsigned)m_padded), dim3(64 * CELL_PREP_WAVES), 0, s, q, m,
                            m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
                            st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
                            w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
         FTRY(hipGetLastError());
-        if (variant == 0) {
+        if (variant == 3) {
+            int cshift = 0;
+            unsigned lcap = 0;
+            sweep_geometry(c, num_cu, &cshift, &lcap);
             if (timed && w.ev_begin)
                 FTRY(hipEventRecord(w.ev_begin, s));
-            FTRY(launch_sweep<8>(st, w, m, m_padded, cshift, lcap, s));
+            FTRY(launch_sweep(st, w, m, m_padded, cshift, lcap, q, r, base, keys, s));
             if (timed && w.ev_end)
                 FTRY(hipEventRecord(w.ev_end, s));
             return hipSuccess;
         }
     }
-    // round-2 match + scan (variants 1 and 2)
     if (c.ncells <= 16384u)
         hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
                            m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
@@ -1442,16 +1750,15 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     FTRY(hipGetLastError());
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    const unsigned gx = w.nlists / CELL_SCAN_WAVES;
     const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
-    if (variant == 1)
-        hipLaunchKernelGGL(knn_cells_scan_kernel<false>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded,
-                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice);
-    else
+    if (variant == 2)
         hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m_padded,
-                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice);
+                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
+    else
+        hipLaunchKernelGGL(knn_cells_scan_kernel<false>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
+                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
     FTRY(hipGetLastError());
     if (timed && w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));

@@ -37,10 +37,12 @@ struct RerankPieces {
 
 // perm (nullable): records name positions of a permuted layout; perm[position] = row (~0u = padding), and n
 // is then the number of positions.
+// ovf_cap != 0: records[ovf_base ..) hold ctl[KNN_CTL_RECORDS] more records (capped at ovf_cap) that belong to no list.
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
                              const u64 *records, const unsigned short *record_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
-                             hipStream_t stream, const unsigned *perm = nullptr);
+                             hipStream_t stream, const unsigned *perm = nullptr, unsigned ovf_base = 0u,
+                             unsigned ovf_cap = 0u);
 
 hipError_t knn_keys_fill_launch(u64 *keys_dev, int m, hipStream_t stream);
 hipError_t knn_keys_unpack_launch(const u64 *keys_dev, int m, int *out_dev, hipStream_t stream);
@@ -51,7 +53,7 @@ hipError_t knn_synth_fill_launch(float *dst, long long count, u64 seed, long lon
 // Device-side control words of one filter query (FilterState::ctl).
 enum {
     KNN_CTL_FALLBACK = 0,  // != 0: the exact kernels must scan the whole shard (filter unusable)
-    KNN_CTL_RECORDS = 1,   // total candidate records re-ranked (summed by the re-rank kernel)
+    KNN_CTL_RECORDS = 1,   // records appended to the SHARED overflow area behind the waves' slices (cell-pruned path)
     // words 2..4 are the out[0..2] window of knn_frag_kernel for the query batch
     KNN_CTL_AMAX = 2,      // float bits: max |scaled query coordinate| in fp16
     KNN_CTL_QNMAX = 3,     // float bits: max fp32 squared norm of the fp16 query rows
@@ -83,6 +85,8 @@ struct FilterWorkspace {
     unsigned rec_cap = 0;
     unsigned *counts = nullptr;// device [nlists]: records each wave produced (may exceed slice)
     unsigned nlists = 0, slice = 0;
+    unsigned ovf_base = 0, ovf_cap = 0; // cell-pruned path: records [ovf_base, ovf_base + ovf_cap) take what a wave's slice
+                               // cannot hold (a thousand copies of one query all hit the same tile); 0 = none
     float *umin = nullptr;     // device [sample blocks][m_padded]: per-block minima of the sample pass
     size_t umin_cap = 0;       // floats allocated in umin
     unsigned *qpart = nullptr; // device [3 * query blocks]: {max |coord|, max norm, #bad} per block
@@ -154,9 +158,10 @@ void knn_cells_free(CellIndex *&c);
 void knn_cells_workspace_free(FilterWorkspace &w);
 // One batch of <= KNN_CELL_BATCH queries already prepared by the filter's query-fragment kernel: seed, thresholds,
 // match, scan (records in w, as the full scan leaves them).  Asynchronous.
-// keys_init (nullable): the batch's keys, set to (+INF, 0) by the first kernel of the chain (variants 0 and 2).
-hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q_dev, int num_cu, bool timed,
-                           hipStream_t s, u64 *keys_init);
+// init_keys: the batch's keys are set to (+INF, 0) by the first kernel of the chain (variants 0 and 2).  Variant 0 folds
+// its answers into keys itself (no records left for a re-rank launch: w.nlists = 0).
+hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q_dev, const float *r_dev, long long base,
+                           u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys);
 
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
 // (and returns hipSuccess) when the data rules the filter out.

@@ -501,6 +501,71 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane16(const float *__re
 // references one lane of a 32x32 MFMA tile covers: (query << 32) | (ref_tile << 1) | half, rows
 // 8g + 4*half + i (g, i in 0..3) of that tile.  One (record, row) pair per thread, v0 arithmetic.
 // ------------------------------------------------------------------------------------------
+// One (record, row) pair: the packed key of row `reg` of record e for its query, ~0 when there is nothing to evaluate.
+template <int K>
+__device__ __forceinline__ u64 rerank_pair(const float *__restrict__ Q, const float *__restrict__ R, int k, long long n,
+                                           long long base, u64 e, unsigned reg, unsigned rmask, unsigned qrow_base,
+                                           const unsigned *__restrict__ perm, unsigned &qi)
+{
+#pragma clang fp contract(off)
+    qi = (unsigned)(e >> 32) + qrow_base;
+    const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
+    long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+    // rows the filter already proved to be above the threshold are not the answer: skip them
+    bool live = ri < n && ((rmask >> reg) & 1u);
+    if (perm && live) {  // cell-sorted layout: position -> row, padding positions hold ~0u
+        const unsigned row = perm[ri];
+        live = row != 0xFFFFFFFFu;
+        ri = (long long)row;
+    }
+    if (!live)
+        return ~0ull;
+    const float *__restrict__ q = Q + (size_t)qi * k;
+    const float *__restrict__ r = R + (size_t)ri * k;
+    float acc = 0.0f;
+    if (K > 0) {
+        float qv[K > 0 ? K : 1], rv[K > 0 ? K : 1];
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            qv[d] = q[d];
+            rv[d] = r[d];
+        }
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const float diff = qv[d] - rv[d];
+            const float sq = diff * diff;
+            acc = acc + sq;
+        }
+    } else {
+        // run-time k: chunks of 16 with all 32 loads of a chunk in flight together
+        // (a plain scalar loop is one dependent round trip per dimension); the
+        // accumulation order stays d = 0..k-1
+        int d = 0;
+        for (; d + 16 <= k; d += 16) {
+            float qv[16], rv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                qv[j] = q[d + j];
+                rv[j] = r[d + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float diff = qv[j] - rv[j];
+                const float sq = diff * diff;
+                acc = acc + sq;
+            }
+        }
+        for (; d < k; ++d) {
+            const float diff = q[d] - r[d];
+            const float sq = diff * diff;
+            acc = acc + sq;
+        }
+    }
+    if (acc < INFINITY)  // false for NaN too: v0 never selects those
+        return pack_key(acc, (unsigned)(base + ri));
+    return ~0ull;
+}
+
 template <int K>  // K > 0: compile-time dimension (all row loads issue before the first use)
 __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__restrict__ Q,
                                                                const float *__restrict__ R, int krt,
@@ -510,9 +575,9 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
                                                                const unsigned *__restrict__ counts,
                                                                unsigned slice, unsigned *__restrict__ ctl,
                                                                u64 *__restrict__ keys, RerankPieces pieces,
-                                                               const unsigned *__restrict__ perm)
+                                                               const unsigned *__restrict__ perm,
+                                                               unsigned ovf_base, unsigned ovf_cap)
 {
-#pragma clang fp contract(off)
     // one block per record list (= per filter wave); the list's piece gives its first query
     unsigned qrow_base = pieces.qrow_base[0];
 #pragma unroll
@@ -537,64 +602,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
         u64 key = ~0ull;
         unsigned qi = 0u;
         if (c < nrec * 16u) {
-            const u64 e = list[c >> 4];
-            const unsigned reg = c & 15u;
-            qi = (unsigned)(e >> 32) + qrow_base;
-            const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
-            long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
-            // rows the filter already proved to be above the threshold are not the answer: skip them
             const unsigned rmask = rec_rows ? rec_rows[(size_t)blockIdx.x * slice + (c >> 4)] : 0xFFFFu;
-            bool live = ri < n && ((rmask >> reg) & 1u);
-            if (perm && live) {  // cell-sorted layout: position -> row, padding positions hold ~0u
-                const unsigned row = perm[ri];
-                live = row != 0xFFFFFFFFu;
-                ri = (long long)row;
-            }
-            if (live) {
-                const float *__restrict__ q = Q + (size_t)qi * k;
-                const float *__restrict__ r = R + (size_t)ri * k;
-                float acc = 0.0f;
-                if (K > 0) {
-                    float qv[K > 0 ? K : 1], rv[K > 0 ? K : 1];
-#pragma unroll
-                    for (int d = 0; d < K; ++d) {
-                        qv[d] = q[d];
-                        rv[d] = r[d];
-                    }
-#pragma unroll
-                    for (int d = 0; d < K; ++d) {
-                        const float diff = qv[d] - rv[d];
-                        const float sq = diff * diff;
-                        acc = acc + sq;
-                    }
-                } else {
-                    // run-time k: chunks of 16 with all 32 loads of a chunk in flight together
-                    // (a plain scalar loop is one dependent round trip per dimension); the
-                    // accumulation order stays d = 0..k-1
-                    int d = 0;
-                    for (; d + 16 <= k; d += 16) {
-                        float qv[16], rv[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            qv[j] = q[d + j];
-                            rv[j] = r[d + j];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const float diff = qv[j] - rv[j];
-                            const float sq = diff * diff;
-                            acc = acc + sq;
-                        }
-                    }
-                    for (; d < k; ++d) {
-                        const float diff = q[d] - r[d];
-                        const float sq = diff * diff;
-                        acc = acc + sq;
-                    }
-                }
-                if (acc < INFINITY)  // false for NaN too: v0 never selects those
-                    key = pack_key(acc, (unsigned)(base + ri));
-            }
+            key = rerank_pair<K>(Q, R, k, n, base, list[c >> 4], c & 15u, rmask, qrow_base, perm, qi);
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
@@ -604,6 +613,33 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
         // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
         if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
             key_atomic_min(&keys[qi], key);
+    }
+    // the shared overflow area (cell-pruned path: what did not fit a wave's slice), all blocks striding over it
+    if (ovf_cap != 0u) {
+        const unsigned have = ctl[KNN_CTL_RECORDS];
+        if (have != 0u) {   // block-uniform
+            if (have > ovf_cap) {
+                if (threadIdx.x == 0)
+                    ctl[KNN_CTL_FALLBACK] = 1u;
+                return;
+            }
+            const u64 *__restrict__ ovf = rec + ovf_base;
+            const unsigned pairs = have * 16u;
+            const unsigned padded = (pairs + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
+            for (unsigned c = blockIdx.x * KNN_BLOCK + threadIdx.x; c < padded; c += gridDim.x * KNN_BLOCK) {
+                u64 key = ~0ull;
+                unsigned qi = 0u;
+                if (c < pairs)
+                    key = rerank_pair<K>(Q, R, k, n, base, ovf[c >> 4], c & 15u, 0xFFFFu, 0u, perm, qi);
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    const u64 o = __shfl_xor(key, off, KNN_WAVE);
+                    key = o < key ? o : key;
+                }
+                if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+                    key_atomic_min(&keys[qi], key);
+            }
+        }
     }
 }
 
@@ -899,7 +935,7 @@ hipError_t knn_exact_gather_launch(int k, int m, unsigned count, long long base,
 hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r, long long base,
                              const u64 *rec, const unsigned short *rec_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
-                             hipStream_t s, const unsigned *perm)
+                             hipStream_t s, const unsigned *perm, unsigned ovf_base, unsigned ovf_cap)
 {
     if (nlists == 0)
         return hipSuccess;
@@ -912,7 +948,7 @@ hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r,
     }
 #define KNN_RERANK(KK)                                                                                     \
     hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows, \
-                       counts, slice, ctl, keys, pieces, perm)
+                       counts, slice, ctl, keys, pieces, perm, ovf_base, ovf_cap)
     switch (k) {
     case 3: KNN_RERANK(3); break;
     case 4: KNN_RERANK(4); break;

@@ -1735,9 +1735,9 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
             u64 *kb = keys + q0;
             if (st.cells_variant == 1)
                 FTRY(prep_queries(st, w, mb, qb, s));
-            FTRY(knn_cells_query(st, w, mb, qb, num_cu, q0 == 0, s, init_keys && prep_inits ? kb : nullptr));
+            FTRY(knn_cells_query(st, w, mb, qb, r, base, kb, num_cu, q0 == 0, s, init_keys && prep_inits));
             FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl_cur,
-                                   kb, w.pieces, s, perm));
+                                   kb, w.pieces, s, perm, w.ovf_base, w.ovf_cap));
             FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
             FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
         }
@@ -1745,6 +1745,7 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     }
     FTRY(ensure_workspace(st, w, m));
     w.ctl_cur = w.ctl;
+    w.ovf_base = w.ovf_cap = 0u;
     if (init_keys)
         FTRY(knn_keys_fill_launch(keys, m, s));
     FTRY(prep_queries(st, w, m, q, s));

@@ -123,11 +123,11 @@ def test_batches_longer_than_one_pass_and_single_queries(oracle):
         ix.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("k,dist", [(16, "uniform"), (16, "lattice"), (5, "copies"), (12, "queries_outside"), (8, "skewed")])
 def test_ab_arms_of_the_pruned_path_are_bit_exact_too(oracle, variant, k, dist):
-    """`cells_variant` 1 (the round-2 chain) and 2 (prep + round-2 match / scan with MFMA norms) stay selectable for
-    A/B timing: they must answer like the default."""
+    """`cells_variant` 1 (the round-2 chain), 2 (MFMA norms in the scan) and 3 (prep + sweep) stay selectable for A/B
+    timing: they must answer like the default."""
     m, n = 700, (1 << 17) + 99
     rng = np.random.default_rng(k * 77 + variant)
     Q, R = _cases(rng, dist, k, m, n)
@@ -182,17 +182,21 @@ def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle):
 
 
 def test_queries_whose_seed_cells_are_empty_are_bounded_by_a_strided_sample(oracle):
-    """A hole in the data: no row has more than six of its first nine coordinates above 0.45, queries sit deep
-    inside the hole (their own cell and the cells across their nearest cuts hold nothing).  Round 2 raised the
-    fallback for such a batch (exact scan) and switched the index's cells off; now the wave looks at 64 tiles spread
-    over the layout for a (loose) bound and the batch is served by the cells."""
+    """Cells no row lives in: the first four coordinates of every row are equal, so a cell whose bits for them differ
+    is empty.  Queries with (0.9, 0.9, 0.1, 0.1) there sit in such a cell, two flips away from any populated one, and
+    their nearest cuts are in OTHER dimensions: the own cell and the three seed cells across the nearest cuts hold
+    nothing.  Round 2 raised the fallback for such a batch (exact scan) and switched the index's cells off; now the
+    wave looks at 64 tiles spread over the layout for a (loose) bound and the batch is served by the cells."""
     k, m, n = 16, 300, 1 << 18
     rng = np.random.default_rng(9)
-    R = rng.random((int(n * 1.3), k), dtype=np.float32)
-    R = R[(R[:, :9] > 0.45).sum(axis=1) <= 6][:n]
-    assert len(R) == n
+    R = rng.random((n, k), dtype=np.float32)
+    R[:, 1] = R[:, 0]
+    R[:, 2] = R[:, 0]
+    R[:, 3] = R[:, 0]
     Q = rng.random((m, k), dtype=np.float32)
-    Q[:200, :9] = (0.8 + 0.19 * rng.random((200, 9))).astype(np.float32)
+    Q[:200, 0:2] = np.float32(0.9)
+    Q[:200, 2:4] = np.float32(0.1)
+    Q[:200, 4:10] = (0.5 + 0.02 * (rng.random((200, 6)) - 0.5)).astype(np.float32)
     want = oracle.v0(k, Q, R, threads=THREADS)
     pkg.set_option("cells", 1)
     try:
@@ -204,7 +208,7 @@ def test_queries_whose_seed_cells_are_empty_are_bounded_by_a_strided_sample(orac
         pkg.set_option("cells", 0)
     np.testing.assert_array_equal(got, want)
     assert st[0] == 4 and st[2] == 0, st
-    assert wide >= 100, wide
+    assert wide >= 150, wide
 
 
 def test_init_keys_flag_replaces_the_keys_init_launch(oracle):

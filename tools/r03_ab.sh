@@ -4,7 +4,7 @@ out=${1:-gpurun_out/r03_ab}; shift
 sizes=${@:-"2097152 4194304 16777216"}
 mkdir -p "$out"
 for n in $sizes; do
-  for v in 0 2 1; do
+  for v in 0 1 2 3; do
     f="$out/n${n}_v${v}.json"
     timeout -k 10 300 python bench.py --workload 16,1024,$n --cpu-queries 0 --steps 300 --warmup 20 --cells-variant $v > "$f" 2> "$out/n${n}_v${v}.err" || { echo "FAILED n=$n v=$v"; tail -5 "$out/n${n}_v${v}.err"; exit 1; }
     python - "$f" <<'PY'
