@@ -97,18 +97,22 @@ FLOAT_FMA = re.compile(r"\bv_(fma|fmac|fmamk|fmaak|mad|mac|madmk|madak|pk_fma)_f
 def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
     """Bit-exactness against v0 needs one rounding per operation: the exact kernels' ISA must
     hold v_sub/v_mul/v_add (or their packed forms), never an FMA."""
-    src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", "knn_exact.hip")
-    asm = tmp_path / "knn_exact.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                           "--cuda-device-only", "-o", str(asm), src])
-    text = asm.read_text()
-    kernels = re.findall(r"^(_Z\w*(?:knn_exact|knn_rerank)\w*):.*?s_endpgm", text, flags=re.S | re.M)
-    bodies = re.findall(r"^(_Z\w*(?:knn_exact|knn_rerank)\w*):(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(bodies) >= 10, len(kernels)
-    for name, body in bodies:
-        bad = FLOAT_FMA.findall(body)
-        assert not bad, (name, bad[:3])
-        assert re.search(r"v_(pk_)?mul_f32", body), name
+    found = 0
+    # (a kernel's body runs to its .Lfunc_end label: kernels with early returns hold several s_endpgm)
+    for fname, pattern, least in (("knn_exact.hip", r"knn_exact|knn_rerank", 10), ("knn_cells.hip", r"knn_cells_sweep", 1)):
+        src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", fname)
+        asm = tmp_path / (fname + ".s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", "-o", str(asm), src])
+        text = asm.read_text()
+        bodies = re.findall(r"^(_Z\w*(?:%s)\w*):(.*?)^\.Lfunc_end" % pattern, text, flags=re.S | re.M)
+        assert len(bodies) >= least, (fname, len(bodies))
+        for name, body in bodies:
+            bad = FLOAT_FMA.findall(body)
+            assert not bad, (name, bad[:3])
+            assert re.search(r"v_(pk_)?mul_f32", body), name
+            found += 1
+    assert found >= 11, found
 
 
 
