@@ -1398,7 +1398,10 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
         return hipSuccess;
     int bits = 0;
-    while ((144ll << (bits + 1)) <= n)   // cells of 144 .. 288 rows on average: 5-9 tiles each
+    long long rows_min = 144;            // cells of 144 .. 288 rows on average: 5-9 tiles each
+    if (const char *e = getenv("KNN_MI355X_CELL_ROWS"))   // experiment: other cell sizes
+        rows_min = std::max(32, atoi(e));
+    while ((rows_min << (bits + 1)) <= n)
         ++bits;
     bits = std::min(bits, std::min(16, 4 * k));
     if (bits < 9)

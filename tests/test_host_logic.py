@@ -135,8 +135,55 @@ def test_filter_kernels_keep_mfma_results_12_wait_states_from_their_readers(tmp_
         bad, n_mfma = mfma_hazard_audit.audit(asm.read_text())
         assert not bad, (name, bad[:5])
         assert n_mfma >= 20, (name, n_mfma)
+        # the other direction (round 3): no MFMA reads an operand a VALU instruction wrote < 2 wait states earlier
+        bad2, _ = mfma_hazard_audit.audit_operands(asm.read_text())
+        assert not bad2, (name, bad2[:5])
         total += n_mfma
     assert total >= 300, total
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
+def test_probe_variants_that_once_faulted_keep_their_accumulators_until_the_mfma_has_retired(tmp_path):
+    """`tools/filter_probe r2 35` (MFMA only, srcC = literal 0) ended in a GPU memory fault in round 2 when run as a
+    process of its own.  Cause (tools/filter_probe.hip, KEEP_ALL / DRAIN): an inline-asm MFMA result nobody reads is dead
+    at ASMEND for the register allocator while the matrix core writes it 8 passes later — the registers were handed out as
+    the address of the kernel's last store.  The audit sees that class statically: the three MFMA-only variants (35, 36,
+    37 = TREE 20, 21, 22) must be clean."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import mfma_hazard_audit
+    finally:
+        sys.path.pop(0)
+    asm = tmp_path / "filter_probe.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DKNN_NO_POOL",
+                           "-I", os.path.join(ROOT, "multicore_hw2_amd", "csrc"), "-S", "--cuda-device-only", "-o", str(asm),
+                           os.path.join(ROOT, "tools", "filter_probe.hip")])
+    bad, n_mfma = mfma_hazard_audit.audit(asm.read_text())
+    assert n_mfma >= 1000, n_mfma
+    mine = [b for b in bad if re.search(r"Lb1ELb[01]ELi2[012]ELb0E", b[0])]
+    assert not mine, mine[:5]
+
+
+def test_hazard_audit_sees_an_operand_written_right_before_the_mfma_reads_it():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import mfma_hazard_audit
+    finally:
+        sys.path.pop(0)
+    frag = """
+_Z4testv:
+	v_mov_b32_e32 v18, v60
+%s	v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]
+	s_endpgm
+"""
+    bad, n = mfma_hazard_audit.audit_operands(frag % "")
+    assert n == 1 and [b[1] for b in bad] == [0], bad
+    bad, n = mfma_hazard_audit.audit_operands(frag % "\ts_nop 0\n")
+    assert [b[1] for b in bad] == [1], bad
+    bad, n = mfma_hazard_audit.audit_operands(frag % "\ts_nop 1\n")
+    assert not bad, bad
+    bad, n = mfma_hazard_audit.audit_operands(frag.replace("v18, v60", "v40, v60") % "")
+    assert not bad, bad          # a register the MFMA does not read
 
 
 

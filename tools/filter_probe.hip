@@ -1,10 +1,11 @@
 // filter_probe.hip — experiment bench for the filter's hot loop: variants of the per-tile
 // epilogue on the production data path (same fragment layout, loads and pipelining as
 // knn_filter_kernel), timed on synthetic data.  Results are NOT checked: this tool only prices
-// instruction mixes.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o filter_probe filter_probe.hip
+// instruction mixes.  Build (in tools/): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o filter_probe filter_probe.hip
 #define KNN_NO_POOL
 #include "../multicore_hw2_amd/csrc/knn_filter.hip"
 #include "../multicore_hw2_amd/csrc/knn_exact.hip"
+#include "../multicore_hw2_amd/csrc/knn_cells.hip"   // (knn_filter.hip links against the cell-pruned form since round 2)
 #include <algorithm>
 
 // VAR 0: production epilogue (8 min3 incl. thr, cmp, branch)
@@ -259,6 +260,27 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
 #define KEEP_V(X) (void)(X)
 #define KEEP_A(X) (void)(X)
 #endif
+// Round 3 (`filter_probe r2 35` ended in a GPU memory fault when run as a process of its own).
+// Cause, read off the ISA (tools/mfma_hazard_audit.py flags it: 4 / 5 / 11 wait states): an asm MFMA's output that no C++
+// statement reads is dead at ASMEND for the register allocator, while the matrix core writes it 8 passes LATER.  KEEP_V
+// kept one of the three rotating accumulators alive per step; the other two were handed out again at once — v[16:17] as
+// the loop bound's compare operand four instructions after the MFMA that was going to overwrite them, and v[0:1] as the
+// ADDRESS of the kernel's final store, computed 5 - 11 wait states after the last MFMA had been issued: when the late
+// write-back won the race the store went to whatever the accumulator held.  Whether it did depended on timing (cold
+// instruction cache in a single-variant process), which is why the full sweep got through.  Fix: every accumulator stays
+// live at every MFMA-only step (KEEP_ALL), and the loop is followed by a drain that holds them until the last MFMA has
+// retired (DRAIN: 2 x s_nop 15 with all accumulators as operands).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KEEP_ALL_V(D) do { if constexpr (NACC == 2) asm volatile("" ::"v"(D[0]), "v"(D[1])); else if constexpr (NACC == 3) asm volatile("" ::"v"(D[0]), "v"(D[1]), "v"(D[2])); else asm volatile("" ::"v"(D[0]), "v"(D[1]), "v"(D[2]), "v"(D[3])); } while (0)
+#define KEEP_ALL_A(D) do { if constexpr (NACC == 2) asm volatile("" ::"a"(D[0]), "a"(D[1])); else if constexpr (NACC == 3) asm volatile("" ::"a"(D[0]), "a"(D[1]), "a"(D[2])); else asm volatile("" ::"a"(D[0]), "a"(D[1]), "a"(D[2]), "a"(D[3])); } while (0)
+#define DRAIN_V(D) do { if constexpr (NACC == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(D[0]), "+v"(D[1])); else if constexpr (NACC == 3) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(D[0]), "+v"(D[1]), "+v"(D[2])); else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3])); } while (0)
+#define DRAIN_A(D) do { if constexpr (NACC == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(D[0]), "+a"(D[1])); else if constexpr (NACC == 3) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(D[0]), "+a"(D[1]), "+a"(D[2])); else asm volatile("s_nop 15\n\ts_nop 15" : "+a"(D[0]), "+a"(D[1]), "+a"(D[2]), "+a"(D[3])); } while (0)
+#else
+#define KEEP_ALL_V(D) (void)(D)
+#define KEEP_ALL_A(D) (void)(D)
+#define DRAIN_V(D) (void)(D)
+#define DRAIN_A(D) (void)(D)
+#endif
 #define TREE0 ""
 #define TREE6 "v_min3_f32 %1, %10, %11, %12\n\t" "v_min3_f32 %2, %13, %14, %15\n\t" "v_min3_f32 %3, %16, %17, %18\n\t" \
               "v_min3_f32 %4, %19, %20, %21\n\t" "v_min3_f32 %1, %1, %2, %3\n\t" "v_min3_f32 %6, %1, %4, %6"
@@ -271,9 +293,12 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void probe_kernel(const h8 *__rest
                "v_min_f32 %4, %4, %23\n\t" "v_min_f32 %5, %5, %24\n\t" "v_min_f32 %1, %1, %25\n\t" "v_min_f32 %2, %2, %3\n\t"       \
                "v_min_f32 %4, %4, %5\n\t" "v_min_f32 %1, %1, %2\n\t" "v_min_f32 %4, %4, %6\n\t" "v_min_f32 %6, %1, %4"
 // MFMA forms (no tree): literal-zero C; C and D both in AGPRs; accumulate chain (srcC = vdst)
-#define STEP_ASM_C0(DN, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(DN) : "v"(A), "a"(B))
+// (the accumulators of the MFMA-only forms are "+v" / "+a": in-out, so their registers stay theirs from one statement to the
+// next.  As plain outputs they were dead between their last KEEP and their redefinition, and the allocator used v[16:17]
+// there as the scratch of the loop-bound compare while the MFMA issued three statements earlier was still writing them.)
+#define STEP_ASM_C0(DN, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "+v"(DN) : "v"(A), "a"(B))
 #define STEP_ASM_CH(DN, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(DN) : "v"(A), "a"(B))
-#define STEP_ASM_AA(DN, A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(DN) : "v"(A), "v"(B), "a"(C))
+#define STEP_ASM_AA(DN, A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "+a"(DN) : "v"(A), "v"(B), "a"(C))
 // 8 ops, the last one (which needs the two before it) moved to the front: it folds the PREVIOUS step's partial minima
 // (kept in %1 / %4 of the other temporary set, passed as %5 <- unused here) -- see STEP_ASM_D
 #define STEP_ASM(BCLS, CCLS, DN, A, B, C, X, RUN, T, PAD, TREE)                                                        \
@@ -346,6 +371,9 @@ __global__ __launch_bounds__(FILTER_BLOCK, WPS) void probe_run_kernel(const h8 *
         else
             MFMA_ASM_V(d[j], a[0][0], qf[j], c[0]);
     }
+    // (hipcc pads nothing in front of an asm statement it cannot see into: the moves that set up d[] / c[] just above may
+    // end one instruction before the first MFMA of the loop reads them — tools/mfma_hazard_audit.py, operand rule)
+    asm volatile("s_nop 1");
     for (long long tile = t0; tile < t1; tile += NSET) {
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
@@ -372,13 +400,13 @@ __global__ __launch_bounds__(FILTER_BLOCK, WPS) void probe_run_kernel(const h8 *
                     // registers get reused — e.g. for an address — while the MFMA is still going to write them.
                     // The empty statement keeps the accumulator issued NACC-1 steps ago live until here.)
                     STEP_ASM_C0(dn, a[su][0], qf[tt % QT]);
-                    KEEP_V(d[t % NACC]);
+                    KEEP_ALL_V(d);
                 } else if constexpr (TREE == 21) {
                     STEP_ASM_CH(dn, a[su][0], qf[tt % QT]);
-                    KEEP_V(d[t % NACC]);
+                    KEEP_ALL_V(d);
                 } else if constexpr (TREE == 22) {
                     STEP_ASM_AA(dn, a[su][0], qf[tt % QT], c[su]);
-                    KEEP_A(d[t % NACC]);
+                    KEEP_ALL_A(d);
                 } else if constexpr (TREE == 23) {   // literal-zero C + the full tree
                     asm volatile("v_mfma_f32_32x32x16_f16 %0, %7, %8, 0\n\t" TREE8
                                  : "=&v"(dn), "+v"(tmp[t & 1][0]), "+v"(tmp[t & 1][1]), "+v"(tmp[t & 1][2]), "+v"(tmp[t & 1][3]),
@@ -415,6 +443,10 @@ __global__ __launch_bounds__(FILTER_BLOCK, WPS) void probe_run_kernel(const h8 *
         if (__builtin_expect(any != 0ull, 0))
             ++hits;
     }
+    if constexpr (TREE == 22)
+        DRAIN_A(d);
+    else
+        DRAIN_V(d);
     float um = run[0];
 #pragma unroll
     for (int t = 1; t < QT; ++t)

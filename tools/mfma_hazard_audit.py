@@ -109,10 +109,57 @@ def audit(text, need=NEED):
     return sorted(set(found)), n_mfma
 
 
+def audit_operands(text, need=2):
+    """The other direction (round 3): a VGPR written by a VALU instruction and read by an MFMA as its
+    A, B or C operand fewer than `need` wait states later (the matrix core then reads the OLD value).  hipcc pads this for
+    code it schedules itself and pads NOTHING inside an inline-asm string — one arm of the C5 experiments produced wrong
+    answers that way (profiles/r02_c5_variants.txt).  Walks every function in fall-through order (a label resets nothing:
+    a jump target right in front of an MFMA can only add wait states on the taken path, never remove those of the
+    fall-through path that is checked here).  -> (violations, MFMAs looked at); a violation is
+    (function, wait_states, writer_line, mfma_line)."""
+    found, cur, n_mfma = [], None, 0
+    recent = []     # (line, set of VGPRs written, wait states since)
+    for ln, raw in enumerate(text.split("\n"), 1):
+        s = raw.strip()
+        if re.match(r"^_Z\w+:", s):
+            cur, recent = s.split(":")[0], []
+            continue
+        if not s or s[0] in ";." or s.endswith(":"):
+            continue
+        s = s.split(";")[0].strip()
+        if not s:
+            continue
+        if s.startswith("s_nop"):
+            k = int(s.split()[1]) + 1
+            recent = [(l, r, w + k) for (l, r, w) in recent if w + k < need]
+            continue
+        if s.startswith("v_mfma"):
+            n_mfma += 1
+            ops = s.split(None, 1)[1].split(", ")
+            src = set()
+            for o in ops[1:4]:
+                src |= _regs(o)
+            for (l, r, w) in recent:
+                if r & src and w < need:
+                    found.append((cur, w, l, ln))
+            recent = [(l, r, w + 1) for (l, r, w) in recent if w + 1 < need]
+            continue
+        recent = [(l, r, w + 1) for (l, r, w) in recent if w + 1 < need]
+        if s.startswith("v_") and not s.startswith(("v_cmp", "v_cmpx", "v_readlane", "v_readfirstlane")) and " " in s:
+            dst = _regs(s.split(None, 1)[1].split(", ")[0])
+            if dst:
+                recent.append((ln, dst, 0))
+    return sorted(set(found)), n_mfma
+
+
 if __name__ == "__main__":
     need = int(sys.argv[2]) if len(sys.argv) > 2 else NEED
     bad, n = audit(open(sys.argv[1]).read(), need)
     for f in bad:
         print("%s: %d wait states (MFMA line %d, reader line %d)" % f)
     print("%d MFMAs audited, %d short of %d wait states" % (n, len(bad), need))
-    sys.exit(1 if bad else 0)
+    bad2, _ = audit_operands(open(sys.argv[1]).read())
+    for f in bad2:
+        print("%s: operand written %d wait states before the MFMA reads it (writer line %d, MFMA line %d)" % f)
+    print("%d MFMA operands written fewer than 2 wait states before the read" % len(bad2))
+    sys.exit(1 if bad or bad2 else 0)
