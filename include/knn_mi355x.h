@@ -152,8 +152,10 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
  *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
  *             (shards of at least 64 MiB)
- *   "deepk"   tuning / A-B: the LDS-tiled filter scan for 32 < k <= 128 with >= 512 queries: 0 = 4 waves
- *             x 4 query tiles share each staged reference tile (default); 1 = 8 waves per block
+ *   "deepk"   tuning / A-B: the LDS-tiled filter scan for 32 < k <= 128 with >= 512 queries: 0 = auto (4 waves x 4
+ *             query tiles share every staged reference tile; for k > 64 four reference tiles are staged per barrier by
+ *             LDS-DMA), 1 = 8 waves per block, 2 / 4 = that many reference tiles per barrier, 3 = one tile per
+ *             barrier through registers (the round-2 kernel)
  *   "ingest"  indexes created from HOST rows (knn_index_create with refs_on_device = 0, and the
  *             staged-filter case of cudaCallback): 0 = the rows go over in chunks and every chunk's
  *             MFMA layouts are built as soon as it has landed (robust box from a strided host

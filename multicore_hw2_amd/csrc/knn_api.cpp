@@ -331,8 +331,8 @@ int knn_set_option(const char *name, long long value)
         return KNN_OK;
     }
     if (!strcmp(name, "deepk")) {
-        if (value < 0 || value > 1)
-            return fail(KNN_EINVAL, "knn_set_option: deepk must be 0 (LDS-tiled scan, 4 waves per block) or 1 (8 waves per block)");
+        if (value < 0 || value > 4)
+            return fail(KNN_EINVAL, "knn_set_option: deepk must be 0 (auto), 1 (8 waves per block), 2 or 4 (tiles per barrier, LDS-DMA) or 3 (one tile per barrier)");
         g_opt_deepk = value;
         return KNN_OK;
     }

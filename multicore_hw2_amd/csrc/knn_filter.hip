@@ -634,7 +634,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : 2)) void k
 //   SAMPLE = false: all tiles, threshold test -> per-wave record slices (as knn_filter_kernel)
 //   grid.x blocks split the (sampled) reference tiles, grid.y = groups of 4*QT query tiles.
 // ------------------------------------------------------------------------------------------
-template <int KT, int QT, bool SAMPLE, int BLOCK = FILTER_BLOCK>
+template <int KT, int QT, bool SAMPLE, int BLOCK = FILTER_BLOCK, int TPB = 1>
 __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, long long stride,
@@ -644,8 +644,12 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     constexpr int WAVES = BLOCK / 64;   // waves that share every staged reference tile
     constexpr int CHUNKS = KT * 64;                 // 16-byte chunks of A per tile
     constexpr int CPT = (CHUNKS + BLOCK - 1) / BLOCK;
-    __shared__ h8 s_a[2][CHUNKS];
-    __shared__ f4v s_n[2][8];
+    // TPB > 1 (round 3): TPB reference tiles per barrier, staged by LDS-DMA (global_load_lds, no staging registers) — the
+    // per-tile barrier coupled the block's four waves, each of which shares its SIMD with a wave of another block, and
+    // waves spent 38 % of their cycles parked at it (profiles/r02_c5_variants.txt); with TPB tiles between two barriers a
+    // wave that is held up has TPB x 32 MFMAs of slack before the others wait for it
+    __shared__ h8 s_a[2][TPB * CHUNKS];
+    __shared__ f4v s_n[2][TPB * 8];
     if (!SAMPLE && ctl[KNN_CTL_FALLBACK] != 0u)
         return;
     const int tid = threadIdx.x;
@@ -676,7 +680,97 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     unsigned short *__restrict__ my_rows = SAMPLE ? nullptr : rec_rows + list * slice;
     unsigned cnt = 0u;
 
-    if (i0 < i1) {
+    // one reference tile (fragments at a_lds, norm tile at n_lds) against this wave's QT query tiles
+    auto score_tile = [&](const h8 *a_lds, const f4v *n_lds, long long i) __attribute__((always_inline)) {
+        f16v c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f4v v = n_lds[2 * g + (lane >> 5)];
+            c[4 * g + 0] = v[0];
+            c[4 * g + 1] = v[1];
+            c[4 * g + 2] = v[2];
+            c[4 * g + 3] = v[3];
+        }
+        f16v d[QT];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const h8 a = a_lds[kk * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                d[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[t][kk], kk == 0 ? c : d[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const f16v &x = d[t];
+            const float m0 = min3f(x[0], x[1], x[2]);
+            const float m1 = min3f(x[3], x[4], x[5]);
+            const float m2 = min3f(x[6], x[7], x[8]);
+            const float m3 = min3f(x[9], x[10], x[11]);
+            const float m4 = min3f(x[12], x[13], x[14]);
+            const float m5 = min3f(m0, m1, m2);
+            const float m6 = min3f(m3, m4, x[15]);
+            if (SAMPLE) {
+                um[t] = min3f(m5, m6, um[t]);
+            } else {
+                const float mn = min3f(m5, m6, th[t]);
+                const bool hit = mn < th[t];
+                const u64 mask = __ballot(hit);
+                if (__builtin_expect(mask != 0ull, 0)) {
+                    if (hit) {
+                        const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (pos < slice) {
+                            my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) |
+                                          ((u64)(i * stride) << 1) | (u64)(lane >> 5);
+                            unsigned rm = 0u;
+#pragma unroll
+                            for (int r16 = 0; r16 < 16; ++r16)
+                                rm |= x[r16] < th[t] ? (1u << r16) : 0u;
+                            my_rows[pos] = (unsigned short)rm;
+                        }
+                    }
+                    cnt += (unsigned)__popcll(mask);
+                }
+            }
+        }
+    };
+    if constexpr (TPB > 1) {
+        static_assert(CHUNKS % 64 == 0 && (CHUNKS / 64) % WAVES == 0, "a tile's 1 KiB pieces are dealt out evenly to the waves");
+        constexpr int PPW = CHUNKS / 64 / WAVES;   // 1 KiB pieces of a tile each wave requests
+        // LDS-DMA: lane l of the wave copies 16 bytes from ITS global address to (wave-uniform LDS base) + 16 l
+        auto issue = [&](int buf, long long j0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < TPB; ++u) {
+                const long long i = j0 + u;
+                if (i < i1) {   // block-uniform
+                    const long long tile = i * stride;
+#pragma unroll
+                    for (int pp = 0; pp < PPW; ++pp) {
+                        const int piece = wib * PPW + pp;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rf + (size_t)tile * CHUNKS + piece * 64 + lane),
+                                                         (__attribute__((address_space(3))) void *)&s_a[buf][u * CHUNKS + piece * 64], 16, 0, 0);
+                    }
+                    if (wib == 0 && lane < 8)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rn + (size_t)tile * 32 + 4 * lane),
+                                                         (__attribute__((address_space(3))) void *)&s_n[buf][u * 8], 16, 0, 0);
+                }
+            }
+        };
+        if (i0 < i1) {
+            issue(0, i0);
+            __syncthreads();   // (waits for the DMA: hipcc drains vmcnt in front of the barrier)
+            int buf = 0;
+            for (long long j0 = i0; j0 < i1; j0 += TPB, buf ^= 1) {
+                if (j0 + TPB < i1)
+                    issue(buf ^ 1, j0 + TPB);   // in flight while this group of tiles is scored
+#pragma unroll
+                for (int u = 0; u < TPB; ++u)
+                    if (j0 + u < i1)   // block-uniform
+                        score_tile(&s_a[buf][u * CHUNKS], &s_n[buf][u * 8], j0 + u);
+                __syncthreads();   // the next group has landed; nobody reads this one any more
+            }
+        }
+    } else if (i0 < i1) {
         h8 stage_a[CPT];
         f4v stage_n = {0.f, 0.f, 0.f, 0.f};
         auto fetch = [&](long long i) {
@@ -1689,7 +1783,21 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    if (wide_scan)
+    // `deepk`: 0 = auto (k > 64: four reference tiles per barrier staged by LDS-DMA, -2.4 % at C5; else one), 1 = 8 waves per
+    // block, 2 / 4 = that many tiles per barrier, 3 = one tile per barrier (the round-2 kernel)
+    const int tpb = st.deepk_variant == 2 ? 2 : (st.deepk_variant == 4 || (st.deepk_variant == 0 && KT == 8)) ? 4 : 1;
+    if (tpb > 1 && !wide_scan) {
+        if (tpb == 2)
+            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 2>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                               (unsigned short *)(w.records + w.rec_cap));
+        else
+            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                               (unsigned short *)(w.records + w.rec_cap));
+    } else if (wide_scan)
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, 512>), dim3(wgx, wgy), dim3(512), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,

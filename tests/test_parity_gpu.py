@@ -826,7 +826,7 @@ def test_grid_index_is_the_resident_path_at_c2_scale_and_steps_aside_for_bad_dat
     assert path != 3
 
 
-@pytest.mark.parametrize("deepk", [1], ids=["tiled_8_waves"])
+@pytest.mark.parametrize("deepk", [1, 2, 3, 4], ids=["tiled_8_waves", "2_tiles_per_barrier_lds_dma", "1_tile_per_barrier_registers", "4_tiles_per_barrier_lds_dma"])
 def test_deep_k_scan_variants_behind_the_deepk_option_stay_bit_exact(oracle, deepk):
     """The A/B arm of the deep-K scan that is kept selectable (8 waves per block; profiles/r02_c5_variants.txt:
     no faster than the default 4-wave kernel) must give the same indices, row masks included."""
