@@ -354,7 +354,7 @@ def main():
             phys = 36.0 * n_local * 1.04
             roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
                     "kernel": {0: "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",
-                               1: "knn_cells_scan (round-2 chain in front of it)",
+                               1: "knn_cells_scan (behind the round-2 chain: fragments, seed, match)",
                                2: "knn_cells_scan (norm tile out of an extra MFMA)",
                                3: "knn_cells_sweep (match + scan + re-rank in one persistent kernel)"}[args.cells_variant],
                     "bytes_per_launch": phys, "bytes_source": "layout size (36 B per position, 4 % padding)"}

@@ -1233,8 +1233,10 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 2 : W <= 12 ? 3 : 4)) void knn_ce
 }
 
 // (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512)
+// (HIP's second launch bound is waves per SIMD: 6 = at most 80 registers.  Left at 2 the allocator settled at 96-98 once the
+// dense-cell and overflow paths were in — 4 waves per SIMD, and the kernel alone went from 0.035 to 0.042 ms at 2^21 rows)
 template <bool NORM_MFMA>
-__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel(
+__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ rn2,
     const unsigned *__restrict__ tile_start, unsigned ncells,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
@@ -1291,6 +1293,9 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
             const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
             // the first two blocks of the list travel with the tiles (one round trip per cell)
             const unsigned l0 = dense ? (unsigned)lane : (unsigned)list[min((unsigned)lane, nq - 1u)];
+            // (round 3: blocks three and four of the list too — lists average 120 entries on the 2^21-row shards of an
+            // 8-GPU run, and every block beyond the second was a dependent read from memory)
+            const unsigned l1 = dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
             for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
                 const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
                 h8 ar[CELL_TILES_PER_PASS];
@@ -1321,28 +1326,22 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 2) void knn_cells_scan_kernel
                     if (q0 < 64u) {
                         const unsigned from = __shfl(l0, (int)idx, KNN_WAVE);
                         qid = valid ? from : __shfl(l0, 0, KNN_WAVE);
+                    } else if (q0 < 128u) {
+                        const unsigned from = __shfl(l1, (int)(idx - 64u), KNN_WAVE);
+                        qid = valid ? from : __shfl(l0, 0, KNN_WAVE);
                     } else {
                         qid = dense ? (valid ? idx : 0u) : (unsigned)list[valid ? idx : 0u];
                     }
                     const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
                     const float th = valid ? s_thr[qid] : -INFINITY;
-                    u64 any = 0ull;
-                    u64 masks[CELL_TILES_PER_PASS];
+                    // (a hit is recorded right behind its tile: parking the nine masks of a pass until its end, as round 2
+                    // did, kept 18 registers busy with them — the allocator put the mask pairs in VGPRs)
 #pragma unroll
                     for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                        masks[p] = 0ull;
                         if (p < nt) {
-                            masks[p] = cell_tile_step<NORM_MFMA>(ar[p], nw[p], my_nrm, p, half, b, th);
-                            any |= masks[p];
-                        }
-                    }
-                    if (__builtin_expect(any != 0ull, 0)) {
-                        const u64 me = 1ull << lane;
-#pragma unroll
-                        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                            const u64 mask = masks[p];
-                            if (mask != 0ull) {
-                                if (mask & me) {
+                            const u64 mask = cell_tile_step<NORM_MFMA>(ar[p], nw[p], my_nrm, p, half, b, th);
+                            if (__builtin_expect(mask != 0ull, 0)) {
+                                if ((mask >> lane) & 1ull) {
                                     const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                     const u64 r = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
@@ -1680,8 +1679,8 @@ static hipError_t launch_sweep(FilterState &st, FilterWorkspace &w, int m, int m
 }
 
 // One batch of <= KNN_CELL_BATCH queries.  `cells_variant`: 0 = prep + match + scan (the default chain), 1 = the round-2
-// chain (query fragments by the caller, seed, match, scan), 2 = as 0 with the scan's norms out of an extra MFMA instead of
-// LDS, 3 = prep + sweep (match, scan and re-rank in one persistent kernel: an experiment that did not pay).
+// chain (query fragments by the caller, seed, match, scan), 2 = as 0 with the scan's norm tile out of an extra MFMA instead
+// of LDS, 3 = prep + sweep (match, scan and re-rank in one persistent kernel: an experiment that did not pay).
 // Records in w, as the full scan leaves them (variant 3: none, w.nlists = 0).
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, const float *r, long long base,
                            u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys)
