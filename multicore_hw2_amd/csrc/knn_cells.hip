@@ -1270,6 +1270,9 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
     const unsigned per_wave = (ncells + nwaves - 1u) / nwaves;
     for (unsigned g0 = 0u; g0 < per_wave; g0 += 64u) {
         // counts and tile ranges of up to 64 cells, one per lane
+        // (measured and not kept, round 3: handing the cells out through an odd multiplier — cells w, w + W, ... share their low
+        // bits and with them the queries that list them, the busiest wave has twice the average number of tile steps — left the
+        // 2^21-row shard where it was and cost C3 4 %: the moving window over the layout is worth more than the balance)
         const unsigned mine = (g0 + (unsigned)lane) * nwaves + wave;
         const bool in = g0 + (unsigned)lane < per_wave && mine < ncells;
         unsigned v_nq = in ? cell_counts[mine] : 0u;
@@ -1750,6 +1753,27 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
                            m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
     FTRY(hipGetLastError());
+    if (getenv("KNN_MI355X_TRACE_CELLS")) {   // development aid: the lists of this batch and how evenly the scan's waves are loaded (synchronises)
+        std::vector<unsigned> hc((size_t)c.ncells), ht((size_t)c.ncells + 1);
+        FTRY(hipStreamSynchronize(s));
+        FTRY(hipMemcpy(hc.data(), w.cell_counts, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        FTRY(hipMemcpy(ht.data(), c.tile_start, ht.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        std::vector<unsigned> sorted(hc);
+        std::sort(sorted.begin(), sorted.end());
+        const unsigned nwaves = w.nlists;
+        std::vector<double> wl((size_t)nwaves, 0.0);
+        double total = 0, biggest = 0;
+        for (unsigned cell = 0; cell < c.ncells; ++cell) {
+            const double steps = (double)((std::min(hc[cell], c.cap + 1u) + 31u) / 32u) * (double)(ht[cell + 1] - ht[cell]);
+            wl[cell % nwaves] += steps;   // (plain order: wave w takes cells w, w + nwaves, ...; the scan's scatter spreads them)
+            total += steps;
+            biggest = std::max(biggest, steps);
+        }
+        const double wmax = *std::max_element(wl.begin(), wl.end());
+        fprintf(stderr, "[knn cells] m %d: %u cells; list length min %u  p10 %u  median %u  p90 %u  max %u; tile steps %.0f in all, %.0f in the largest "
+                        "cell; %u waves: %.1f steps each on average, %.0f on the busiest\n", m, c.ncells, sorted.front(), sorted[sorted.size() / 10],
+                sorted[sorted.size() / 2], sorted[sorted.size() * 9 / 10], sorted.back(), total, biggest, nwaves, total / nwaves, wmax);
+    }
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
     const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
