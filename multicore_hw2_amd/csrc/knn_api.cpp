@@ -70,7 +70,8 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_deepk{0};
-std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pruned path (0 prep + sweep, 1 round-2 chain, 2 prep + round-2 match / scan with MFMA norms)
+std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pruned path (knn_cells_query)
+std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
@@ -336,6 +337,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_deepk = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "scan_blocks")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: scan_blocks must be 0 (auto), 1 or 2");
+        g_opt_scan_blocks = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "cells_variant")) {
         if (value < 0 || value > 3)
             return fail(KNN_EINVAL, "knn_set_option: cells_variant must be 0 .. 3");
@@ -391,6 +398,8 @@ long long knn_get_option(const char *name)
         return g_opt_cells;
     if (name && !strcmp(name, "cells_variant"))
         return g_opt_cells_variant;
+    if (name && !strcmp(name, "scan_blocks"))
+        return g_opt_scan_blocks;
     if (name && !strcmp(name, "deepk"))
         return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -641,6 +650,11 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         idx->filter.deepk_variant = (int)g_opt_deepk;
         idx->filter.cells_policy = (int)g_opt_cells;
         idx->filter.cells_variant = (int)g_opt_cells_variant;
+        // batches in flight on several workspace slots = a caller after throughput: the pruned scan of a small shard then
+        // takes ONE block per CU, so that the next batch's preparation kernels find registers beside it (knn_cells_query)
+        if (slot != 0)
+            idx->filter.several_slots = true;
+        idx->filter.scan_blocks = (int)g_opt_scan_blocks;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys));

@@ -1703,7 +1703,12 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     w.has_rows = false;
     w.pieces = RerankPieces();
     const double sigma2 = (double)st.sigma * (double)st.sigma;
-    unsigned gx = (unsigned)num_cu * 2u;   // scan: two blocks of CELL_SCAN_WAVES waves per CU
+    // scan grid: two blocks of CELL_SCAN_WAVES waves per CU fill every SIMD's registers (6 waves x 80) and give the shortest
+    // launch — and leave nothing for the kernels of the next batch, so with batches in flight side by side the step was the
+    // SUM of the kernels' durations.  One block per CU: the scan alone takes 10-20 % longer, the step of a shard of up to 2^14
+    // cells 5-7 % less (0.0465 -> 0.0444 ms at 2^21 rows; at C3 the two are within 1 %: it keeps two).
+    const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 16384u);
+    unsigned gx = (unsigned)num_cu * (one_block ? 1u : 2u);
     if (gx * CELL_SCAN_WAVES > c.ncells)
         gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
     w.nlists = gx * CELL_SCAN_WAVES;
