@@ -593,7 +593,8 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 &a, unsigned nw, const f4
 #define CELL_PREP_WAVES 4
 #define CELL_PREP_TILES 9     // seed tiles a wave requests at once (a cell of 144 .. 288 rows: one round trip)
 
-__global__ __launch_bounds__(64 * CELL_PREP_WAVES, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
+template <int PW>   // waves per query: 4 (one seed cell each) or 2 (two each: half the registers held, see knn_cells_query)
+__global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
     const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
     const float *__restrict__ center, float sigma, const unsigned *__restrict__ tile_start, long long ntiles,
     const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
@@ -603,13 +604,13 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES, 4) void knn_cells_prep_kernel
 {
 #pragma clang fp contract(off)
     __shared__ float s_gap[16][CELL_MAX_BINS];
-    __shared__ float s_red[CELL_PREP_WAVES];
+    __shared__ float s_red[PW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = blockIdx.x;
     // housekeeping folded in here to save launches: the record counters of the scan, the control words of the NEXT
     // batch on this slot (calls on a slot are stream-ordered; this batch's own words were cleared by the previous one)
-    for (unsigned i = blockIdx.x * (64u * CELL_PREP_WAVES) + (unsigned)tid; i < nlists; i += gridDim.x * (64u * CELL_PREP_WAVES))
+    for (unsigned i = blockIdx.x * (64u * PW) + (unsigned)tid; i < nlists; i += gridDim.x * (64u * PW))
         counts[i] = 0u;
     if (blockIdx.x == 0 && tid == 0) {
         ctl_next[KNN_CTL_FALLBACK] = 0u;
@@ -655,9 +656,9 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES, 4) void knn_cells_prep_kernel
     if (wib == 0 && (lane & 31) == 0)
         qfg[frag_at] = bq;   // for the scan (lanes 0 and 32 hold the two halves)
 
-    // ---- squared gaps to every bin of every dimension (scaled units, rounded down): one entry per thread
-    {
-        const int d = tid >> 4, b = tid & 15;
+    // ---- squared gaps to every bin of every dimension (scaled units, rounded down): 256 entries over the block's threads
+    for (int e = tid; e < 256; e += 64 * PW) {
+        const int d = e >> 4, b = e & 15;
         float v = 0.0f;
         if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
             const int nbins = 1 << g.nb[d];
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES, 4) void knn_cells_prep_kernel
     // come from the lanes that hold them — nbl, shl above — as wave-uniform values: indexing the geometry struct with a
     // run-time d is a dependent scalar load from the kernel arguments per dimension and entry.)
     const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);   // nl >= 64: a wave's entries are all low or all high
-    for (int e0 = 64 * wib; e0 < nl + nh; e0 += 64 * CELL_PREP_WAVES) {
+    for (int e0 = 64 * wib; e0 < nl + nh; e0 += 64 * PW) {
         const int e = e0 + lane;
         const bool low = e0 < nl;   // wave-uniform
         const unsigned ecode = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
@@ -786,31 +787,39 @@ __global__ __launch_bounds__(64 * CELL_PREP_WAVES, 4) void knn_cells_prep_kernel
                 }
         }
     };
-    score_run((unsigned)__builtin_amdgcn_readlane((int)v_tb, wib), (unsigned)__builtin_amdgcn_readlane((int)v_nt, wib), 1u);
+#pragma unroll
+    for (int c = 0; c < CELL_SEEDS / PW; ++c)   // this wave's seed cells
+        score_run((unsigned)__builtin_amdgcn_readlane((int)v_tb, wib + PW * c), (unsigned)__builtin_amdgcn_readlane((int)v_nt, wib + PW * c), 1u);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)   // (every column is this query; the halves hold different rows)
         um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
     if (lane == 0)
         s_red[wib] = um;
     __syncthreads();
-    float u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    float u = s_red[0];
+#pragma unroll
+    for (int i = 1; i < PW; ++i)
+        u = fminf(u, s_red[i]);
     if (!(u < INFINITY) && ntiles > 0) {   // block-uniform
         // nothing in the seed cells (a query in an empty corner of a clustered set): any real row gives a valid, if
-        // loose, bound — look at 64 tiles spread over the whole layout, 16 per wave
+        // loose, bound — look at 64 tiles spread over the whole layout, 64 / PW per wave
         __syncthreads();   // s_red has been read by everybody
         const unsigned total = (unsigned)(ntiles > 64 ? 64 : ntiles);
         const unsigned stride = (unsigned)(ntiles > 64 ? ntiles / 64 : 1);
-        const unsigned mine_first = (unsigned)wib * 16u;   // (two passes of CELL_PREP_TILES)
+        const unsigned mine_first = (unsigned)wib * (64u / PW);
         um = INFINITY;
         if (mine_first < total)
-            score_run(mine_first * stride, min(16u, total - mine_first), stride);
+            score_run(mine_first * stride, min(64u / PW, total - mine_first), stride);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
         if (lane == 0)
             s_red[wib] = um;
         __syncthreads();
-        u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+        u = s_red[0];
+#pragma unroll
+        for (int i = 1; i < PW; ++i)
+            u = fminf(u, s_red[i]);
         if (tid == 0)
             atomicAdd(&ctl[KNN_CTL_WIDE_SEEDS], 1u);   // rare; statistics only
     }
@@ -1734,10 +1743,18 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
             w.nlists = 0u;   // no record lists: the sweep re-ranks its hits itself
             w.slice = w.ovf_base = w.ovf_cap = 0u;
         }
-        hipLaunchKernelGGL(knn_cells_prep_kernel, dim3((unsigned)m_padded), dim3(64 * CELL_PREP_WAVES), 0, s, q, m,
-                           m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
-                           st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
-                           w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+        // batches in flight side by side: two waves per query (two seed cells each) — half the registers the launch holds,
+        // 0.0421 -> 0.0408 ms per step at n_local 2^21 for 2 us more when a batch runs alone; else four waves per query
+        if (st.several_slots)
+            hipLaunchKernelGGL(knn_cells_prep_kernel<2>, dim3((unsigned)m_padded), dim3(64 * 2), 0, s, q, m,
+                               m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
+                               st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
+                               w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+        else
+            hipLaunchKernelGGL(knn_cells_prep_kernel<4>, dim3((unsigned)m_padded), dim3(64 * 4), 0, s, q, m,
+                               m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
+                               st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
+                               w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
         FTRY(hipGetLastError());
         if (variant == 3) {
             int cshift = 0;

@@ -566,53 +566,60 @@ __device__ __forceinline__ u64 rerank_pair(const float *__restrict__ Q, const fl
     return ~0ull;
 }
 
-template <int K>  // K > 0: compile-time dimension (all row loads issue before the first use)
+template <int K, bool LPW = false>  // K > 0: compile-time dimension (all row loads issue before the first use)
 __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__restrict__ Q,
                                                                const float *__restrict__ R, int krt,
                                                                long long n, long long base,
                                                                const u64 *__restrict__ rec,
                                                                const unsigned short *__restrict__ rec_rows,
-                                                               const unsigned *__restrict__ counts,
+                                                               const unsigned *__restrict__ counts, unsigned nlists,
                                                                unsigned slice, unsigned *__restrict__ ctl,
                                                                u64 *__restrict__ keys, RerankPieces pieces,
                                                                const unsigned *__restrict__ perm,
                                                                unsigned ovf_base, unsigned ovf_cap)
 {
-    // one block per record list (= per filter wave); the list's piece gives its first query
+    // LPW = true (the cell-pruned path: ~3000 records over 6144 lists, most of them empty): one WAVE per record list, four
+    // lists per block — a quarter of the blocks and of the registers the launch holds while the next batch's kernels
+    // wait for room; else one block per list (= per filter wave).  The list's piece gives its first query.
+    const unsigned list_id = LPW ? blockIdx.x * (KNN_BLOCK / KNN_WAVE) + (threadIdx.x >> 6) : blockIdx.x;
+    const unsigned tid_l = LPW ? (threadIdx.x & 63u) : threadIdx.x;       // thread inside the group that owns the list
+    constexpr unsigned GROUP = LPW ? KNN_WAVE : KNN_BLOCK;
     unsigned qrow_base = pieces.qrow_base[0];
 #pragma unroll
     for (int i = 1; i < 4; ++i)
-        if (blockIdx.x >= pieces.list_base[i])
+        if (list_id >= pieces.list_base[i])
             qrow_base = pieces.qrow_base[i];
     if (ctl[KNN_CTL_FALLBACK] != 0u)
         return;  // the exact scan is going to run anyway: do not re-rank a truncated candidate set
     const int k = K > 0 ? K : krt;
-    const unsigned want = counts[blockIdx.x];
-    const unsigned nrec = min(want, slice);
-    // (no shared record counter here: 2048 blocks adding to one word cost ~23 us; the host sums
-    // counts[] when statistics are asked for)
-    if (threadIdx.x == 0 && want > slice)
-        ctl[KNN_CTL_FALLBACK] = 1u;  // candidates were dropped: the gated exact scan takes over
-    const u64 *__restrict__ list = rec + (size_t)blockIdx.x * slice;
-    // 16 consecutive lanes share one record (one query): their keys are min-folded with shuffles
-    // and ONE guarded atomic is issued per record (the keys sit on a handful of cache lines; the
-    // unguarded 16-per-record form spent ~1 ms in atomic contention at 270k records).
-    const unsigned total = (nrec * 16u + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
-    for (unsigned c = threadIdx.x; c < total; c += KNN_BLOCK) {
-        u64 key = ~0ull;
-        unsigned qi = 0u;
-        if (c < nrec * 16u) {
-            const unsigned rmask = rec_rows ? rec_rows[(size_t)blockIdx.x * slice + (c >> 4)] : 0xFFFFu;
-            key = rerank_pair<K>(Q, R, k, n, base, list[c >> 4], c & 15u, rmask, qrow_base, perm, qi);
-        }
+    if (list_id < nlists) {
+        const unsigned want = counts[list_id];
+        const unsigned nrec = min(want, slice);
+        // (no shared record counter here: 2048 blocks adding to one word cost ~23 us; the host sums
+        // counts[] when statistics are asked for)
+        if (tid_l == 0 && want > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;  // candidates were dropped: the gated exact scan takes over
+        const u64 *__restrict__ list = rec + (size_t)list_id * slice;
+        // 16 consecutive lanes share one record (one query): their keys are min-folded with shuffles
+        // and ONE guarded atomic is issued per record (the keys sit on a handful of cache lines; the
+        // unguarded 16-per-record form spent ~1 ms in atomic contention at 270k records).
+        const unsigned total = (nrec * 16u + GROUP - 1) / GROUP * GROUP;
+        for (unsigned c = tid_l; c < total; c += GROUP) {
+            u64 key = ~0ull;
+            unsigned qi = 0u;
+            if (c < nrec * 16u) {
+                const unsigned rmask = rec_rows ? rec_rows[(size_t)list_id * slice + (c >> 4)] : 0xFFFFu;
+                key = rerank_pair<K>(Q, R, k, n, base, list[c >> 4], c & 15u, rmask, qrow_base, perm, qi);
+            }
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const u64 o = __shfl_xor(key, off, KNN_WAVE);
-            key = o < key ? o : key;
+            for (int off = 8; off > 0; off >>= 1) {
+                const u64 o = __shfl_xor(key, off, KNN_WAVE);
+                key = o < key ? o : key;
+            }
+            // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
+            if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+                key_atomic_min(&keys[qi], key);
         }
-        // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
-        if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
-            key_atomic_min(&keys[qi], key);
     }
     // the shared overflow area (cell-pruned path: what did not fit a wave's slice), all blocks striding over it
     if (ovf_cap != 0u) {
@@ -948,7 +955,20 @@ hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r,
     }
 #define KNN_RERANK(KK)                                                                                     \
     hipLaunchKernelGGL(knn_rerank_kernel<KK>, dim3(nlists), dim3(KNN_BLOCK), 0, s, q, r, k, n, base, rec, rec_rows, \
-                       counts, slice, ctl, keys, pieces, perm, ovf_base, ovf_cap)
+                       counts, nlists, slice, ctl, keys, pieces, perm, ovf_base, ovf_cap)
+#define KNN_RERANK_LPW(KK)                                                                                 \
+    hipLaunchKernelGGL((knn_rerank_kernel<KK, true>), dim3((nlists + KNN_WAVES - 1) / KNN_WAVES), dim3(KNN_BLOCK), 0, s, q, r, k, n, \
+                       base, rec, rec_rows, counts, nlists, slice, ctl, keys, pieces, perm, ovf_base, ovf_cap)
+    if (perm) {   // cell-sorted layout = the pruned scan's records: few, spread thin
+        switch (k) {
+        case 3: KNN_RERANK_LPW(3); break;
+        case 4: KNN_RERANK_LPW(4); break;
+        case 8: KNN_RERANK_LPW(8); break;
+        case 16: KNN_RERANK_LPW(16); break;
+        default: KNN_RERANK_LPW(0); break;
+        }
+        return hipGetLastError();
+    }
     switch (k) {
     case 3: KNN_RERANK(3); break;
     case 4: KNN_RERANK(4); break;
@@ -957,6 +977,7 @@ hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r,
     default: KNN_RERANK(0); break;
     }
 #undef KNN_RERANK
+#undef KNN_RERANK_LPW
     return hipGetLastError();
 }
 
