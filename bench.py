@@ -400,6 +400,11 @@ def main():
                         roof["bytes_source"] = "PMC (traffic)"
             else:
                 roof["traffic_source"] = "profiles/%s is from another build of the kernels: not quoted" % pmc_name
+        if path_taken == 4 and m < 512 and roof.get("traffic") is None:
+            # a small batch lists only some of the cells: the kernel reads a fraction of the layout and there is no byte model
+            # for it short of a PMC pass (m = 1 at C3 reads its ~1600 cells: 2.5 % of the layout)
+            roof["bytes_per_launch"] = None
+            roof["bytes_source"] = "batch too small to touch every cell: the layout size is not what the kernel reads"
         if roof.get("bound") == "hbm":
             bpl = roof.get("bytes_per_launch")
             roof["achieved"] = bpl / (kern_ms_alone * 1e-3) / 1e9 if bpl else None
@@ -424,7 +429,7 @@ def main():
         if path_taken == 4:
             roof["ceiling"] = {
                 "what": "HBM read rate a bare reader of the same access pattern reaches on this chip",
-                "GBps": 6500.0, "ms_for_this_launch": roof["bytes_per_launch"] / 6500e9 * 1e3,
+                "GBps": 6500.0, "ms_for_this_launch": (roof["bytes_per_launch"] / 6500e9 * 1e3) if roof["bytes_per_launch"] else None,
                 "source": "tools/read_probe2.hip, tools/read_probe.hip (profiles/r02_cells_probes.txt), DESIGN 4.5"}
 
         cpu = None
