@@ -11,6 +11,7 @@ from tests.oracle_lib import TA_SAMPLES
 from tests.test_oracle import read_golden_indices
 
 pytestmark = pytest.mark.gpu
+THREADS = min(16, os.cpu_count() or 1)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -654,6 +655,66 @@ def test_rccl_exchange_step_with_a_one_device_communicator(oracle):
     finally:
         for name in ("rccl", "shards", "stream"):
             pkg.set_option(name, 0)
+
+
+def test_a_failing_rccl_reduction_falls_back_to_the_host_merge(oracle):
+    """in the automatic mode a run-time RCCL failure (communicator creation on a node it does not
+    like, a failed collective) must not end the process — the reduction writes to scratch buffers, so the shards' keys are
+    still what the scans left and the host merge takes over.  The test hook KNN_MI355X_TEST_RCCL_FAIL makes the reduction
+    fail after the shards have run; on a one-GPU box that code is only reachable with rccl = 1, whose own reaction (the
+    reference's print-and-exit) the hook replaces by the automatic mode's."""
+    k, m, n = 16, 257, 150001
+    Q, R = oracle.synth(m * k, 61), oracle.synth(n * k, 62)
+    want = oracle.v0(k, Q, R)
+    done = pkg.get_option("rccl_reductions")
+    os.environ["KNN_MI355X_TEST_RCCL_FAIL"] = "1"
+    try:
+        pkg.set_option("rccl", 1)
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), want)
+        assert pkg.get_option("rccl_reductions") == done      # nothing was reduced by RCCL: the host merged
+    finally:
+        del os.environ["KNN_MI355X_TEST_RCCL_FAIL"]
+        pkg.set_option("rccl", 0)
+    pkg.set_option("rccl", 1)
+    try:
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), want)
+        assert pkg.get_option("rccl_reductions") == done + 1  # and without the hook RCCL does reduce
+    finally:
+        pkg.set_option("rccl", 0)
+
+
+def test_grid_index_on_one_live_axis_with_hundreds_of_thousands_of_cells(oracle):
+    """k = 1 (and k <= 4 with one varying axis) gives the grid up to 2^19 cells on its one axis, where the
+    fp32 cell assignment is off by a visible fraction of a cell; the stop rule's allowance has to cover that
+    (tests/test_grid_logic.py restates the rule on the CPU).  Here the device: a box not anchored at 0, a sparse stretch,
+    every answer against the oracle."""
+    rng = np.random.default_rng(12)
+    n, m = 1 << 21, 4096
+    x = (3.7 + 2.0 * rng.random(n)).astype(np.float32)
+    keep = (np.abs(x - np.float32(5.5)) > 0.1) | (rng.random(n) < 0.02)
+    R1 = x[keep]
+    Q1 = (3.7 + 2.0 * rng.random(m)).astype(np.float32)
+    for k in (1, 3):
+        if k == 1:
+            R, Q = R1.reshape(-1, 1), Q1.reshape(-1, 1)
+        else:                                    # one varying axis among three
+            R = np.zeros((len(R1), 3), dtype=np.float32)
+            R[:, 1] = R1
+            R[:, 0] = np.float32(0.25)
+            R[:, 2] = np.float32(-7.0)
+            Q = np.zeros((m, 3), dtype=np.float32)
+            Q[:, 1] = Q1
+            Q[:, 0] = np.float32(0.25)
+            Q[:, 2] = np.float32(-7.0)
+        want = oracle.v0(k, Q, R, threads=THREADS)
+        ix = pkg.KnnIndex(k, R)
+        try:
+            got = ix.query(Q)
+            st = ix.last_stats()
+        finally:
+            ix.close()
+        assert st[0] == 3, st                    # served by the grid index
+        np.testing.assert_array_equal(got, want, err_msg=f"k={k}")
 
 
 @pytest.mark.parametrize("k,m,n", [(16, 1024, 3_300_001), (3, 700, 6 << 20), (40, 600, 900_000)])
