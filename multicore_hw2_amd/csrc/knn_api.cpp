@@ -471,9 +471,9 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     const bool want_cells = k <= 16 && n_local >= (1ll << 17) &&
                             (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));
     if (build_filter < 0) {
-        // library policy: shards of >= 65536 rows; for 32 < k <= 128 (3k+3 exact lane-ops per pair,
-        // one query per lane above k = 64) the MFMA filter pays off from 4096 rows already
-        build_filter = g_opt_path == 2 || n_local >= 65536 || (k > 32 && k <= 128 && n_local >= 4096);
+        // library policy: shards of >= 65536 rows; for 32 < k <= 512 (3k+3 exact lane-ops per pair,
+        // one query per lane above k = 64, row-per-lane kernels above 128) the MFMA filter pays off from 4096 rows already
+        build_filter = g_opt_path == 2 || n_local >= 65536 || (k > 32 && k <= KNN_FILTER_MAX_K && n_local >= 4096);
         idx->filter_wanted = build_filter && n_local < 65536 && g_opt_path != 2;
     }
     const bool grid_planned = k <= 4 && (g_opt_path == 3 || (g_opt_path == 0 && build_grid != 0 && (build_grid > 0 || n_local >= 16384)));
@@ -1030,12 +1030,12 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
         const double exact_rate = (fast_k || m < 48) ? 58e12 : k <= 64 ? 45e12 : k <= 128 ? 22e12 : 5e12;
         const double t_exact = (3.0 * k + 3.0) * pairs / exact_rate;
-        const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
-        const double t_filter = k > 128 ? 1e30
+        const int kt = knn_kt_of(k);   // 0: no fp16 layouts for this k (k > 512)
+        const double t_filter = kt == 0 ? 1e30
                                         : 1.0e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * kt * pairs + 1e-4;
         const double t_filter_under_copy = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // host rows: layouts built under the copy
         int want_filter = g_opt_path == 2 ||
-                          (g_opt_path == 0 && m >= 5 && k <= 128 && (g_opt_ingest == 1 ? t_filter : t_filter_under_copy) < t_exact);
+                          (g_opt_path == 0 && m >= 5 && kt != 0 && (g_opt_ingest == 1 ? t_filter : t_filter_under_copy) < t_exact);
         static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         // Third option: the exact scan chunk by chunk under the copy (pageable H2D measured at 50-55 GB/s,

@@ -100,6 +100,14 @@ struct FilterWorkspace {
     bool last_used_cells = false;
 };
 
+// 16-wide K steps of the fp16 layouts for dimension k: 1, 2, 4, 8 (register / LDS-tiled scans), 16 and 32 (LDS-tiled scan with
+// two / one block of queries per wave: the B operands of k = 512 fill a wave's registers); 0 = no filter for this k.
+#define KNN_FILTER_MAX_K 512
+static inline int knn_kt_of(int k)
+{
+    return k < 1 ? 0 : k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : k <= 128 ? 8 : k <= 256 ? 16 : k <= KNN_FILTER_MAX_K ? 32 : 0;
+}
+
 // Cell-sorted layout of the references (k <= 16): see the head of knn_cells.hip.
 struct CellIndex {
     int bits = 0, sa = 0;            // cells = 2^bits; low pruning table = 2^sa entries

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void knn_ref_stats_kernel(const float *__restr
             hi = fmaxf(hi, v);
         }
     }
-    // fold the block in LDS first (k <= 128): one guarded global atomic per dimension per block —
+    // fold the block in LDS first: one guarded global atomic per dimension per block —
     // per-thread atomics on the same 2k words ran at the single-word rate (1.4 ms for a 20 MB shard)
-    __shared__ unsigned s_lo[128], s_hi[128], s_bad;
+    __shared__ unsigned s_lo[KNN_FILTER_MAX_K], s_hi[KNN_FILTER_MAX_K], s_bad;
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         s_lo[i] = 0xFFFFFFFFu;
         s_hi[i] = 0u;
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restri
             }
         }
     }
-    // fold the block in LDS first (k <= 128): one guarded global atomic per dimension per block
+    // fold the block in LDS first: one guarded global atomic per dimension per block
     // instead of eight per thread on the same two cache lines
-    __shared__ unsigned s_lo[128], s_hi[128], s_bad;
+    __shared__ unsigned s_lo[KNN_FILTER_MAX_K], s_hi[KNN_FILTER_MAX_K], s_bad;
     for (int d = threadIdx.x; d < k; d += blockDim.x) {
         s_lo[d] = 0xFFFFFFFFu;
         s_hi[d] = 0u;
@@ -1082,9 +1082,9 @@ static double robust_box(const std::vector<float> &samp, long long samples, int 
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s, int want_cells)
 {
     st = FilterState();
-    if (n <= 0 || k < 1 || k > 128)
+    const int kt = knn_kt_of(k);
+    if (n <= 0 || kt == 0)
         return hipSuccess;
-    const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
     const int kp = 16 * kt;
     long long ntiles = (n + 31) / 32;
     const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
@@ -1288,8 +1288,8 @@ hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float
         t_last = now;
     };
     const size_t row_bytes = (size_t)k * sizeof(float);
-    const bool layouts = n > 0 && k >= 1 && k <= 128;
-    const int kt = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+    const bool layouts = n > 0 && knn_kt_of(k) != 0;
+    const int kt = layouts ? knn_kt_of(k) : 1;
     const int kp = 16 * kt;
     const long long ntiles = (n + 31) / 32;
 
@@ -1729,7 +1729,7 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         return hipErrorInvalidValue;
     // `deepk` = 1 (A/B arm): the same kernel with 8 waves per block — each staged reference tile feeds 32 query
     // tiles, half the L2 -> LDS traffic.  Measured equal to the 4-wave form (profiles/r02_c5_variants.txt).
-    const bool wide_scan = st.deepk_variant == 1;
+    const bool wide_scan = st.deepk_variant == 1 && KT <= 8;
     unsigned wgy = (unsigned)((qtiles + 8 * QT - 1) / (8 * QT)), wgx = 1;
     if (wide_scan) {
         wgx = ((unsigned)num_cu * 4 + wgy - 1) / wgy;    // ~4 rounds of one block per CU
@@ -1785,8 +1785,14 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         FTRY(hipEventRecord(w.ev_begin, s));
     // `deepk`: 0 = auto (k > 64: four reference tiles per barrier staged by LDS-DMA, -2.4 % at C5; else one), 1 = 8 waves per
     // block, 2 / 4 = that many tiles per barrier, 3 = one tile per barrier (the round-2 kernel)
-    const int tpb = st.deepk_variant == 2 ? 2 : (st.deepk_variant == 4 || (st.deepk_variant == 0 && KT == 8)) ? 4 : 1;
-    if (tpb > 1 && !wide_scan) {
+    // (k > 128: one tile per barrier, 4 waves — a tile is 16 or 32 KiB there, four of them twice over do not fit the LDS)
+    const int tpb = KT > 8 ? 1 : st.deepk_variant == 2 ? 2 : (st.deepk_variant == 4 || (st.deepk_variant == 0 && KT == 8)) ? 4 : 1;
+    if constexpr (KT > 8) {
+        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                           (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                           1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                           (unsigned short *)(w.records + w.rec_cap));
+    } else if (tpb > 1 && !wide_scan) {
         if (tpb == 2)
             hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 2>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                                (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
@@ -1797,12 +1803,12 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
                                (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                                1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
                                (unsigned short *)(w.records + w.rec_cap));
-    } else if (wide_scan)
+    } else if (wide_scan) {
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, 512>), dim3(wgx, wgy), dim3(512), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
                            (unsigned short *)(w.records + w.rec_cap));
-    else
+    } else
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
@@ -1867,12 +1873,17 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
         else
             FTRY(launch_filter<4>(st, w, m, num_cu, s));
         break;
-    default:
+    case 8:
         if (qtiles >= 16)
             FTRY((launch_filter_tiled<8, 4>(st, w, m, num_cu, s)));
         else
             FTRY(launch_filter<8>(st, w, m, num_cu, s));
         break;
+    // 128 < k <= 512: always the LDS-tiled scan (a reference tile is 16 / 32 KiB: no wave can hold one in registers beside its
+    // queries); the B operands of 2 / 1 blocks of 32 queries are the wave's 128 operand registers
+    case 16: FTRY((launch_filter_tiled<16, 2>(st, w, m, num_cu, s))); break;
+    case 32: FTRY((launch_filter_tiled<32, 1>(st, w, m, num_cu, s))); break;
+    default: return hipErrorInvalidValue;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
     FTRY(knn_rerank_launch(st.k, positions, q, r, base, w.records,
@@ -1898,7 +1909,9 @@ hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float 
     case 1: hipLaunchKernelGGL(knn_filter_scores_kernel<1>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     case 2: hipLaunchKernelGGL(knn_filter_scores_kernel<2>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
-    default: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 8: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 16: hipLaunchKernelGGL(knn_filter_scores_kernel<16>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    default: hipLaunchKernelGGL(knn_filter_scores_kernel<32>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     }
     FTRY(hipGetLastError());
     FTRY(hipMemcpyAsync(qnorm_out, w.qry_norms, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -53,7 +53,10 @@ def test_ragged_shapes_bit_exact(oracle, path, k, m, n):
                                    (16, 1, 1 << 20), (16, 1, 5000), (16, 2, 70001), (16, 5, 70001), (16, 8, 70001),
                                    (8, 300, 100000), (16, 1057, 70001), (16, 1100, 70001), (16, 1600, 70001),
                                    (16, 577, 70001), (20, 600, 70001), (20, 1057, 70001), (3, 2100, 70001),
-                                   (128, 600, 4100), (40, 513, 9000), (64, 2048, 70000), (33, 1000, 131072)])
+                                   (128, 600, 4100), (40, 513, 9000), (64, 2048, 70000), (33, 1000, 131072),
+                                   # 128 < k <= 512: the LDS-tiled filter with 2 / 1 blocks of queries per wave; beyond: exact only
+                                   (129, 600, 4100), (200, 70, 9000), (256, 513, 5000), (257, 300, 9000), (384, 1100, 4100),
+                                   (512, 200, 5000), (513, 100, 3000), (1000, 48, 2000)])
 def test_synthetic_uniform_bit_exact(oracle, path, k, m, n):
     Q, R = oracle.synth(m * k, 1000), oracle.synth(n * k, 1001)
     got = pkg.cudaCallback(k, m, n, Q, R)
@@ -181,7 +184,7 @@ def _filter_case(rng, name, m, n, k):
     raise ValueError(name)
 
 
-@pytest.mark.parametrize("k", [3, 16, 24, 100])
+@pytest.mark.parametrize("k", [3, 16, 24, 100, 200, 500])
 @pytest.mark.parametrize("dist", ["uniform", "offset", "clustered", "mixed_scales", "queries_outside"])
 def test_filter_scores_stay_inside_the_proven_error_bound(k, dist):
     """The MFMA filter is only sound if |S + M - sigma^2 d^2| <= 2 eta sigma d + eta^2 + rho for
@@ -239,6 +242,30 @@ def test_filter_path_is_taken_and_reports_candidates(oracle):
     assert 0 < records < 400 * m          # ~n/sample survivors per query, far below m*n/32
     np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R))
     ix.close()
+
+
+@pytest.mark.parametrize("k,m,n", [(256, 2048, 32768), (512, 1024, 16384), (160, 100, 20000)])
+def test_deep_dimensions_take_the_filter_and_stay_bit_exact(oracle, k, m, n):
+    """128 < k <= 512 (the reference loops over any k, core.cu:831-835): library policy puts these on the MFMA filter
+    (round 2 left them on the row-per-lane exact kernels); gaussian data, planted exact duplicates."""
+    rng = np.random.default_rng(k + m)
+    R = rng.normal(0, 1, (n, k)).astype(np.float32)
+    Q = rng.normal(0, 1, (m, k)).astype(np.float32)
+    Q[::7] = R[rng.integers(0, n, len(Q[::7]))]
+    R[n - 1] = R[3]
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.empty(m, dtype=torch.int32, device=dev)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)   # auto path
+    pkg.keys_init(keys.data_ptr(), m)
+    ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+    pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+    torch.cuda.synchronize()
+    path_taken, records, fallback, _ = ix.last_stats()
+    ix.close()
+    assert path_taken == 2 and fallback == 0 and records > 0
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R, threads=THREADS))
 
 
 def test_filter_falls_back_on_the_device_when_queries_rule_it_out(oracle):
@@ -423,7 +450,7 @@ def test_one_far_away_query_does_not_loosen_the_whole_batch(oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("k", [16, 40, 128])
+@pytest.mark.parametrize("k", [16, 40, 128, 256, 512])
 def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
     """The one unproven constant of the filter bound is omega = kt * 2^-18: the matrix core's internal
     fp32 accumulation error relative to the sum of term magnitudes.  Measured here by rebuilding the
@@ -459,7 +486,7 @@ def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
     mag = np.abs(N.astype(np.float64))[None, :] + np.abs(terms).sum(-1)
     S = scores.cpu().numpy().astype(np.float64)
     rel = float((np.abs(S - exact) / mag).max())
-    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8
+    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8 if k <= 128 else 16 if k <= 256 else 32
     assert rel <= kt * 2.0 ** -18, rel
     assert rel <= 2.0 ** -20, rel   # in practice about one fp32 rounding per 16-wide K-step
 
