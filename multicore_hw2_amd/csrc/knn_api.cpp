@@ -731,7 +731,7 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
         if (idx->stats[0] == 4)   // + the shared overflow area (variant 3: the sweep re-ranks its hits itself and counts them here)
             records += w.nlists == 0 ? ctl[KNN_CTL_RECORDS] : (ctl[KNN_CTL_RECORDS] < w.ovf_cap ? ctl[KNN_CTL_RECORDS] : w.ovf_cap);
         idx->stats[1] = records;
-        idx->stats[2] = ctl[KNN_CTL_FALLBACK];
+        idx->stats[2] = ctl[KNN_CTL_FALLBACK] ? 1 : ctl[KNN_CTL_EXACT_CELLS] ? 2 : 0;   // 2: the batch's listed (cell, query) pairs were evaluated exactly
         idx->stats[3] = idx->filter.n_outliers;
     }
     memcpy(stats, idx->stats, sizeof idx->stats);

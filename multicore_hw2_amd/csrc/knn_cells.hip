@@ -592,6 +592,7 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 &a, unsigned nw, const f4
 // ------------------------------------------------------------------------------------------
 #define CELL_PREP_WAVES 4
 #define CELL_PREP_TILES 9     // seed tiles a wave requests at once (a cell of 144 .. 288 rows: one round trip)
+#define CELL_SEED_MAX_TILES 36u   // tiles of one seed cell a query looks at (a larger cell: every stride-th tile)
 
 template <int PW>   // waves per query: 4 (one seed cell each) or 2 (two each: half the registers held, see knn_cells_query)
 __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         ctl_next[KNN_CTL_RECORDS] = 0u;
         ctl_next[KNN_CTL_WIDE_SEEDS] = 0u;
         ctl_next[KNN_CTL_DENSE_CELLS] = 0u;
+        ctl_next[KNN_CTL_EXACT_CELLS] = 0u;
     }
     const int half = lane >> 5;
     const size_t frag_at = (size_t)(qi >> 5) * 64 + (size_t)half * 32 + (size_t)(qi & 31);
@@ -788,8 +790,14 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         }
     };
 #pragma unroll
-    for (int c = 0; c < CELL_SEEDS / PW; ++c)   // this wave's seed cells
-        score_run((unsigned)__builtin_amdgcn_readlane((int)v_tb, wib + PW * c), (unsigned)__builtin_amdgcn_readlane((int)v_nt, wib + PW * c), 1u);
+    for (int c = 0; c < CELL_SEEDS / PW; ++c) {   // this wave's seed cells
+        // (a seed cell of many tiles — clustered data — is sampled: any real row's score bounds the answer, and one query
+        // per MFMA against thousands of tiles would cost more than the scan it prepares)
+        const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, wib + PW * c);
+        const unsigned nt = (unsigned)__builtin_amdgcn_readlane((int)v_nt, wib + PW * c);
+        const unsigned stride = (nt + CELL_SEED_MAX_TILES - 1u) / CELL_SEED_MAX_TILES;   // 1 up to the cap
+        score_run(tb, nt == 0u ? 0u : (nt + stride - 1u) / stride, stride);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)   // (every column is this query; the halves hold different rows)
         um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
@@ -1247,7 +1255,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 2 : W <= 12 ? 3 : 4)) void knn_ce
 template <bool NORM_MFMA>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ rn2,
-    const unsigned *__restrict__ tile_start, unsigned ncells,
+    const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
     u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice,
@@ -1274,20 +1282,23 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
     const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
     unsigned cnt = 0u;
+    bool dead = false;                  // the shared area is over-full: stop scanning (wave-uniform)
     const int col = lane & 31, half = lane >> 5;
-    // wave w takes cells w, w + W, ...: all waves read one moving window of the layout (contiguous ranges per wave: +6 %)
-    const unsigned per_wave = (ncells + nwaves - 1u) / nwaves;
-    for (unsigned g0 = 0u; g0 < per_wave; g0 += 64u) {
-        // counts and tile ranges of up to 64 cells, one per lane
+    // wave w takes items w, w + W, ... (an item = a run of tiles of one cell; uniform data: one item per cell): all waves read
+    // one moving window of the layout (contiguous ranges per wave: +6 %)
+    const unsigned per_wave = (nitems + nwaves - 1u) / nwaves;
+    for (unsigned g0 = 0u; g0 < per_wave && !dead; g0 += 64u) {
+        // cells, list lengths and tile ranges of up to 64 items, one per lane
         // (measured and not kept, round 3: handing the cells out through an odd multiplier — cells w, w + W, ... share their low
         // bits and with them the queries that list them, the busiest wave has twice the average number of tile steps — left the
         // 2^21-row shard where it was and cost C3 4 %: the moving window over the layout is worth more than the balance)
         const unsigned mine = (g0 + (unsigned)lane) * nwaves + wave;
-        const bool in = g0 + (unsigned)lane < per_wave && mine < ncells;
-        unsigned v_nq = in ? cell_counts[mine] : 0u;
-        const unsigned v_tb = in ? tile_start[mine] : 0u;
-        const unsigned v_te = in ? tile_start[mine + 1u] : 0u;
-        for (u64 todo = __ballot(v_nq != 0u && v_te > v_tb); todo != 0ull; todo &= todo - 1ull) {
+        const bool in = g0 + (unsigned)lane < per_wave && mine < nitems;
+        const u64 item = in ? items[mine] : 0ull;
+        const unsigned v_meta = (unsigned)(item >> 40);   // cell << 8 | tiles
+        const unsigned v_tb = (unsigned)item;
+        unsigned v_nq = in ? cell_counts[v_meta >> 8] : 0u;
+        for (u64 todo = __ballot(v_nq != 0u); todo != 0ull && !dead; todo &= todo - 1ull) {
             const int j = (int)__builtin_ctzll(todo);
             unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
             // a list longer than its room (a thousand copies of one query all want the same cells) is cut short by the
@@ -1300,15 +1311,16 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
                     atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
             }
             const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
-            const unsigned te = (unsigned)__builtin_amdgcn_readlane((int)v_te, j);
-            const unsigned cellj = (g0 + (unsigned)j) * nwaves + wave;
+            const unsigned meta = (unsigned)__builtin_amdgcn_readlane((int)v_meta, j);
+            const unsigned te = tb + (meta & 0xFFu);
+            const unsigned cellj = meta >> 8;
             const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
             // the first two blocks of the list travel with the tiles (one round trip per cell)
             const unsigned l0 = dense ? (unsigned)lane : (unsigned)list[min((unsigned)lane, nq - 1u)];
             // (round 3: blocks three and four of the list too — lists average 120 entries on the 2^21-row shards of an
             // 8-GPU run, and every block beyond the second was a dependent read from memory)
             const unsigned l1 = dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
-            for (unsigned t0 = tb; t0 < te; t0 += CELL_TILES_PER_PASS) {
+            for (unsigned t0 = tb; t0 < te && !dead; t0 += CELL_TILES_PER_PASS) {
                 const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
                 h8 ar[CELL_TILES_PER_PASS];
                 unsigned nw[CELL_TILES_PER_PASS];
@@ -1331,7 +1343,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
                         my_nrm[64 + lane] = n1;
                     wave_lds_sync();
                 }
-                for (unsigned q0 = 0u; q0 < nq; q0 += 32u) {
+                for (unsigned q0 = 0u; q0 < nq && !dead; q0 += 32u) {
                     const unsigned idx = q0 + (unsigned)col;
                     const bool valid = idx < nq;
                     unsigned qid;
@@ -1353,21 +1365,37 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
                         if (p < nt) {
                             const u64 mask = cell_tile_step<NORM_MFMA>(ar[p], nw[p], my_nrm, p, half, b, th);
                             if (__builtin_expect(mask != 0ull, 0)) {
-                                if ((mask >> lane) & 1ull) {
-                                    const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                    const u64 r = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
-                                    if (pos < slice)
-                                        my_rec[pos] = r;
-                                    else if (ovf_cap != 0u) {
-                                        // this wave's slice is full (many queries of the batch want the same tile — copies
-                                        // of one query): the record goes to the area all waves share, one atomic each (rare)
-                                        const unsigned op = atomicAdd(&ctl[KNN_CTL_RECORDS], 1u);
+                                const bool hit = (mask >> lane) & 1ull;
+                                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                const u64 r = ((u64)qid << 32) | ((u64)(t0 + (unsigned)p) << 1) | (u64)half;
+                                if (hit && pos < slice)
+                                    my_rec[pos] = r;
+                                const unsigned total = cnt + (unsigned)__popcll(mask);
+                                if (total > slice && ovf_cap != 0u) {   // wave-uniform
+                                    // this wave's slice is full (many queries of the batch want the same tile — copies of one
+                                    // query): what does not fit goes to the area all waves share, ONE atomic per step for the
+                                    // lanes that need room there, none once the area is over-full
+                                    const unsigned first_over = max(cnt, slice);
+                                    unsigned obase = ovf_cap;
+                                    if (lane == 0 && !dead)
+                                        obase = atomicAdd(&ctl[KNN_CTL_RECORDS], total - first_over);
+                                    obase = (unsigned)__builtin_amdgcn_readfirstlane((int)obase);
+                                    if (hit && pos >= slice) {
+                                        const unsigned op = obase + (pos - first_over);
                                         if (op < ovf_cap)
                                             rec[(size_t)ovf_base + op] = r;   // (beyond: the re-rank sees the count and falls back)
                                     }
+                                    // Slice full AND the shared area over-full (what the atomic returned says so; a plain read
+                                    // of a word other XCDs are adding to can stay stale in this XCD's L2): the fp16 scores do not
+                                    // separate this batch's rows (a cluster tighter than the fp16 step — every row of a query's
+                                    // cells is a candidate).  The re-rank will see the count and hand the batch's listed pairs to
+                                    // knn_cells_exact_kernel; nothing this wave still finds is needed.  The loops around the
+                                    // steps look at `dead`; a jump out of the unrolled steps cost every step of every batch six
+                                    // instructions of exec bookkeeping.
+                                    dead = obase + (total - first_over) > ovf_cap;
                                 }
-                                cnt += (unsigned)__popcll(mask);
+                                cnt = total;
                             }
                         }
                     }
@@ -1392,6 +1420,7 @@ void knn_cells_free(CellIndex *&c)
     (void)KNN_DEV_FREE(c->bounds);
     (void)KNN_DEV_FREE(c->tile_start);
     (void)KNN_DEV_FREE(c->perm);
+    (void)KNN_DEV_FREE(c->items);
     delete c;
     c = nullptr;
 }
@@ -1460,6 +1489,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
 
     unsigned *code = nullptr, *counts = nullptr;
     std::vector<unsigned> hcounts((size_t)c->ncells), hstart((size_t)c->ncells + 1);
+    std::vector<u64> hitems;
     hipError_t e = KNN_DEV_ALLOC((void **)&c->bounds, bounds.size() * sizeof(float));
     if (e == hipSuccess)
         e = KNN_DEV_ALLOC((void **)&c->tile_start, hstart.size() * sizeof(unsigned));
@@ -1491,9 +1521,14 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         }
         hstart[c->ncells] = (unsigned)tiles;
         c->max_cell_rows = biggest;
-        // badly unbalanced cells (clustered data the sample quantiles do not describe) leave a few waves with all the
-        // work and a few lists with all the queries: full scans serve such a shard better
-        keep = (long long)biggest * c->ncells <= 16 * n;
+        // (round 2 gave up here when the largest cell held more than 16x the average — clustered or low-rank data the
+        // per-dimension quantiles do not spread.  The scan now takes ITEMS, runs of at most KNN_CELL_ITEM_TILES tiles of one
+        // cell, so a fat cell is many waves' work instead of one's, and cells without rows cost nothing)
+        for (unsigned i = 0; i < c->ncells; ++i)
+            for (unsigned t = hstart[i]; t < hstart[i + 1]; t += KNN_CELL_ITEM_TILES)
+                hitems.push_back(((u64)i << 48) | ((u64)std::min((unsigned)KNN_CELL_ITEM_TILES, hstart[i + 1] - t) << 40) | (u64)t);
+        c->nitems = (unsigned)hitems.size();
+        keep = c->nitems != 0u;
     }
     if (keep) {
         // the rows are placed (and turned into fragments) by knn_cells_scatter_frag_kernel once the layout buffers
@@ -1502,11 +1537,15 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         if (e == hipSuccess)
             e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
         if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&c->items, hitems.size() * sizeof(u64));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->items, hitems.data(), hitems.size() * sizeof(u64), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
             e = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles * 32 * sizeof(unsigned));
         if (e == hipSuccess)
             e = hipMemsetAsync(c->perm, 0xFF, (size_t)tiles * 32 * sizeof(unsigned), s);
         if (e == hipSuccess)
-            e = hipStreamSynchronize(s);   // hstart is about to go out of scope
+            e = hipStreamSynchronize(s);   // hstart / hitems are about to go out of scope
     }
     if (e == hipErrorOutOfMemory) {   // no room for the sort: the plain layout still works
         (void)hipGetLastError();
@@ -1718,11 +1757,14 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // cells 5-7 % less (0.0465 -> 0.0444 ms at 2^21 rows; at C3 the two are within 1 %: it keeps two).
     const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 16384u);
     unsigned gx = (unsigned)num_cu * (one_block ? 1u : 2u);
-    if (gx * CELL_SCAN_WAVES > c.ncells)
-        gx = std::max(1u, c.ncells / CELL_SCAN_WAVES);
+    if (gx * CELL_SCAN_WAVES > c.nitems)
+        gx = std::max(1u, c.nitems / CELL_SCAN_WAVES);
     w.nlists = gx * CELL_SCAN_WAVES;
-    // the last quarter of the record buffer is shared by all waves: what a wave's own slice cannot hold goes there
-    w.ovf_cap = w.rec_cap / 4u;
+    // the tail of the record buffer is shared by all waves: what a wave's own slice cannot hold goes there.  2^16 records:
+    // room for a batch whose queries crowd into a few cells (1024 copies of one query leave ~2000 records there), and small
+    // enough that a batch the fp16 scores cannot separate at all (a cluster tighter than the fp16 step: millions of
+    // candidates, one atomic on ONE word per overflowing step) over-fills it — and stops scanning — within microseconds
+    w.ovf_cap = std::min(w.rec_cap / 4u, 1u << 16);
     w.ovf_base = w.rec_cap - w.ovf_cap;
     w.slice = (w.rec_cap - w.ovf_cap) / w.nlists;
 
@@ -1801,11 +1843,11 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
     if (variant == 2)
         hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
                            w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
     else
         hipLaunchKernelGGL(knn_cells_scan_kernel<false>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.tile_start, c.ncells, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
                            w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
     FTRY(hipGetLastError());
     if (timed && w.ev_end)

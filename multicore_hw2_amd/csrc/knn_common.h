@@ -38,6 +38,11 @@ struct RerankPieces {
 // perm (nullable): records name positions of a permuted layout; perm[position] = row (~0u = padding), and n
 // is then the number of positions.
 // ovf_cap != 0: records[ovf_base ..) hold ctl[KNN_CTL_RECORDS] more records (capped at ovf_cap) that belong to no list.
+// Cell-pruned path, gated on ctl[KNN_CTL_EXACT_CELLS]: exact v0 arithmetic over the batch's listed (item, query) pairs.
+hipError_t knn_cells_exact_launch(int k, int m, long long base, const float *q_dev, const float *r_dev,
+                                  const unsigned long long *items, unsigned nitems, const unsigned *cell_counts,
+                                  const unsigned short *lists, unsigned cap, const unsigned *perm, const unsigned *ctl,
+                                  unsigned long long *keys, int num_cu, hipStream_t s);
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
                              const u64 *records, const unsigned short *record_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
@@ -61,7 +66,9 @@ enum {
     KNN_CTL_CELLS = 5,     // != 0: this batch went through the cell-pruned scan
     KNN_CTL_WIDE_SEEDS = 6,  // cell-pruned path: queries whose seed cells held no row (bounded by a strided sample instead)
     KNN_CTL_DENSE_CELLS = 7, // cell-pruned path: cells whose query list outgrew its LDS room (scored against the whole batch)
-    KNN_CTL_WORDS = 8
+    KNN_CTL_EXACT_CELLS = 8, // cell-pruned path, != 0: more candidates than the record buffers hold (the fp16 scores cannot tell
+                             // the rows of a tight cluster apart): the listed (cell, query) pairs are evaluated exactly instead
+    KNN_CTL_WORDS = 12
 };
 
 #define KNN_SLOTS 8  // independent query workspaces per index: up to eight batches may be in flight
@@ -103,6 +110,7 @@ struct FilterWorkspace {
 // 16-wide K steps of the fp16 layouts for dimension k: 1, 2, 4, 8 (register / LDS-tiled scans), 16 and 32 (LDS-tiled scan with
 // two / one block of queries per wave: the B operands of k = 512 fill a wave's registers); 0 = no filter for this k.
 #define KNN_FILTER_MAX_K 512
+#define KNN_CELL_ITEM_TILES 18     // two passes of the scan (CELL_TILES_PER_PASS = 9)
 static inline int knn_kt_of(int k)
 {
     return k < 1 ? 0 : k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : k <= 128 ? 8 : k <= 256 ? 16 : k <= KNN_FILTER_MAX_K ? 32 : 0;
@@ -117,6 +125,11 @@ struct CellIndex {
     unsigned *tile_start = nullptr;  // device [ncells + 1]: first 32-row tile of each cell in the layout
     unsigned *perm = nullptr;        // device [ntiles * 32]: row held by each layout position (~0u = padding)
     unsigned max_cell_rows = 0;
+    // what the scan's waves take one at a time: (cell << 48) | (tiles << 40) | first tile — a run of at most
+    // KNN_CELL_ITEM_TILES tiles of ONE cell.  Cells without rows have no item; a cell of many rows (clustered data the
+    // quantile cuts do not spread) has several, all scored against the same list
+    unsigned long long *items = nullptr;
+    unsigned nitems = 0;
 };
 
 struct FilterState {

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void knn_frag_kernel(const float *__restrict__
             if (blockIdx.x == 0) {
                 ctl[KNN_CTL_FALLBACK] = 0u;
                 ctl[KNN_CTL_RECORDS] = 0u;
+                ctl[KNN_CTL_EXACT_CELLS] = 0u;
             }
         }
         return;
@@ -1853,6 +1854,11 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
             FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl_cur,
                                    kb, w.pieces, s, perm, w.ovf_base, w.ovf_cap));
             FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
+            // gated on the device, both: the listed pairs exactly when the records overflowed, the whole shard when the
+            // batch has a query nothing bounds
+            if (st.cells_variant != 3)
+                FTRY(knn_cells_exact_launch(st.k, mb, base, qb, r, st.cells->items, st.cells->nitems, w.cell_counts, w.cell_lists,
+                                            st.cells->cap, perm, w.ctl_cur, kb, num_cu, s));
             FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
         }
         return hipSuccess;
