@@ -181,6 +181,11 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^14 cells once a query has
  *             used a workspace slot other than 0 — batches in flight side by side: the scan alone gets 10-20 % longer and
  *             the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
+ *   "scan_deal" how the pruned scan's waves get their work items (runs of tiles of one cell): 1 = fixed (wave w takes items
+ *             w, w + W, ...), 2 = a block owns a contiguous run and its waves take items from a counter in LDS (the launch
+ *             is 6-8 % shorter: no wave is left with twice the average), 0 = auto: 2 for callers that query one batch at a
+ *             time, 1 once a workspace slot other than 0 has been used (batches in flight fill each other's gaps; the
+ *             fixed deal's cheaper prologue then gives the shorter step)
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

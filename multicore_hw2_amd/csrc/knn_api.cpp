@@ -72,6 +72,7 @@ std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_deepk{0};
 std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pruned path (knn_cells_query)
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
+std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
@@ -343,6 +344,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_scan_blocks = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "scan_deal")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: scan_deal must be 0 (auto), 1 (fixed deal) or 2 (block counter)");
+        g_opt_scan_deal = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "cells_variant")) {
         if (value < 0 || value > 3)
             return fail(KNN_EINVAL, "knn_set_option: cells_variant must be 0 .. 3");
@@ -400,6 +407,8 @@ long long knn_get_option(const char *name)
         return g_opt_cells_variant;
     if (name && !strcmp(name, "scan_blocks"))
         return g_opt_scan_blocks;
+    if (name && !strcmp(name, "scan_deal"))
+        return g_opt_scan_deal;
     if (name && !strcmp(name, "deepk"))
         return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -655,6 +664,7 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         if (slot != 0)
             idx->filter.several_slots = true;
         idx->filter.scan_blocks = (int)g_opt_scan_blocks;
+        idx->filter.scan_deal = (int)g_opt_scan_deal;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys));

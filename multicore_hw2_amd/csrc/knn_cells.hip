@@ -557,6 +557,7 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 //                      and block of queries (round 2: 0.113 ms at C3, the LDS pipe busy 0.081 ms of it)
 //   NORM_MFMA = true : the C tile comes out of one extra MFMA on the split norms (see the head of this file)
 #define CELL_SCAN_WAVES 12
+#define CELL_SCAN_CHUNK 256   // items of a block's run whose tile ranges and list lengths sit in LDS at a time (DYN)
 
 // One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
 template <bool NORM_MFMA>
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 2 : W <= 12 ? 3 : 4)) void knn_ce
 // (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512)
 // (HIP's second launch bound is waves per SIMD: 6 = at most 80 registers.  Left at 2 the allocator settled at 96-98 once the
 // dense-cell and overflow paths were in — 4 waves per SIMD, and the kernel alone went from 0.035 to 0.042 ms at 2^21 rows)
-template <bool NORM_MFMA>
+template <bool NORM_MFMA, bool DYN = false>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ rn2,
     const u64 *__restrict__ items, unsigned nitems,
@@ -1284,20 +1285,56 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
     unsigned cnt = 0u;
     bool dead = false;                  // the shared area is over-full: stop scanning (wave-uniform)
     const int col = lane & 31, half = lane >> 5;
-    // wave w takes items w, w + W, ... (an item = a run of tiles of one cell; uniform data: one item per cell): all waves read
-    // one moving window of the layout (contiguous ranges per wave: +6 %)
+    // DYN = false: wave w takes items w, w + W, ... (an item = a run of tiles of one cell; uniform data: one item per cell):
+    // all waves read one moving window of the layout (contiguous ranges per wave: +6 %).
+    // DYN = true (small shards: an item or three per wave): the block owns a contiguous run of items and its waves take them
+    // one by one from a counter in LDS — with the fixed deal the busiest wave of a 2^21-row shard had 115 tile steps against
+    // 48.5 on average (lists of 76..160 queries, cells of 5..9 tiles) and the launch lasted as long as that wave.
+    __shared__ unsigned s_next, s_imeta[DYN ? CELL_SCAN_CHUNK : 1], s_itb[DYN ? CELL_SCAN_CHUNK : 1], s_inq[DYN ? CELL_SCAN_CHUNK : 1];
     const unsigned per_wave = (nitems + nwaves - 1u) / nwaves;
-    for (unsigned g0 = 0u; g0 < per_wave && !dead; g0 += 64u) {
-        // cells, list lengths and tile ranges of up to 64 items, one per lane
-        // (measured and not kept, round 3: handing the cells out through an odd multiplier — cells w, w + W, ... share their low
-        // bits and with them the queries that list them, the busiest wave has twice the average number of tile steps — left the
-        // 2^21-row shard where it was and cost C3 4 %: the moving window over the layout is worth more than the balance)
-        const unsigned mine = (g0 + (unsigned)lane) * nwaves + wave;
-        const bool in = g0 + (unsigned)lane < per_wave && mine < nitems;
-        const u64 item = in ? items[mine] : 0ull;
-        const unsigned v_meta = (unsigned)(item >> 40);   // cell << 8 | tiles
-        const unsigned v_tb = (unsigned)item;
-        unsigned v_nq = in ? cell_counts[v_meta >> 8] : 0u;
+    const unsigned per_block = (nitems + gridDim.x - 1u) / gridDim.x;
+    const unsigned i0 = min(blockIdx.x * per_block, nitems), i1 = min(i0 + per_block, nitems);
+    unsigned c0 = i0, nc = 0u, mine_dyn = 0u;   // DYN: the chunk of the block's run whose tables are in LDS, this wave's item in it
+    for (unsigned g0 = 0u;; g0 += 64u) {
+        unsigned v_meta = 0u, v_tb = 0u, v_nq = 0u;
+        if constexpr (DYN) {
+            if (g0 == 0u || mine_dyn >= nc) {   // block-uniform in effect: every wave runs dry before the barrier lets anyone on
+                if (g0 != 0u)
+                    c0 += CELL_SCAN_CHUNK;
+                if (c0 >= i1)
+                    break;
+                nc = min((unsigned)CELL_SCAN_CHUNK, i1 - c0);
+                __syncthreads();   // everybody is done with the previous chunk's tables
+                for (unsigned i = threadIdx.x; i < nc; i += 64 * CELL_SCAN_WAVES) {
+                    const u64 item = items[c0 + i];
+                    s_imeta[i] = (unsigned)(item >> 40);
+                    s_itb[i] = (unsigned)item;
+                    s_inq[i] = cell_counts[(unsigned)(item >> 48)];
+                }
+                if (threadIdx.x == 0)
+                    s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
+                __syncthreads();
+                mine_dyn = (unsigned)wib;
+            }
+            if (mine_dyn < nc && lane == 0 && !dead) {
+                v_meta = s_imeta[mine_dyn];
+                v_tb = s_itb[mine_dyn];
+                v_nq = s_inq[mine_dyn];
+            }
+        } else {
+            if (g0 >= per_wave || dead)
+                break;
+            // cells, list lengths and tile ranges of up to 64 items, one per lane
+            // (measured and not kept, round 3: handing the cells out through an odd multiplier — cells w, w + W, ... share their
+            // low bits and with them the queries that list them, the busiest wave has twice the average number of tile steps —
+            // left the 2^21-row shard where it was and cost C3 4 %: the moving window over the layout is worth more than the balance)
+            const unsigned mine = (g0 + (unsigned)lane) * nwaves + wave;
+            const bool in = g0 + (unsigned)lane < per_wave && mine < nitems;
+            const u64 item = in ? items[mine] : 0ull;
+            v_meta = (unsigned)(item >> 40);   // cell << 8 | tiles
+            v_tb = (unsigned)item;
+            v_nq = in ? cell_counts[v_meta >> 8] : 0u;
+        }
         for (u64 todo = __ballot(v_nq != 0u); todo != 0ull && !dead; todo &= todo - 1ull) {
             const int j = (int)__builtin_ctzll(todo);
             unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
@@ -1401,6 +1438,12 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
                     }
                 }
             }
+        }
+        if constexpr (DYN) {   // the next item of the chunk (an index past its end: the chunk is done for this wave)
+            unsigned nx = 0u;
+            if (lane == 0)
+                nx = dead ? nc : atomicAdd(&s_next, 1u);
+            mine_dyn = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
         }
     }
     if (lane == 0) {
@@ -1841,8 +1884,19 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
     const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    // Items handed out inside the block (LDS counter, see the kernel) when batches come one at a time: the launch is as long as
+    // its busiest wave, and evening the waves out takes 6-8 % off it (alone, ms: 0.0433 -> 0.0408 at 2^21 rows, 0.060 -> 0.055 at
+    // 2^22, 0.1176 -> 0.1094 at C3; one batch at a time 0.0855 -> 0.0828, 0.102 -> 0.097, 0.1677 -> 0.160).  With batches in
+    // flight on several slots the next batch's kernels fill the gaps early finishers leave, and the fixed deal's cheaper prologue
+    // and moving window win: the step is 1-4 % SHORTER with it (0.0415 / 0.0549 / 0.0794 / 0.1233 against 0.0425 / 0.0568 /
+    // 0.0831 / 0.1249) — so that is what pipelined callers get.
+    const bool dyn = st.scan_deal == 2 || (st.scan_deal == 0 && !st.several_slots);
     if (variant == 2)
         hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
+                           st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
+    else if (dyn)
+        hipLaunchKernelGGL((knn_cells_scan_kernel<false, true>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
                            st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
                            w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
     else

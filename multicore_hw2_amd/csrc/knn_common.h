@@ -155,6 +155,7 @@ struct FilterState {
     CellIndex *cells = nullptr;   // non-null: the layout is cell-sorted (ntiles counts its padded tiles)
     int cells_policy = 0;         // per call: 0 use the cells when present, 2 full scan
     bool several_slots = false;   // a query has used a workspace slot other than 0: batches are in flight side by side
+    int scan_deal = 0;            // pruned scan: 0 auto (block counter unless several_slots), 1 fixed deal, 2 items from a block counter
     int scan_blocks = 0;          // pruned scan, blocks per CU: 0 auto (one for small shards when several_slots, else two), 1, 2
     int cells_variant = 0;        // A/B hook: 0 = prep + fused match/scan (default), 1 = round-2 kernels (fragments, seed,
                                   // match, scan with LDS norms), 2 = prep + match + scan with MFMA norms

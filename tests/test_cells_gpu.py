@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells", "cells_variant"):
+    for name in ("path", "shards", "cells", "cells_variant", "scan_deal"):
         pkg.set_option(name, 0)
 
 
@@ -190,6 +190,30 @@ def test_ab_arms_of_the_pruned_path_are_bit_exact_too(oracle, variant, k, dist):
         pkg.set_option("cells_variant", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"variant {variant} {dist} k={k} stats={st}")
     assert st[0] == 4, st
+
+
+@pytest.mark.parametrize("deal", [1, 2], ids=["fixed_deal", "block_counter"])
+@pytest.mark.parametrize("k,dist,n", [(16, "uniform", (1 << 18) + 5), (16, "clustered", 1 << 17), (8, "lattice", (1 << 17) + 99),
+                                      (16, "tight_clusters", 1 << 20), (16, "low_rank", 1 << 19)])
+def test_both_ways_of_dealing_items_to_the_scan_waves_are_bit_exact(oracle, deal, k, dist, n):
+    """`scan_deal` 1 (wave w takes items w, w + W, ...: what callers with batches in flight get) and 2 (a block's waves take
+    items of its contiguous run from a counter in LDS: what one-batch-at-a-time callers get) must answer alike — including
+    the shard whose items outnumber a block's table (fat cells cut into many items) and the batch that overflows."""
+    m = 900
+    rng = np.random.default_rng(k + deal + len(dist))
+    Q, R = _off_the_cube(rng, dist, k, m, n) if dist in ("tight_clusters", "low_rank") else _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("scan_deal", deal)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("scan_deal", 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"deal {deal} {dist} k={k} stats={st}")
+    assert st[0] == 4 and st[2] in (0, 2), st
 
 
 def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle):
