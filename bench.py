@@ -58,6 +58,8 @@ def parse_args():
                          "3 = prep + sweep (one persistent kernel)")
     ap.add_argument("--separate-init", action="store_true",
                     help="A/B: start the keys with a knn_keys_init launch per step instead of KNN_QUERY_INIT_KEYS")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: any other library option (knn_set_option), e.g. --opt scan_deal=2 --opt scan_blocks=1")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
@@ -174,6 +176,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg.set_option("path", args.path)
+    for item in args.opt:
+        name, _, value = item.partition("=")
+        pkg.set_option(name, int(value))
     if args.filter_qt:
         pkg.set_option("filter_qt", args.filter_qt)
     if args.filter_rounds:

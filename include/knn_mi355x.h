@@ -152,7 +152,8 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
  *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
  *             (shards of at least 64 MiB)
- *   "deepk"   tuning / A-B: the LDS-tiled filter scan for 32 < k <= 128 with >= 512 queries: 0 = auto (4 waves x 4
+ *   "deepk"   tuning / A-B: the LDS-tiled filter scan for 32 < k <= 128 with >= 512 queries (128 < k <= 512 always run its
+ *             one-tile-per-barrier form with 2 / 1 blocks of queries per wave): 0 = auto (4 waves x 4
  *             query tiles share every staged reference tile; for k > 64 four reference tiles are staged per barrier by
  *             LDS-DMA), 1 = 8 waves per block, 2 / 4 = that many reference tiles per barrier, 3 = one tile per
  *             barrier through registers (the round-2 kernel)
@@ -171,9 +172,13 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^20 rows (k = 13 .. 16); never for the
  *             one-shot cudaCallback (one batch does not repay the sort).  1 = every index of >= 2^17 rows,
  *             cudaCallback's shards included; 2 = never.  Read when an index is created; 2 also makes
- *             existing indexes use the full scan.  A batch the pruned path cannot bound (non-finite or
- *             far-away queries, no reference row found to bound a query with) is answered by the exact scan;
- *             the next batch is back on the pruned path.  Results are bit-exact either way
+ *             existing indexes use the full scan.  Any distribution keeps its cells: a cell of many rows
+ *             (clustered, low-rank data) is cut into several work items, empty cells cost nothing.  A batch
+ *             the pruned path cannot bound (non-finite or far-away queries, no reference row found to bound a
+ *             query with) is answered by the exact scan of the shard; a batch whose candidates overflow the
+ *             record buffers (rows of a cluster tighter than the fp16 step) by the exact arithmetic over its
+ *             listed (cell, query) pairs only; the next batch is back on the pruned path.  Results are
+ *             bit-exact either way
  *   "cells_variant" A/B of the pruned path's kernels: 0 = prep (one block per query: fragments, seed scores,
  *             thresholds, pruning tables, keys) + match + scan; 1 = the round-2 chain (query fragments, seed, match,
  *             scan); 2 = as 0 with the scan's norm tile out of an extra MFMA instead of LDS; 3 = prep + sweep
@@ -198,8 +203,11 @@ long long knn_get_option(const char *name);
  * when the stream has completed; call after synchronising):
  *   [0] path taken (1 exact, 2 filter, 3 grid index, 4 filter in its cell-pruned form)
  *   [1] candidates re-ranked exactly
- *   [2] != 0: the device fell back to the exact scan   [3] reference rows outside the filter's
- *   robust box (scanned exactly on every query) */
+ *   [2] how the device answered a batch the filter could not: 0 = it could; 1 = exact scan of the whole shard (a query
+ *       nothing bounds: not finite, far outside the references' box); 2 = cell-pruned path only: more candidates than the
+ *       record buffers hold (rows of a cluster tighter than the fp16 step), the batch's listed (cell, query) pairs were
+ *       evaluated with the exact arithmetic — the cells the geometry ruled out stay ruled out
+ *   [3] reference rows outside the filter's robust box (scanned exactly on every query) */
 int knn_index_last_stats(knn_index *idx, long long stats[4]);
 
 /* Test / development hook: counters of the most recent batch on the cell-pruned path (call after synchronising; all 0

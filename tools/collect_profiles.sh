@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final/; tools/pmc_traffic.py and the
+# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_b/ — a fresh directory: gpurun MERGES into
+# gpurun_out/, and an earlier collection's files would mix with this one's; tools/pmc_traffic.py and the
 # copy into profiles/ happen afterwards in the build container).  usage: gpurun -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03_final
+O=$R/gpurun_out/r03_final_b
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
@@ -36,6 +37,18 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
+step "one batch at a time (single-slot callers: block-counter deal, two blocks per CU)"
+for n in 16777216 4194304 2097152; do
+  timeout -k 10 200 python3 $R/bench.py --workload 16,1024,$n --cpu-queries 0 --serial > $O/16_1024_${n}_serial_bench.json 2>> $O/c3_bench.err || exit 1
+done
+step "128 < k <= 512 on the MFMA filter"
+timeout -k 10 200 python3 $R/bench.py --workload 256,65536,65536 --cpu-queries 0 --steps 20 --warmup 3 > $O/256_65536_65536_bench.json 2>> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload 512,65536,65536 --cpu-queries 0 --steps 20 --warmup 3 > $O/512_65536_65536_bench.json 2>> $O/c3_bench.err || exit 1
+step "off the uniform cube"
+( cd $R && timeout -k 10 300 python3 tools/distribution_check.py 2>&1 | grep -v amdgpu.ids > $O/distribution_check.txt ) || exit 1
+for c in clusters64 heavy_tail; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$c -- python3 $R/tools/distribution_check.py $c > /dev/null 2>&1 || exit 1
+done
 step "index build stages"
 cd $R
 KNN_MI355X_TRACE_BUILD=1 timeout -k 10 120 python3 tools/build_trace.py > $O/build_trace.txt 2>&1 || exit 1
