@@ -104,8 +104,10 @@ int knn_index_query_keys(knn_index *idx, int m, const float *queries_dev,
 /* Same, using query workspace `slot` (0 .. 7) of the index.  The index owns eight independent
  * workspaces, so up to eight batches may be in flight at once on their own streams (e.g. batch
  * i+1's small preparation kernels beside batch i's scan); calls that share a slot must be
- * stream-ordered, and one index must not be driven from two host threads at once (its event and
- * statistics bookkeeping is not locked).  A slot outside 0 .. 7 is KNN_EINVAL.
+ * stream-ordered by the caller.  Calls on one index from several host threads are serialised by the
+ * index (a lock around the ~20 us of host work of a call; the GPU work of different slots still
+ * overlaps); knn_index_last_stats then describes whichever call was enqueued last.  A slot outside
+ * 0 .. 7 is KNN_EINVAL.
  * knn_index_query_keys == slot 0. */
 int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *queries_dev,
                               unsigned long long *keys_dev, void *stream);

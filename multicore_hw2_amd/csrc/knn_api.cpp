@@ -259,6 +259,10 @@ struct knn_index {
     size_t events_used = 0;
     int last_slot = 0;
     bool filter_wanted = false;  // the creator asked for the filter layouts explicitly (one-shot cost model)
+    // Calls on one index from several host threads are serialised (enqueueing a batch is ~20 us of host work; the GPU
+    // work of different slots still overlaps): the workspaces' lazily grown buffers, the event list, the statistics and
+    // the chain events are plain members.  Recursive: knn_index_query_host calls the keyed entry points.
+    std::recursive_mutex mu;
 };
 
 extern "C" {
@@ -605,6 +609,7 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         return fail(KNN_EINVAL, "knn_index_query_keys: bad arguments");
     if (m == 0)
         return KNN_OK;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
     if (!guard.ok)
         return fail(KNN_EHIP, "knn_index_query_keys: hipSetDevice failed");
@@ -686,6 +691,7 @@ int knn_debug_filter_scores(knn_index *idx, int m, const float *queries_dev, flo
 {
     if (!idx || m < 1 || !queries_dev || !scores_dev || !qnorm_dev || !consts)
         return fail(KNN_EINVAL, "knn_debug_filter_scores: bad arguments");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     if (!idx->filter.usable)
         return fail(KNN_EINVAL, "knn_debug_filter_scores: this index has no filter layouts");
     DeviceGuard guard(idx->device);
@@ -698,6 +704,7 @@ int knn_index_timing(knn_index *idx, int enable)
 {
     if (!idx)
         return fail(KNN_EINVAL, "knn_index_timing: null index");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     idx->timing = enable > 0 ? enable : 0;
     idx->timing_seq = 0;
     idx->events_used = 0;
@@ -708,6 +715,7 @@ int knn_index_timing_read(knn_index *idx, int *launches, double *total_ms)
 {
     if (!idx || !launches || !total_ms)
         return fail(KNN_EINVAL, "knn_index_timing_read: bad arguments");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
     double sum = 0.0;
     for (size_t i = 0; i < idx->events_used; ++i) {
@@ -726,6 +734,7 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
 {
     if (!idx || !stats)
         return fail(KNN_EINVAL, "knn_index_last_stats: bad arguments");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     const FilterWorkspace &w = idx->filter.ws[idx->last_slot];
     if ((idx->stats[0] == 2 || idx->stats[0] == 4) && w.ctl) {
         DeviceGuard guard(idx->device);
@@ -752,6 +761,7 @@ int knn_index_debug_counters(knn_index *idx, long long out[4])
 {
     if (!idx || !out)
         return fail(KNN_EINVAL, "knn_index_debug_counters: bad arguments");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     out[0] = out[1] = out[2] = out[3] = 0;
     const FilterWorkspace &w = idx->filter.ws[idx->last_slot];
     if (idx->stats[0] == 4 && w.ctl_cur) {

@@ -973,3 +973,49 @@ def test_grid_index_give_up_flag_is_reset_between_batches_on_a_slot(oracle):
     ix.close()
     for j, Q in enumerate(batches):
         np.testing.assert_array_equal(outs[j][0].cpu().numpy(), oracle.v0(k, Q, R), err_msg=f"batch {j}")
+
+
+def test_one_index_driven_from_several_host_threads(oracle):
+    """Round 2 documented "one index, one host thread"; the index now serialises its callers.  Four threads, each with
+    its own slot, stream and batch, 20 calls each on ONE index (ctypes drops the GIL inside the library): every answer is
+    v0's."""
+    import threading
+    k, m, n = 16, 512, 1 << 18
+    R = oracle.synth(n * k, 77)
+    dev = torch.device("cuda:0")
+    r_d = torch.from_numpy(R).to(dev)
+    pkg.set_option("cells", 1)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    finally:
+        pkg.set_option("cells", 0)
+    nthreads, rounds = 4, 20
+    Qs = [oracle.synth(m * k, 300 + t).reshape(m, k) for t in range(nthreads)]
+    wants = [oracle.v0(k, Q, R, threads=THREADS) for Q in Qs]
+    errors = []
+
+    def worker(t):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            q_d = torch.from_numpy(Qs[t]).to(dev)
+            keys = torch.empty(m, dtype=torch.int64, device=dev)
+            out = torch.empty(m, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(rounds):
+                ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), stream=st.cuda_stream, slot=t, init_keys=True)
+                pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr(), stream=st.cuda_stream)
+                st.synchronize()
+                if not (out.cpu().numpy() == wants[t]).all():
+                    errors.append((t, "mismatch"))
+                    return
+                ix.last_stats()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    ix.close()
+    assert not errors, errors

@@ -32,11 +32,26 @@ def make_data(rng, kind, rows, k):
     if kind == "heavy":
         x = rng.normal(0, 1, (rows, k)) / np.sqrt(np.maximum(rng.random((rows, 1)), 1e-4))
         return x.astype(np.float32)
+    if kind == "tight":           # clusters far tighter than the fp16 step: every row of a query's cluster is a candidate
+        nc = int(rng.choice([2, 9, 64, 300]))
+        c = rng.random((nc, k), dtype=np.float32)
+        return (c[rng.integers(0, nc, rows)] + rng.normal(0, float(rng.choice([1e-5, 1e-4, 1e-3])), (rows, k))).astype(np.float32)
+    if kind == "lowrank":         # a low-dimensional subspace: most cells empty, a few fat
+        r = int(rng.integers(1, max(2, min(5, k))))
+        b = rng.normal(0, 1, (r, k))
+        return (rng.normal(0, 1, (rows, r)) @ b).astype(np.float32)
+    if kind == "mixture":
+        c = rng.random((1000, k), dtype=np.float32)
+        return (c[rng.integers(0, 1000, rows)] + rng.normal(0, 0.05, (rows, k))).astype(np.float32)
+    if kind == "onepoint":        # (almost) every row the same point
+        x = np.tile(rng.random((1, k), dtype=np.float32), (rows, 1))
+        x[rng.integers(0, rows, max(1, rows // 1000))] += np.float32(0.25)
+        return x
     raise ValueError(kind)
 
 
 def one_case(o, rng, case):
-    k = int(rng.choice([1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 32, 33, 48, 64, 100, 128, 130]))
+    k = int(rng.choice([1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 32, 33, 48, 64, 100, 128, 130, 200, 256, 257, 400, 512, 513, 700]))
     m = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 100, 257, 1000, 1024, 2049]))
     n = int(rng.choice([1, 2, 31, 33, 1000, 4097, 65535, 65536, 70001, 200000, 600000]))
     if k * n > 40_000_000 or k * m * n > 3e11:
@@ -98,19 +113,26 @@ def cells_case(o, rng, case):
     first left in the workspace: lists, flags, the pinned switch-off word)."""
     k = int(rng.choice([3, 5, 8, 12, 15, 16]))
     m = int(rng.choice([1, 7, 33, 100, 257, 1000, 1024, 1300]))
-    n = int(rng.choice([1 << 17, 150001, 262144, 400000, 600000, 1200000]))
-    kind = str(rng.choice(["uniform", "gauss", "offset", "grid", "clusters", "heavy"]))
+    n = int(rng.choice([1 << 17, 150001, 262144, 400000, 600000, 1200000, 1 << 21]))
+    kind = str(rng.choice(["uniform", "gauss", "offset", "grid", "clusters", "heavy", "tight", "lowrank", "mixture", "onepoint"]))
     shards = int(rng.choice([0, 0, 0, 2]))
     R = make_data(rng, kind, n, k)
-    Q = make_data(rng, kind, m, k)
-    Q2 = make_data(rng, str(rng.choice(["uniform", kind])), m, k)
+    if kind in ("tight", "lowrank", "mixture", "onepoint"):   # queries from the same structure: rows of it, jittered
+        Q = (R[rng.integers(0, n, m)] + rng.normal(0, float(rng.choice([0.0, 1e-4, 1e-2])), (m, k))).astype(np.float32)
+    else:
+        Q = make_data(rng, kind, m, k)
+    variant, deal, blocks = int(rng.choice([0, 0, 0, 1, 2, 3])), int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    pkg.set_option("cells_variant", variant)
+    pkg.set_option("scan_deal", deal)
+    pkg.set_option("scan_blocks", blocks)
+    Q2 = make_data(rng, "uniform" if kind in ("tight", "lowrank", "mixture", "onepoint") else str(rng.choice(["uniform", kind])), m, k)
     if rng.random() < 0.3:
         Q[: min(m, 8)] = R[rng.integers(0, n, min(m, 8))]
     if rng.random() < 0.15:
         R[rng.integers(0, n), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3e38]))
     if rng.random() < 0.1:
         Q2[rng.integers(0, m), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, 1e30]))
-    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards)
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, variant=variant, deal=deal, blocks=blocks)
     pkg.set_option("cells", 1)
     pkg.set_option("shards", shards)
     pkg.set_option("path", int(rng.choice([0, 2])))
@@ -143,7 +165,7 @@ def main():
             if case % 25 == 24:
                 print("%d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
     finally:
-        for name in ("path", "shards", "stream", "cells"):
+        for name in ("path", "shards", "stream", "cells", "cells_variant", "scan_deal", "scan_blocks"):
             pkg.set_option(name, 0)
     print("all %d cases bit-exact (seed %d)" % (cases, seed))
     return 0
