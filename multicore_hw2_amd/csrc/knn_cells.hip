@@ -1780,7 +1780,11 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
                            u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys)
 {
     u64 *keys_init = init_keys ? keys : nullptr;
-    const int variant = st.cells_variant;
+    // (the fused sweep kernel — an experiment arm — gives a cell to ONE wave and re-ranks its hits inline: on a set whose rows
+    // crowd into a few cells it runs for minutes (190 s for 2^21 copies of one point, tools/fuzz_parity.py).  Such indexes —
+    // the ones round 2 declined: largest cell > 16x the average — take the default chain whatever the option says.)
+    const bool fat_cells = (long long)st.cells->max_cell_rows * (long long)st.cells->ncells > 16ll * st.n;
+    const int variant = st.cells_variant == 3 && fat_cells ? 0 : st.cells_variant;
     FTRY(ensure_cells_workspace(st, w, m, variant != 3));
     const CellIndex &c = *st.cells;
     const int m_padded = (m + 31) / 32 * 32;

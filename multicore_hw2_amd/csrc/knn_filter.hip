@@ -1856,7 +1856,7 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
             FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
             // gated on the device, both: the listed pairs exactly when the records overflowed, the whole shard when the
             // batch has a query nothing bounds
-            if (st.cells_variant != 3)
+            if (w.nlists != 0u)   // (0: the sweep arm re-ranked its hits itself: no record buffers to overflow)
                 FTRY(knn_cells_exact_launch(st.k, mb, base, qb, r, st.cells->items, st.cells->nitems, w.cell_counts, w.cell_lists,
                                             st.cells->cap, perm, w.ctl_cur, kb, num_cu, s));
             FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));

@@ -216,6 +216,27 @@ def test_both_ways_of_dealing_items_to_the_scan_waves_are_bit_exact(oracle, deal
     assert st[0] == 4 and st[2] in (0, 2), st
 
 
+def test_the_sweep_arm_steps_aside_on_indexes_with_fat_cells(oracle):
+    """`cells_variant` 3 hands a cell to one wave: 2^18 copies of one point kept it busy for minutes (found by
+    tools/fuzz_parity.py).  Indexes whose largest cell holds more than 16x the average take the default chain instead —
+    including its exact evaluation of the listed cells when the records overflow."""
+    k, m, n = 8, 600, 1 << 18
+    rng = np.random.default_rng(9)
+    Q, R = _off_the_cube(rng, "one_point", k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("cells_variant", 3)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("cells_variant", 0)
+    np.testing.assert_array_equal(got, want)
+    assert st[0] == 4 and st[2] in (0, 2), st
+
+
 def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle):
     """1024 copies of one query want the same ~4 % of the cells, with all 1024 on each of their lists: far beyond a
     list's on-chip room (256 entries at 2^16 cells).  Round 2 answered such a batch with the exact scan and sent the

@@ -133,6 +133,8 @@ def cells_case(o, rng, case):
     if rng.random() < 0.1:
         Q2[rng.integers(0, m), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, 1e30]))
     desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, variant=variant, deal=deal, blocks=blocks)
+    if os.environ.get("FUZZ_VERBOSE") == "1":
+        print("case", desc, "%.1f s" % time.time(), flush=True)
     pkg.set_option("cells", 1)
     pkg.set_option("shards", shards)
     pkg.set_option("path", int(rng.choice([0, 2])))
