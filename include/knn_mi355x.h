@@ -155,7 +155,7 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
  *             (shards of at least 64 MiB)
  *   "deepk"   tuning / A-B: the LDS-tiled filter scan for 32 < k <= 128 with >= 512 queries (128 < k <= 512 always run its
- *             one-tile-per-barrier form with 2 / 1 blocks of queries per wave): 0 = auto (4 waves x 4
+ *             one-tile-per-barrier form with 2 / 1 blocks of queries per wave, 512 < k <= 4096 the chunked-K kernel): 0 = auto (4 waves x 4
  *             query tiles share every staged reference tile; for k > 64 four reference tiles are staged per barrier by
  *             LDS-DMA), 1 = 8 waves per block, 2 / 4 = that many reference tiles per barrier, 3 = one tile per
  *             barrier through registers (the round-2 kernel)

@@ -484,7 +484,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     const bool want_cells = k <= 16 && n_local >= (1ll << 17) &&
                             (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));
     if (build_filter < 0) {
-        // library policy: shards of >= 65536 rows; for 32 < k <= 512 (3k+3 exact lane-ops per pair,
+        // library policy: shards of >= 65536 rows; for 32 < k <= 4096 (3k+3 exact lane-ops per pair,
         // one query per lane above k = 64, row-per-lane kernels above 128) the MFMA filter pays off from 4096 rows already
         build_filter = g_opt_path == 2 || n_local >= 65536 || (k > 32 && k <= KNN_FILTER_MAX_K && n_local >= 4096);
         idx->filter_wanted = build_filter && n_local < 65536 && g_opt_path != 2;
@@ -1050,7 +1050,7 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
         const double exact_rate = (fast_k || m < 48) ? 58e12 : k <= 64 ? 45e12 : k <= 128 ? 22e12 : 5e12;
         const double t_exact = (3.0 * k + 3.0) * pairs / exact_rate;
-        const int kt = knn_kt_of(k);   // 0: no fp16 layouts for this k (k > 512)
+        const int kt = knn_kt_of(k);   // 0: no fp16 layouts for this k (k > 4096)
         const double t_filter = kt == 0 ? 1e30
                                         : 1.0e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * kt * pairs + 1e-4;
         const double t_filter_under_copy = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // host rows: layouts built under the copy

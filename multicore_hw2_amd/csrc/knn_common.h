@@ -108,12 +108,14 @@ struct FilterWorkspace {
 };
 
 // 16-wide K steps of the fp16 layouts for dimension k: 1, 2, 4, 8 (register / LDS-tiled scans), 16 and 32 (LDS-tiled scan with
-// two / one block of queries per wave: the B operands of k = 512 fill a wave's registers); 0 = no filter for this k.
-#define KNN_FILTER_MAX_K 512
+// two / one block of queries per wave: the B operands of k = 512 fill a wave's registers), beyond that a multiple of 8 (K walked
+// in chunks of 128 dimensions, knn_filter_chunked_kernel); 0 = no filter for this k.
+#define KNN_FILTER_MAX_K 4096
 #define KNN_CELL_ITEM_TILES 18     // two passes of the scan (CELL_TILES_PER_PASS = 9)
 static inline int knn_kt_of(int k)
 {
-    return k < 1 ? 0 : k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : k <= 128 ? 8 : k <= 256 ? 16 : k <= KNN_FILTER_MAX_K ? 32 : 0;
+    return k < 1 ? 0 : k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : k <= 128 ? 8 : k <= 256 ? 16 : k <= 512 ? 32
+         : k <= KNN_FILTER_MAX_K ? 8 * ((k + 127) / 128) : 0;
 }
 
 // Cell-sorted layout of the references (k <= 16): see the head of knn_cells.hip.

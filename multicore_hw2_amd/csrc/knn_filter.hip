@@ -872,6 +872,177 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Any k beyond 512 (round 3).  The B operands of even one block of 32 queries no longer fit a wave's registers, so K is
+// walked in CHUNKS of KC = 8 K-steps (128 dimensions; the layouts pad k to a multiple of 128): a wave owns QT = 2 blocks of
+// queries and keeps the accumulators of T = 4 reference tiles x QT alive (128 registers) while the chunks go by; per
+// chunk it fetches its B fragments (64 registers, from L2: 16 KiB per 64 MFMAs) and the block's four waves share the
+// T tiles' A fragments of that chunk through LDS (32 KiB, LDS-DMA, double-buffered: one barrier per chunk, every
+// ds_read_b128 feeds two MFMAs).  After the last chunk the T x QT accumulators go through the same min3 tree /
+// threshold / record code as knn_filter_tiled_kernel (records carry row masks).  SAMPLE as there.
+//   grid.x blocks split the groups of T (sampled) reference tiles, grid.y = groups of 4 * QT query tiles.
+// ------------------------------------------------------------------------------------------
+#define CHK_KC 8
+#define CHK_T 4
+#define CHK_QT 2
+template <bool SAMPLE>
+__global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
+    const float *__restrict__ thrg, int kt, int qtiles, long long ntiles, long long stride,
+    float *__restrict__ umin, int m_padded, u64 *__restrict__ rec, unsigned *__restrict__ counts,
+    unsigned *__restrict__ ctl, unsigned slice, unsigned short *__restrict__ rec_rows)
+{
+    constexpr int WAVES = FILTER_BLOCK / 64;
+    constexpr int PIECES = CHK_T * CHK_KC;          // 1 KiB pieces of A per stage
+    static_assert(PIECES % WAVES == 0, "a stage's pieces are dealt out evenly to the waves");
+    __shared__ h8 s_a[2][PIECES * 64];
+    __shared__ f4v s_n[2][CHK_T * 8];
+    if (!SAMPLE && ctl[KNN_CTL_FALLBACK] != 0u)
+        return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qt0 = (blockIdx.y * WAVES + wib) * CHK_QT;   // this wave's first query tile
+    const int nq = max(0, min(CHK_QT, qtiles - qt0));      // wave-uniform; 0 = padding wave
+    const int nchunks = kt / CHK_KC;
+
+    const long long ns = (ntiles + stride - 1) / stride;            // (sampled) tiles
+    const long long ng = (ns + CHK_T - 1) / CHK_T;                  // groups of T
+    const long long g0 = ng * blockIdx.x / gridDim.x, g1 = ng * (blockIdx.x + 1) / gridDim.x;
+
+    float th[CHK_QT], um[CHK_QT];
+    int qtile[CHK_QT];
+#pragma unroll
+    for (int t = 0; t < CHK_QT; ++t) {
+        qtile[t] = min(qt0 + min(t, max(nq - 1, 0)), qtiles - 1);
+        th[t] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + (lane & 31)] : -INFINITY;
+        um[t] = INFINITY;
+    }
+    const size_t list = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wib;
+    u64 *__restrict__ my_rec = SAMPLE ? nullptr : rec + list * slice;
+    unsigned short *__restrict__ my_rows = SAMPLE ? nullptr : rec_rows + list * slice;
+    unsigned cnt = 0u;
+
+    // stage = (group, chunk): the A fragments of the group's T tiles for K-steps [8 chunk, 8 chunk + 8), and with chunk 0
+    // the tiles' norms.  Tiles past the end are clamped to the last one (their scores are dropped in the epilogue).
+    auto issue = [&](int buf, long long g, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pp = 0; pp < PIECES / WAVES; ++pp) {
+            const int piece = wib * (PIECES / WAVES) + pp;      // = tt * KC + kk
+            const int tt = piece / CHK_KC, kk = piece % CHK_KC;
+            const long long tile = min((g * CHK_T + tt) * stride, ntiles - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rf + ((size_t)tile * kt + (size_t)chunk * CHK_KC + kk) * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&s_a[buf][piece * 64], 16, 0, 0);
+        }
+        if (chunk == 0 && wib == 0 && lane < CHK_T * 8) {
+            const long long tile = min((g * CHK_T + (lane >> 3)) * stride, ntiles - 1);
+            s_n[buf][lane] = *(const f4v *)(rn + (size_t)tile * 32 + 4 * (lane & 7));
+        }
+    };
+    if (g0 < g1) {
+        f16v acc[CHK_T][CHK_QT];
+        issue(0, g0, 0);
+        __syncthreads();   // (waits for the DMA: hipcc drains vmcnt in front of the barrier)
+        int buf = 0;
+        for (long long g = g0; g < g1; ++g) {
+            for (int chunk = 0; chunk < nchunks; ++chunk, buf ^= 1) {
+                // the next stage is in flight while this one is scored
+                if (chunk + 1 < nchunks)
+                    issue(buf ^ 1, g, chunk + 1);
+                else if (g + 1 < g1)
+                    issue(buf ^ 1, g + 1, 0);
+                h8 qf[CHK_QT][CHK_KC];
+#pragma unroll
+                for (int t = 0; t < CHK_QT; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < CHK_KC; ++kk)
+                        qf[t][kk] = qfg[((size_t)qtile[t] * kt + (size_t)chunk * CHK_KC + kk) * 64 + lane];
+                if (chunk == 0) {
+#pragma unroll
+                    for (int tt = 0; tt < CHK_T; ++tt) {
+                        f16v c;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const f4v v = s_n[buf][tt * 8 + 2 * gq + (lane >> 5)];
+                            c[4 * gq + 0] = v[0];
+                            c[4 * gq + 1] = v[1];
+                            c[4 * gq + 2] = v[2];
+                            c[4 * gq + 3] = v[3];
+                        }
+#pragma unroll
+                        for (int t = 0; t < CHK_QT; ++t)
+                            acc[tt][t] = c;
+                    }
+                }
+#pragma unroll
+                for (int tt = 0; tt < CHK_T; ++tt)
+#pragma unroll
+                    for (int kk = 0; kk < CHK_KC; ++kk) {
+                        const h8 a = s_a[buf][(tt * CHK_KC + kk) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < CHK_QT; ++t)
+                            acc[tt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[t][kk], acc[tt][t], 0, 0, 0);
+                    }
+                if (chunk + 1 == nchunks) {
+#pragma unroll
+                    for (int tt = 0; tt < CHK_T; ++tt) {
+                        const long long i = g * CHK_T + tt;   // (sampled) tile number
+                        if (i >= ns)
+                            continue;   // block-uniform: a clamped copy of the last tile
+#pragma unroll
+                        for (int t = 0; t < CHK_QT; ++t) {
+                            const f16v &x = acc[tt][t];
+                            const float m0 = min3f(x[0], x[1], x[2]);
+                            const float m1 = min3f(x[3], x[4], x[5]);
+                            const float m2 = min3f(x[6], x[7], x[8]);
+                            const float m3 = min3f(x[9], x[10], x[11]);
+                            const float m4 = min3f(x[12], x[13], x[14]);
+                            const float m5 = min3f(m0, m1, m2);
+                            const float m6 = min3f(m3, m4, x[15]);
+                            if (SAMPLE) {
+                                um[t] = min3f(m5, m6, um[t]);
+                            } else {
+                                const float mn = min3f(m5, m6, th[t]);
+                                const bool hit = mn < th[t];
+                                const u64 mask = __ballot(hit);
+                                if (__builtin_expect(mask != 0ull, 0)) {
+                                    if (hit) {
+                                        const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                        if (pos < slice) {
+                                            my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) |
+                                                          ((u64)(i * stride) << 1) | (u64)(lane >> 5);
+                                            unsigned rm = 0u;
+#pragma unroll
+                                            for (int r16 = 0; r16 < 16; ++r16)
+                                                rm |= x[r16] < th[t] ? (1u << r16) : 0u;
+                                            my_rows[pos] = (unsigned short)rm;
+                                        }
+                                    }
+                                    cnt += (unsigned)__popcll(mask);
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();   // the next stage has landed; nobody reads this one any more
+            }
+        }
+    }
+    if (SAMPLE) {
+#pragma unroll
+        for (int t = 0; t < CHK_QT; ++t) {
+            const float v = fminf(um[t], __shfl_xor(um[t], 32, KNN_WAVE));
+            if (lane < 32 && t < nq)
+                umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + lane] = v;
+        }
+    } else if (lane == 0) {
+        counts[list] = cnt;
+        if (cnt > slice)
+            ctl[KNN_CTL_FALLBACK] = 1u;
+    }
+}
+
 // Sample pass: the same MFMA stream over every `stride`-th reference tile, keeping only the
 // running minimum score per query (no thresholds, no branches).  It replaces an exact pre-pass:
 // the minimum is a score of a real reference, which is all knn_threshold needs.  Per-block
@@ -974,6 +1145,33 @@ __global__ __launch_bounds__(64) void knn_filter_scores_kernel(const h8 *__restr
     for (int kk = 0; kk < KT; ++kk)
         d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], qfg[((size_t)blockIdx.y * KT + kk) * 64 + lane], d,
                                                    0, 0, 0);
+    const long long q = (long long)blockIdx.y * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long long r = (long long)blockIdx.x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (q < m && r < n)
+            scores[(size_t)q * n + r] = d[i];
+    }
+}
+
+// The same for any kt (k > 512): K-steps in a loop, fragments straight from memory.
+__global__ __launch_bounds__(64) void knn_filter_scores_rt_kernel(const h8 *__restrict__ rf, const float *__restrict__ rn,
+                                                                  const h8 *__restrict__ qfg, int kt, int m, long long n,
+                                                                  float *__restrict__ scores)
+{
+    const int lane = threadIdx.x & 63;
+    f16v d;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const f4v v = *(const f4v *)(rn + (size_t)blockIdx.x * 32 + 8 * gq + 4 * (lane >> 5));
+        d[4 * gq + 0] = v[0];
+        d[4 * gq + 1] = v[1];
+        d[4 * gq + 2] = v[2];
+        d[4 * gq + 3] = v[3];
+    }
+    for (int kk = 0; kk < kt; ++kk)
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf[((size_t)blockIdx.x * kt + kk) * 64 + lane],
+                                                   qfg[((size_t)blockIdx.y * kt + kk) * 64 + lane], d, 0, 0, 0);
     const long long q = (long long)blockIdx.y * 32 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -1825,6 +2023,64 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     return hipSuccess;
 }
 
+// k > 512: the chunked-K scan (knn_filter_chunked_kernel), sample pass -> thresholds -> scan, as launch_filter_tiled.
+static hipError_t launch_filter_chunked(FilterState &st, FilterWorkspace &w, int m, int num_cu, hipStream_t s)
+{
+    const int qtiles = (m + 31) / 32;
+    const int m_padded = qtiles * 32;
+    const unsigned gy = (unsigned)((qtiles + 4 * CHK_QT - 1) / (4 * CHK_QT));
+    const long long groups = (st.ntiles + CHK_T - 1) / CHK_T;
+    unsigned gx = ((unsigned)num_cu * 8 + gy - 1) / gy;
+    if ((long long)gx > groups)
+        gx = (unsigned)groups;
+    if (gx < 1)
+        gx = 1;
+    while ((size_t)gx * 4 * gy > kMaxLists && gx > 1)
+        gx = (gx + 1) / 2;
+    if ((size_t)gx * 4 * gy > kMaxLists)
+        return hipErrorInvalidValue;
+    w.nlists = gx * 4 * gy;
+    w.slice = w.rec_cap / w.nlists;
+    long long stride = st.ntiles / 256;
+    if (stride < 1)
+        stride = 1;
+    if (stride > 16)
+        stride = 16;
+    const long long sgroups = ((st.ntiles + stride - 1) / stride + CHK_T - 1) / CHK_T;
+    unsigned sb = gx;
+    if ((long long)sb > sgroups)
+        sb = (unsigned)sgroups;
+    {
+        const size_t need = (size_t)sb * (size_t)m_padded;
+        if (need > w.umin_cap) {
+            (void)KNN_DEV_FREE(w.umin);
+            w.umin = nullptr;
+            w.umin_cap = 0;
+            FTRY(KNN_DEV_ALLOC((void **)&w.umin, need * sizeof(float)));
+            w.umin_cap = need;
+        }
+    }
+    hipLaunchKernelGGL(knn_filter_chunked_kernel<true>, dim3(sb, gy), dim3(FILTER_BLOCK), 0, s, (const h8 *)st.ref_frags,
+                       st.ref_norms, (const h8 *)w.qry_frags, w.thr, st.kt, qtiles, st.ntiles, stride, w.umin, m_padded, w.records,
+                       w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap));
+    FTRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
+                       (int)sb, w.qry_norms, w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
+                       w.thr, w.ctl, w.qpart, (m_padded + 255) / 256, w.counts, w.nlists);
+    FTRY(hipGetLastError());
+    if (w.ev_begin)
+        FTRY(hipEventRecord(w.ev_begin, s));
+    hipLaunchKernelGGL(knn_filter_chunked_kernel<false>, dim3(gx, gy), dim3(FILTER_BLOCK), 0, s, (const h8 *)st.ref_frags,
+                       st.ref_norms, (const h8 *)w.qry_frags, w.thr, st.kt, qtiles, st.ntiles, 1ll, w.umin, m_padded, w.records,
+                       w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap));
+    w.has_rows = true;
+    w.pieces = RerankPieces();
+    FTRY(hipGetLastError());
+    if (w.ev_end)
+        FTRY(hipEventRecord(w.ev_end, s));
+    return hipSuccess;
+}
+
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
                             u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys)
 {
@@ -1889,7 +2145,11 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     // queries); the B operands of 2 / 1 blocks of 32 queries are the wave's 128 operand registers
     case 16: FTRY((launch_filter_tiled<16, 2>(st, w, m, num_cu, s))); break;
     case 32: FTRY((launch_filter_tiled<32, 1>(st, w, m, num_cu, s))); break;
-    default: return hipErrorInvalidValue;
+    default:   // k > 512: K in chunks of 128 dimensions
+        if (st.kt % CHK_KC != 0)
+            return hipErrorInvalidValue;
+        FTRY(launch_filter_chunked(st, w, m, num_cu, s));
+        break;
     }
     // exact re-rank of the survivors; a list that overflowed its slice raises the fallback flag
     FTRY(knn_rerank_launch(st.k, positions, q, r, base, w.records,
@@ -1917,7 +2177,8 @@ hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float 
     case 4: hipLaunchKernelGGL(knn_filter_scores_kernel<4>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     case 8: hipLaunchKernelGGL(knn_filter_scores_kernel<8>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
     case 16: hipLaunchKernelGGL(knn_filter_scores_kernel<16>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
-    default: hipLaunchKernelGGL(knn_filter_scores_kernel<32>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    case 32: hipLaunchKernelGGL(knn_filter_scores_kernel<32>, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, m, st.n, scores); break;
+    default: hipLaunchKernelGGL(knn_filter_scores_rt_kernel, grid, dim3(64), 0, s, (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, st.kt, m, st.n, scores); break;
     }
     FTRY(hipGetLastError());
     FTRY(hipMemcpyAsync(qnorm_out, w.qry_norms, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));

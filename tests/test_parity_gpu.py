@@ -56,7 +56,10 @@ def test_ragged_shapes_bit_exact(oracle, path, k, m, n):
                                    (128, 600, 4100), (40, 513, 9000), (64, 2048, 70000), (33, 1000, 131072),
                                    # 128 < k <= 512: the LDS-tiled filter with 2 / 1 blocks of queries per wave; beyond: exact only
                                    (129, 600, 4100), (200, 70, 9000), (256, 513, 5000), (257, 300, 9000), (384, 1100, 4100),
-                                   (512, 200, 5000), (513, 100, 3000), (1000, 48, 2000)])
+                                   (512, 200, 5000),
+                                   # k > 512: K walked in chunks of 128 dimensions (knn_filter_chunked_kernel); k > 4096: exact only
+                                   (513, 100, 3000), (1000, 48, 2000), (640, 300, 4100), (1024, 513, 3000), (1500, 70, 5000),
+                                   (4096, 64, 1200), (4100, 48, 600)])
 def test_synthetic_uniform_bit_exact(oracle, path, k, m, n):
     Q, R = oracle.synth(m * k, 1000), oracle.synth(n * k, 1001)
     got = pkg.cudaCallback(k, m, n, Q, R)
@@ -184,7 +187,7 @@ def _filter_case(rng, name, m, n, k):
     raise ValueError(name)
 
 
-@pytest.mark.parametrize("k", [3, 16, 24, 100, 200, 500])
+@pytest.mark.parametrize("k", [3, 16, 24, 100, 200, 500, 700, 1100])
 @pytest.mark.parametrize("dist", ["uniform", "offset", "clustered", "mixed_scales", "queries_outside"])
 def test_filter_scores_stay_inside_the_proven_error_bound(k, dist):
     """The MFMA filter is only sound if |S + M - sigma^2 d^2| <= 2 eta sigma d + eta^2 + rho for
@@ -244,7 +247,7 @@ def test_filter_path_is_taken_and_reports_candidates(oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("k,m,n", [(256, 2048, 32768), (512, 1024, 16384), (160, 100, 20000)])
+@pytest.mark.parametrize("k,m,n", [(256, 2048, 32768), (512, 1024, 16384), (160, 100, 20000), (1024, 1024, 16384), (600, 300, 20001)])
 def test_deep_dimensions_take_the_filter_and_stay_bit_exact(oracle, k, m, n):
     """128 < k <= 512 (the reference loops over any k, core.cu:831-835): library policy puts these on the MFMA filter
     (round 2 left them on the row-per-lane exact kernels); gaussian data, planted exact duplicates."""
@@ -450,7 +453,7 @@ def test_one_far_away_query_does_not_loosen_the_whole_batch(oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("k", [16, 40, 128, 256, 512])
+@pytest.mark.parametrize("k", [16, 40, 128, 256, 512, 1024])
 def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
     """The one unproven constant of the filter bound is omega = kt * 2^-18: the matrix core's internal
     fp32 accumulation error relative to the sum of term magnitudes.  Measured here by rebuilding the
@@ -486,7 +489,7 @@ def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
     mag = np.abs(N.astype(np.float64))[None, :] + np.abs(terms).sum(-1)
     S = scores.cpu().numpy().astype(np.float64)
     rel = float((np.abs(S - exact) / mag).max())
-    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8 if k <= 128 else 16 if k <= 256 else 32
+    kt = 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8 if k <= 128 else 16 if k <= 256 else 32 if k <= 512 else 8 * ((k + 127) // 128)
     assert rel <= kt * 2.0 ** -18, rel
     assert rel <= 2.0 ** -20, rel   # in practice about one fp32 rounding per 16-wide K-step
 
