@@ -331,6 +331,22 @@ def main():
         torch.cuda.synchronize()
         serial_step_ms = (time.perf_counter() - t1) * 1e3 / 50
     index.timing(False)
+    # the exchange step by itself (N > 1): one group's all-reduce + unpack on the reduction stream, nothing else running —
+    # what a rank's step carries on top of its scan when the collective does not hide behind the next group
+    collective_ms = None
+    if dist is not None:
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        with torch.cuda.stream(reduce_stream):
+            ev0.record()
+            for _ in range(reps):
+                dist.all_reduce(keys_all[0, :nbuf], op=dist.ReduceOp.MIN)
+                pkg.keys_to_indices(keys_all[0].data_ptr(), nbuf * m, outs_all[0].data_ptr(), device=local_rank,
+                                    stream=reduce_stream.cuda_stream)
+            ev1.record()
+        torch.cuda.synchronize()
+        collective_ms = ev0.elapsed_time(ev1) / reps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -464,7 +480,9 @@ def main():
                        "keys_init": "separate launch" if args.separate_init else "inside the query (KNN_QUERY_INIT_KEYS)",
                        "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %
                                       ("gloo (one-GPU rehearsal)" if rehearse else "rccl", nbuf, m, nbuf))
-                       if dist is not None else None},
+                       if dist is not None else None,
+                       "collective_ms_per_group_alone": collective_ms,
+                       "collective_ms_per_step_alone": collective_ms / nbuf if collective_ms is not None else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu_all is not None:
