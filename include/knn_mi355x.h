@@ -193,6 +193,11 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             is 6-8 % shorter: no wave is left with twice the average), 0 = auto: 2 for callers that query one batch at a
  *             time, 1 once a workspace slot other than 0 has been used (batches in flight fill each other's gaps; the
  *             fixed deal's cheaper prologue then gives the shorter step)
+ *   "graphs"  1 = on the cell-pruned path (batches of up to 1024 queries, a non-null stream) the second call that repeats the
+ *             previous call's arguments on a slot records the batch's launches as a hipGraph from the caller's stream, and
+ *             later ones replay it with one hipGraphLaunch (knn_get_option("graph_replays") counts them).  0 = plain
+ *             launches (default: measured on ROCm 7.2 the replay is SLOWER than the six launches it replaces — one batch at
+ *             a time 0.078 -> 0.085 ms at 2^21 rows, 0.160 -> 0.167 at C3; equal with batches in flight)
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

@@ -73,6 +73,8 @@ std::atomic<long long> g_opt_deepk{0};
 std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pruned path (knn_cells_query)
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
 std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
+std::atomic<long long> g_graph_replays{0};       // batches answered by hipGraphLaunch (tests)
+std::atomic<long long> g_opt_graphs{0};          // cell-pruned path: replay a batch's launches as a hipGraph when a call repeats the previous one's arguments
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
@@ -263,6 +265,17 @@ struct knn_index {
     // work of different slots still overlaps): the workspaces' lazily grown buffers, the event list, the statistics and
     // the chain events are plain members.  Recursive: knn_index_query_host calls the keyed entry points.
     std::recursive_mutex mu;
+    // Option `graphs`: the launches of one batch on the cell-pruned path (prep, match, scan, re-rank, the two gated
+    // fallbacks), captured from the caller's stream the second time a call repeats the previous call's arguments on a slot
+    // and replayed with ONE hipGraphLaunch from then on.  Two graphs per slot: the control words alternate between two
+    // blocks from batch to batch (knn_cells_query), and a graph has its block baked in.
+    struct GraphCache {
+        hipGraphExec_t exec[2] = {nullptr, nullptr};
+        int m = -1;
+        const float *q = nullptr;
+        const void *keys = nullptr;
+        long long opts = -1;   // init flag, kernel variants, several_slots: what else the launches have baked in
+    } graphs[KNN_SLOTS];
 };
 
 extern "C" {
@@ -348,6 +361,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_scan_blocks = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "graphs")) {
+        if (value < 0 || value > 1)
+            return fail(KNN_EINVAL, "knn_set_option: graphs must be 0 or 1");
+        g_opt_graphs = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "scan_deal")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: scan_deal must be 0 (auto), 1 (fixed deal) or 2 (block counter)");
@@ -413,6 +432,10 @@ long long knn_get_option(const char *name)
         return g_opt_scan_blocks;
     if (name && !strcmp(name, "scan_deal"))
         return g_opt_scan_deal;
+    if (name && !strcmp(name, "graphs"))
+        return g_opt_graphs;
+    if (name && !strcmp(name, "graph_replays"))
+        return g_graph_replays;
     if (name && !strcmp(name, "deepk"))
         return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -574,6 +597,10 @@ void knn_index_destroy(knn_index *idx)
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
+        for (auto &gc : idx->graphs)
+            for (auto &e : gc.exec)
+                if (e)
+                    (void)hipGraphExecDestroy(e);
     }
     delete idx;
 }
@@ -671,6 +698,52 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         idx->filter.scan_blocks = (int)g_opt_scan_blocks;
         idx->filter.scan_deal = (int)g_opt_scan_deal;
         idx->last_slot = slot;
+        FilterState &fs = idx->filter;
+        const bool graph_ok = g_opt_graphs != 0 && !ev && s != nullptr && fs.cells && fs.cells_policy != 2 && fs.kt == 1 &&
+                              m <= KNN_CELL_BATCH && (fs.cells_variant == 0 || fs.cells_variant == 2);
+        if (graph_ok) {
+            knn_index::GraphCache &gc = idx->graphs[slot];
+            FilterWorkspace &w = fs.ws[slot];
+            const long long opts = (init_keys ? 1 : 0) | (fs.cells_variant << 1) | (fs.scan_blocks << 4) | (fs.scan_deal << 7) |
+                                   (fs.several_slots ? 1 << 10 : 0);
+            if (gc.m == m && gc.q == queries_dev && gc.keys == (const void *)keys_dev && gc.opts == opts) {
+                const unsigned parity = w.cell_batches & 1u;
+                if (!gc.exec[parity]) {
+                    // second (third) call with these arguments: record this batch's launches instead of issuing them.  The
+                    // first call ran the ordinary way, so every buffer the launches name exists already.
+                    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                    const hipError_t qe = knn_filter_query(fs, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
+                                                           idx->num_cu, s, nullptr, nullptr, init_keys);
+                    hipGraph_t graph = nullptr;
+                    const hipError_t ce = hipStreamEndCapture(s, &graph);
+                    hipError_t ie = hipSuccess;
+                    if (qe == hipSuccess && ce == hipSuccess && graph)
+                        ie = hipGraphInstantiate(&gc.exec[parity], graph, nullptr, nullptr, 0);
+                    if (graph)
+                        (void)hipGraphDestroy(graph);
+                    HIP_TRY(qe);
+                    HIP_TRY(ce);
+                    HIP_TRY(ie);
+                } else {
+                    ++w.cell_batches;   // what knn_cells_query does on the host for a batch
+                    w.ctl_cur = w.ctl + KNN_CTL_WORDS * (1u + parity);
+                    w.last_used_cells = true;
+                }
+                HIP_TRY(hipGraphLaunch(gc.exec[parity], s));
+                ++g_graph_replays;
+                idx->stats[0] = 4;
+                return KNN_OK;
+            }
+            for (auto &e : gc.exec)
+                if (e) {
+                    (void)hipGraphExecDestroy(e);
+                    e = nullptr;
+                }
+            gc.m = m;
+            gc.q = queries_dev;
+            gc.keys = (const void *)keys_dev;
+            gc.opts = opts;
+        }
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys));
         if (idx->filter.ws[slot].last_used_cells)

@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells", "cells_variant", "scan_deal"):
+    for name in ("path", "shards", "cells", "cells_variant", "scan_deal", "graphs"):
         pkg.set_option(name, 0)
 
 
@@ -420,3 +420,45 @@ def test_c3_full_shape_every_query_against_the_oracle(oracle):
     assert st[0] == 4 and st[2] == 0, st
     want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("slots", [1, 3])
+def test_graph_replay_of_a_batch_answers_like_the_launches_it_recorded(oracle, slots):
+    """Option `graphs`: the second call that repeats the previous call's arguments on a slot records the batch's launches
+    from the caller's stream, later ones replay them with one hipGraphLaunch.  Same buffers, NEW contents every round
+    (a serving loop): every answer is v0's; a batch with a NaN query still takes the gated exact scan inside the graph."""
+    k, m, n = 16, 777, 1 << 18
+    R = oracle.synth(n * k, 41)
+    dev = torch.device("cuda:0")
+    r_d = torch.from_numpy(R).to(dev)
+    pkg.set_option("cells", 1)
+    pkg.set_option("graphs", 1)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+        q_d = [torch.empty((m, k), dtype=torch.float32, device=dev) for _ in range(slots)]
+        keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(slots)]
+        outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(slots)]
+        before = pkg.get_option("graph_replays")
+        for rnd in range(7):
+            wants = []
+            for b in range(slots):
+                Q = oracle.synth(m * k, 1000 + 10 * rnd + b).reshape(m, k).copy()
+                if rnd == 5 and b == 0:
+                    Q[3, 2] = np.nan          # the whole batch falls back to the exact scan, on the device
+                wants.append(oracle.v0(k, Q, R, threads=THREADS))
+                q_d[b].copy_(torch.from_numpy(Q))
+            torch.cuda.synchronize()
+            for b in range(slots):
+                ix.query_keys(m, q_d[b].data_ptr(), keys[b].data_ptr(), stream=streams[b].cuda_stream, slot=b, init_keys=True)
+                pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), stream=streams[b].cuda_stream)
+            torch.cuda.synchronize()
+            for b in range(slots):
+                np.testing.assert_array_equal(outs[b].cpu().numpy(), wants[b], err_msg=f"round {rnd} slot {b}")
+            st = ix.last_stats()
+            assert st[0] == 4 and st[2] == (1 if rnd == 5 and slots == 1 else st[2])
+        assert pkg.get_option("graph_replays") - before >= 3 * slots     # rounds 0 (and 1 after the slot switch) ran the ordinary way
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("graphs", 0)
