@@ -16,36 +16,36 @@
 // cycles per 32x32 tile pair whatever the schedule, so the only way under it is not to
 // score most pairs.  The index sorts the rows into 2^B cells — every dimension cut into 2^nb[d] bins at
 // sample quantiles, cell = the tuple of bin numbers — and lays the fp16 fragments out cell by cell (each
-// cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch, TWO kernels
-// (round 3; the round-2 chain was query fragments -> seed -> match -> scan, four dependent launches):
-//   prep    : one WAVE per query.  The wave rounds the query to its fp16 B operand, scores the query's own cell and
-//             the 3 cells across its two nearest cuts with the MFMA (all their tiles in flight at once) — the
-//             minimum is a score of a real reference, which is all knn_threshold needs — derives thr_q for the
-//             scores and Dup_q = the largest real (scaled) squared distance any candidate for the answer can have,
-//             and tabulates the separable halves of the cell lower bound: a row of cell c differs from the query by
-//             at least gap_d(bin_d(c)) in every dimension, so LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of
-//             the cell = lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  LB > Dup_q rules the whole cell
-//             out, ties included (a row that ties with the answer obeys the Dup bound too).  The kernel also starts
-//             the batch's keys at (+INF, 0) when asked to and clears the control words of the NEXT batch.
-//   sweep   : match + scan in one kernel.  A block owns C consecutive cells.  Phase A (the old match kernel):
-//             which queries cannot rule the cells out — queries on the lanes against the high table, survivors
-//             against 64-byte runs of the low table — appended to per-cell lists that live in LDS (a list longer
-//             than its LDS room turns the cell `dense`: every query of the batch is scored against it, which is
-//             what a list that long asks for anyway — no overflow, no fallback).  Phase B (the old scan kernel): a
-//             wave walks its cells; per cell it gathers the listed queries' B operands from LDS (32 per block of
-//             columns) and runs MFMA + min3 tree + threshold test over the cell's tiles; the first cell's tiles are
-//             requested before phase A so that HBM latency hides under it.
-// The C operand (reference norms along the query axis) no longer comes through LDS — four broadcast
-// ds_read_b128 per tile and block of queries were what bound the round-2 scan next to its bytes (12k LDS
-// instructions per CU at C3, 4k per CU for the 2^21-row shards of an 8-GPU run) — but out of the matrix core: the
-// layout keeps every norm as two fp16 halves (ref_norms2: N ~ hi + mid 2^-11, exact to 2^-22 N, folded into rho),
-// lanes 0..31 hold their row's pair as K-slots 0 and 1 of an otherwise zero A operand, and one extra MFMA against
-// the constant B operand {1, 2^-11, 0 ...} leaves N_row in every column of the accumulator the scoring MFMA
-// then continues from.  The matrix pipe has the room: the pruned scan issues 4 % of the full scan's MFMAs.
+// cell padded to whole 32-row tiles, `perm` maps a layout position back to its row).  Per batch (the default chain):
+//   prep    : one block of 2 or 4 waves per query (knn_cells_prep_kernel).  Rounds the query to its fp16 B operand, scores
+//             the query's own cell and the 3 cells across its two nearest cuts with the MFMA (a cell of many tiles is
+//             sampled) — the minimum is a score of a real reference, which is all knn_threshold needs — derives thr_q for
+//             the scores and Dup_q = the largest real (scaled) squared distance any candidate for the answer can have,
+//             and tabulates the separable halves of the cell lower bound: a row of cell c differs from the query by at
+//             least gap_d(bin_d(c)) in every dimension, so LB(c, q) = sum_d gap_d^2 <= |q - r|^2 for every row of the
+//             cell = lo_q[low bits of c] + hi_q[high bits], both rounded DOWN.  LB > Dup_q rules the whole cell out, ties
+//             included (a row that ties with the answer obeys the Dup bound too).  The kernel also starts the batch's
+//             keys at (+INF, 0) when asked to and clears the control words of the NEXT batch.
+//   match   : cell-major (knn_cells_match_kernel): which queries cannot rule a cell out — queries on the lanes against the
+//             high table, survivors against 64-byte runs of the low table — written as per-cell lists (a list longer than
+//             its room marks the cell `dense`: scored against every query of the batch, which is what a list that long asks
+//             for anyway).
+//   scan    : knn_cells_scan_kernel.  The unit of work is an ITEM: a run of at most 18 tiles of one cell (fat cells of
+//             clustered data are several items, empty cells none).  A wave loads the item's tiles once, gathers the listed
+//             queries' B operands from LDS 32 at a time and runs MFMA + min3 tree + threshold test per tile; hits become
+//             records (query, tile, half) in the wave's slice, overflow in a small area all waves share.
+//   re-rank : knn_rerank_kernel (knn_exact.hip): v0's arithmetic on the records' 16 rows each, through `perm`.
+//   gated, on the device: more candidates than the record buffers hold (rows of a cluster tighter than the fp16 step:
+//             every row of a query's cells passes) -> knn_cells_exact_kernel evaluates the batch's listed (item, query) pairs
+//             with the exact arithmetic — the geometry's verdict stands, it never depended on fp16; a query nothing bounds
+//             (not finite, far away, no real row seen) -> the exact scan of the whole shard.  Nothing switches the cells off
+//             for later batches.
+// A/B arms kept selectable with their parity tests (`cells_variant`): 1 = the round-2 chain (query fragments, seed, match,
+// scan); 2 = the scan's C tile (reference norms) out of one extra MFMA on norms kept as two fp16 halves (ref_norms2:
+// N ~ hi + mid 2^-11, exact to 2^-22 N, folded into rho) instead of four broadcast ds_read_b128; 3 = prep + "sweep": match,
+// scan and exact re-rank fused into one persistent kernel with the lists in LDS.  2 and 3 lose to the lean scan at every
+// size (profiles/r03_sweep_experiments.txt): registers per wave are what the path is short of.
 // Uniform data in 16 dimensions, n = 2^24: ~1600 of 65536 cells survive per query, 25 queries per cell.
-// What still raises the FALLBACK flag for a batch (the gated exact scan answers it): non-finite or far-away
-// queries, a query for which neither its seed cells nor a strided sample of the layout held a single row, and a
-// wave's record slice overflowing.  Nothing switches the cells off for later batches.
 // ------------------------------------------------------------------------------------------
 #define CELL_MAX_BINS 16
 #define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts
