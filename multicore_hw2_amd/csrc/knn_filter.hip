@@ -20,14 +20,20 @@
 //     magnitudes (16x a single fp32 rounding per 16-wide K-step; the matrix core's internal summation order is
 //     not documented).  It is measured on every GPU test run: test_mfma_accumulation_error_is_far_inside_the_
 //     assumed_allowance rebuilds the fp16 operands on the host, evaluates N - 2 a.b in float64 and asserts the
-//     device scores are within 2^-20 (a 4x margin to the allowance) for k = 16, 40, 128; test_filter_scores_stay_
-//     inside_the_proven_error_bound checks the whole bound against float64 distances on 20 data sets.
+//     device scores are within 2^-20 (a 4x margin to the allowance) for k = 16 ... 1024; test_filter_scores_stay_
+//     inside_the_proven_error_bound checks the whole bound against float64 distances on 40 data sets (k = 3 ... 1100).
 //   => S_j* <= Dup + 2 eta sqrt(Dup) + eta^2 + rho - M_q(1-g) =: thr_q.
 //
 // Survivors are written as records (query, reference tile, lane half) and re-evaluated with the
 // exact arithmetic by knn_rerank_kernel, which folds them into the packed keys.  If anything
 // rules the filter out (non-finite data, fp16 range, record overflow) a device-side flag makes
 // the gated exact kernels scan everything instead: results are bit-exact either way.
+//
+// Scans by dimension (kt = 16-wide K-steps of the padded k, knn_kt_of): kt 1, 2 (and kt 4, 8 with few queries)
+// knn_filter_kernel, fragments in registers; kt 4, 8 knn_filter_tiled_kernel, reference tiles shared by a block's waves
+// through LDS, 4 query blocks per wave; kt 16, 32 (128 < k <= 512) the same kernel with 2 / 1 query blocks per wave;
+// beyond (k <= 4096) knn_filter_chunked_kernel, K walked in chunks of 128 dimensions.  k <= 16 on large resident
+// shards: the cell-pruned form, knn_cells.hip.
 #include "knn_filter_dev.h"
 
 // ------------------------------------------------------------------------------------------
