@@ -185,7 +185,7 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             thresholds, pruning tables, keys) + match + scan; 1 = the round-2 chain (query fragments, seed, match,
  *             scan); 2 = as 0 with the scan's norm tile out of an extra MFMA instead of LDS; 3 = prep + sweep
  *             (match, scan and exact re-rank in one persistent kernel; an experiment, slower than 0)
- *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^14 cells once a query has
+ *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^15 cells once a query has
  *             used a workspace slot other than 0 — batches in flight side by side: the scan alone gets 10-20 % longer and
  *             the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
  *   "scan_deal" how the pruned scan's waves get their work items (runs of tiles of one cell): 1 = fixed (wave w takes items

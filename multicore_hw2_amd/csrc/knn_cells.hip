@@ -1802,7 +1802,9 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // launch — and leave nothing for the kernels of the next batch, so with batches in flight side by side the step was the
     // SUM of the kernels' durations.  One block per CU: the scan alone takes 10-20 % longer, the step of a shard of up to 2^14
     // cells 5-7 % less (0.0465 -> 0.0444 ms at 2^21 rows; at C3 the two are within 1 %: it keeps two).
-    const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 16384u);
+    // (2^15 cells, n = 2^23: step 0.0795 -> 0.0777 with one, three runs each on one box; 2^16 cells, C3: 0.1237 -> 0.1223, not
+    // worth the 8 % the launch itself gets longer)
+    const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 32768u);
     unsigned gx = (unsigned)num_cu * (one_block ? 1u : 2u);
     if (gx * CELL_SCAN_WAVES > c.nitems)
         gx = std::max(1u, c.nitems / CELL_SCAN_WAVES);
