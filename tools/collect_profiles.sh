@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_b/ — a fresh directory: gpurun MERGES into
+# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_c/ — a fresh directory: gpurun MERGES into
 # gpurun_out/, and an earlier collection's files would mix with this one's; tools/pmc_traffic.py and the
 # copy into profiles/ happen afterwards in the build container).  usage: gpurun -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03_final_b
+O=$R/gpurun_out/r03_final_c
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
@@ -41,9 +41,10 @@ step "one batch at a time (single-slot callers: block-counter deal, two blocks p
 for n in 16777216 4194304 2097152; do
   timeout -k 10 200 python3 $R/bench.py --workload 16,1024,$n --cpu-queries 0 --serial > $O/16_1024_${n}_serial_bench.json 2>> $O/c3_bench.err || exit 1
 done
-step "128 < k <= 512 on the MFMA filter"
+step "128 < k <= 4096 on the MFMA filter"
 timeout -k 10 200 python3 $R/bench.py --workload 256,65536,65536 --cpu-queries 0 --steps 20 --warmup 3 > $O/256_65536_65536_bench.json 2>> $O/c3_bench.err || exit 1
 timeout -k 10 200 python3 $R/bench.py --workload 512,65536,65536 --cpu-queries 0 --steps 20 --warmup 3 > $O/512_65536_65536_bench.json 2>> $O/c3_bench.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --workload 1024,65536,65536 --cpu-queries 0 --steps 10 --warmup 2 > $O/1024_65536_65536_bench.json 2>> $O/c3_bench.err || exit 1
 step "off the uniform cube"
 ( cd $R && timeout -k 10 300 python3 tools/distribution_check.py 2>&1 | grep -v amdgpu.ids > $O/distribution_check.txt ) || exit 1
 for c in clusters64 heavy_tail; do
