@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_c/ — a fresh directory: gpurun MERGES into
+# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_e/ — a fresh directory: gpurun MERGES into
 # gpurun_out/, and an earlier collection's files would mix with this one's; tools/pmc_traffic.py and the
 # copy into profiles/ happen afterwards in the build container).  usage: gpurun -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03_final_c
+O=$R/gpurun_out/r03_final_e
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
@@ -28,9 +28,12 @@ step "kernel traces: pipelined (the default bench) and --serial (one batch at a 
 for w in c3 c2 c5; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -- python3 $R/bench.py --workload $w --cpu-queries 0 > /dev/null 2>&1 || exit 1
 done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c3_serial -- python3 $R/bench.py --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2097152_serial -- python3 $R/bench.py --workload 16,1024,2097152 --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2097152_r02chain_serial -- python3 $R/bench.py --workload 16,1024,2097152 --cpu-queries 0 --serial --cells-variant 1 --separate-init > /dev/null 2>&1 || exit 1
+# (--serial from a fresh process would take the single-slot shapes — items from a block counter, two blocks per CU; the traces the
+# roofline block is checked against must show the kernel of the TIMED region: the fixed deal, one block per CU on small shards)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c3_serial -- python3 $R/bench.py --cpu-queries 0 --serial --opt scan_deal=1 --opt scan_blocks=2 > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c3_serial_block_counter -- python3 $R/bench.py --cpu-queries 0 --serial > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2097152_serial -- python3 $R/bench.py --workload 16,1024,2097152 --cpu-queries 0 --serial --opt scan_deal=1 --opt scan_blocks=1 > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2097152_r02chain_serial -- python3 $R/bench.py --workload 16,1024,2097152 --cpu-queries 0 --serial --cells-variant 1 --separate-init --opt scan_deal=1 --opt scan_blocks=1 > /dev/null 2>&1 || exit 1
 step "pmc passes (C3)"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-queries 0 > /dev/null 2>&1 || exit 1

@@ -26,7 +26,8 @@ for path in sorted(glob.glob(os.path.join(src, "*_bench.json"))):
 for name in ("build_trace", "cells_trace", "dropin_timing", "ingest_timing", "distribution_check"):
     shutil.copy(os.path.join(src, name + ".txt"), os.path.join(dst, f"{tag}_{name}.txt"))
 for d, out in (("kt_c3", "c3_kernel_stats"), ("kt_c2", "c2_kernel_stats"), ("kt_c5", "c5_kernel_stats"),
-               ("kt_c3_serial", "c3_serial_kernel_stats"), ("kt_2097152_serial", "16_1024_2097152_serial_kernel_stats"),
+               ("kt_c3_serial", "c3_serial_kernel_stats"), ("kt_c3_serial_block_counter", "c3_serial_block_counter_kernel_stats"),
+               ("kt_2097152_serial", "16_1024_2097152_serial_kernel_stats"),
                ("kt_2097152_r02chain_serial", "16_1024_2097152_r02chain_serial_kernel_stats"),
                ("kt_clusters64", "clusters64_kernel_stats"), ("kt_heavy_tail", "heavy_tail_kernel_stats")):
     shutil.copy(one(f"{d}/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{out}.csv"))
