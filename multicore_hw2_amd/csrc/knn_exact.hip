@@ -23,6 +23,7 @@
 #include "knn_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -612,21 +613,35 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__re
         // and ONE guarded atomic is issued per record (the keys sit on a handful of cache lines; the
         // unguarded 16-per-record form spent ~1 ms in atomic contention at 270k records).
         const unsigned total = (nrec * 16u + GROUP - 1) / GROUP * GROUP;
-        for (unsigned c = tid_l; c < total; c += GROUP) {
-            u64 key = ~0ull;
-            unsigned qi = 0u;
-            if (c < nrec * 16u) {
-                const unsigned rmask = rec_rows ? rec_rows[(size_t)list_id * slice + (c >> 4)] : 0xFFFFu;
-                key = rerank_pair<K>(Q, R, k, n, base, list[c >> 4], c & 15u, rmask, qrow_base, perm, qi);
+        // Four chunks of pairs per trip: a pair is a chain of dependent loads (record -> perm -> rows), and a wave that owns a
+        // long list (skewed data: 136k records over 6144 lists, the longest in the thousands) walked it one round trip at a
+        // time — 0.084 ms for that batch's re-rank, 0.072 with four in flight (a block of four waves per list: 0.062 — it is
+        // the few very long lists, not the width).  Short lists (the usual case) make one trip either way.
+        constexpr unsigned U = LPW ? 4u : 1u;
+        for (unsigned c0 = tid_l; c0 < total; c0 += GROUP * U) {
+            u64 key[U];
+            unsigned qi[U];
+#pragma unroll
+            for (unsigned u = 0; u < U; ++u) {
+                const unsigned c = c0 + u * GROUP;
+                key[u] = ~0ull;
+                qi[u] = 0u;
+                if (c < nrec * 16u) {
+                    const unsigned rmask = rec_rows ? rec_rows[(size_t)list_id * slice + (c >> 4)] : 0xFFFFu;
+                    key[u] = rerank_pair<K>(Q, R, k, n, base, list[c >> 4], c & 15u, rmask, qrow_base, perm, qi[u]);
+                }
             }
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const u64 o = __shfl_xor(key, off, KNN_WAVE);
-                key = o < key ? o : key;
+            for (unsigned u = 0; u < U; ++u) {
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    const u64 o = __shfl_xor(key[u], off, KNN_WAVE);
+                    key[u] = o < key[u] ? o : key[u];
+                }
+                // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
+                if ((threadIdx.x & 15u) == 0u && key[u] != ~0ull && key[u] < keys[qi[u]])
+                    key_atomic_min(&keys[qi[u]], key[u]);
             }
-            // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
-            if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
-                key_atomic_min(&keys[qi], key);
         }
     }
     // the shared overflow area (cell-pruned path: what did not fit a wave's slice), all blocks striding over it
