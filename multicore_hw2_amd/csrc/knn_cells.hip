@@ -186,6 +186,281 @@ __global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
     // test above and are on the exact list)
 }
 
+// ---- the two-pass build (round 3) ---------------------------------------------------------------------------
+// The one-pass placement above reads the rows once and writes every row's 44 bytes as five pieces to a random place of a
+// 0.6 GB layout: 3.2 GB of HBM writes for 0.73 GB of output at n = 2^24 (partial lines), and 16 M atomics on 2^16
+// counters in front of it.  Two-pass: the rows are first grouped by the TOP 8 BITS of their cell code — 256 buckets of
+// consecutive cells, 256 write streams of whole 64-byte lines — and every bucket is then placed by blocks that share
+// one XCD's L2: its 2-3 MB of layout are written piecewise but leave the cache as whole lines.  Cell counts come from
+// per-block LDS histograms of a bucket's records instead of one global atomic per row.
+#define CELL_BUCKETS 256
+#define CELL_PLACE_PARTS 16   // blocks per bucket in the placement pass
+
+#define CELL_BUILD_ROWS 4096   // rows (records) a block of the build's passes handles: 16 per thread
+
+// the cell code of a row held in registers
+__device__ __forceinline__ unsigned cell_code_of(const float (&x)[16], const CellGeom &g, const float *__restrict__ bounds)
+{
+    unsigned c = 0u;
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+        if (d < g.k && g.nb[d])
+            c |= cell_bin(bounds + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], x[d]) << g.shift[d];
+    return c;
+}
+
+// A: code of every row + how many rows each bucket gets.  (A lane reads its 64-byte row as four 16-byte loads when k = 16:
+// sixteen 4-byte loads at a 64-byte stride kept the texture path busy for 0.9 ms of a pass that moves 1 GB.)
+__global__ __launch_bounds__(256) void knn_cells_bucket_count_kernel(const float *__restrict__ R, long long n, CellGeom g,
+                                                                     const float *__restrict__ bounds, int bshift,
+                                                                     unsigned *__restrict__ code,
+                                                                     unsigned *__restrict__ bucket_counts)
+{
+    __shared__ unsigned s_h[CELL_BUCKETS];
+    __shared__ float s_bnd[16 * (CELL_MAX_BINS - 1)];
+    s_h[threadIdx.x] = 0u;
+    if (threadIdx.x < 16 * (CELL_MAX_BINS - 1))
+        s_bnd[threadIdx.x] = bounds[threadIdx.x];
+    __syncthreads();
+    const bool vec = g.k == 16 && ((uintptr_t)R & 15u) == 0;
+    const long long i0 = (long long)blockIdx.x * CELL_BUILD_ROWS;
+    for (int it = 0; it < CELL_BUILD_ROWS / 256; ++it) {
+        const long long i = i0 + it * 256 + threadIdx.x;
+        if (i < n) {
+            float x[16];
+            if (vec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4v v = __builtin_nontemporal_load(&((const f4v *)(R + (size_t)i * 16))[j]);
+                    x[4 * j] = v[0];
+                    x[4 * j + 1] = v[1];
+                    x[4 * j + 2] = v[2];
+                    x[4 * j + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 16; ++d)
+                    x[d] = d < g.k ? R[(size_t)i * g.k + d] : 0.0f;
+            }
+            const unsigned c = cell_code_of(x, g, s_bnd);
+            code[i] = c;
+            atomicAdd(&s_h[c >> bshift], 1u);
+        }
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x] != 0u)
+        atomicAdd(&bucket_counts[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// Block-wide helper of the build's passes: s_h[256] holds a histogram of the block's 4096 items over 256 bins; on return
+// s_start[bin] = first slot of the bin in the block's sorted order (exclusive prefix), s_h unchanged.  256 threads.
+__device__ __forceinline__ void block_prefix_256(const unsigned *__restrict__ s_h, unsigned *__restrict__ s_start,
+                                                 unsigned *__restrict__ s_wsum)
+{
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const unsigned v = s_h[threadIdx.x];
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off, KNN_WAVE);
+        if (lane >= (unsigned)off)
+            inc += o;
+    }
+    if (lane == 63u)
+        s_wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0u;
+    for (unsigned j = 0; j < w; ++j)
+        base += s_wsum[j];
+    s_start[threadIdx.x] = base + inc - v;
+    __syncthreads();
+}
+
+// B: every row to the next free record of its bucket: 64 bytes of coordinates (k of them used) + (code << 32 | row).  A block
+// counts its 4096 rows per bucket first and reserves its room in every bucket with ONE atomic (one per row's block of 256
+// was 16 M returning atomics on 256 words: 1.6 ms), then writes in BUCKET order — a counting sort of the rows' numbers in
+// LDS — so that the ~16 records it adds to a bucket leave as one 1 KiB run (in row order they were 64-byte pieces spread
+// over time: 0.94 ms against 0.6).
+__global__ __launch_bounds__(256) void knn_cells_bucket_scatter_kernel(const float *__restrict__ R, long long n, int k, int bshift,
+                                                                       const unsigned *__restrict__ code,
+                                                                       const unsigned *__restrict__ bucket_start,
+                                                                       unsigned *__restrict__ bucket_fill,
+                                                                       float *__restrict__ trows, u64 *__restrict__ tmeta)
+{
+    __shared__ unsigned s_h[CELL_BUCKETS], s_start[CELL_BUCKETS], s_cur[CELL_BUCKETS], s_base[CELL_BUCKETS], s_wsum[4];
+    __shared__ unsigned short s_order[CELL_BUILD_ROWS];
+    s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const long long i0 = (long long)blockIdx.x * CELL_BUILD_ROWS;
+    unsigned cs[CELL_BUILD_ROWS / 256];
+#pragma unroll
+    for (int it = 0; it < CELL_BUILD_ROWS / 256; ++it) {
+        const long long i = i0 + it * 256 + threadIdx.x;
+        cs[it] = i < n ? code[i] : 0u;
+        if (i < n)
+            atomicAdd(&s_h[cs[it] >> bshift], 1u);
+    }
+    __syncthreads();
+    block_prefix_256(s_h, s_start, s_wsum);
+    {
+        const unsigned cnt = s_h[threadIdx.x];   // thread t reserves the block's room in bucket t
+        s_base[threadIdx.x] = cnt != 0u ? bucket_start[threadIdx.x] + atomicAdd(&bucket_fill[threadIdx.x], cnt) : 0u;
+        s_cur[threadIdx.x] = s_start[threadIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < CELL_BUILD_ROWS / 256; ++it)
+        if (i0 + it * 256 + threadIdx.x < n)
+            s_order[atomicAdd(&s_cur[cs[it] >> bshift], 1u)] = (unsigned short)(it * 256 + threadIdx.x);
+    __syncthreads();
+    const unsigned nrows = (unsigned)min((long long)CELL_BUILD_ROWS, n - i0);
+    const bool vec = k == 16 && ((uintptr_t)R & 15u) == 0;
+    for (unsigned slot = threadIdx.x; slot < nrows; slot += 256u) {
+        const unsigned src = s_order[slot];
+        const long long i = i0 + src;
+        const unsigned c = code[i];
+        const unsigned bk = c >> bshift;
+        const size_t pos = (size_t)s_base[bk] + (slot - s_start[bk]);
+        const float *__restrict__ x = R + (size_t)i * k;
+        float *__restrict__ t = trows + pos * 16;
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ((f4v *)t)[j] = ((const f4v *)x)[j];
+        } else {
+            for (int d = 0; d < k; ++d)
+                t[d] = x[d];
+        }
+        tmeta[pos] = ((u64)c << 32) | (u64)(unsigned)i;
+    }
+}
+
+// C1: rows per cell from the buckets' records (a bucket's cells are consecutive: an LDS histogram per block).
+__global__ __launch_bounds__(256) void knn_cells_bucket_cellcount_kernel(const u64 *__restrict__ tmeta,
+                                                                         const unsigned *__restrict__ bucket_start, int bshift,
+                                                                         unsigned *__restrict__ counts)
+{
+    __shared__ unsigned s_h[256];   // cells of one bucket (2^bshift <= 256: bits <= 16)
+    const unsigned b = blockIdx.x / CELL_PLACE_PARTS, part = blockIdx.x % CELL_PLACE_PARTS;
+    s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned r0 = bucket_start[b], r1 = bucket_start[b + 1];
+    const unsigned len = (r1 - r0 + CELL_PLACE_PARTS - 1u) / CELL_PLACE_PARTS;
+    const unsigned a = min(r0 + part * len, r1), e = min(a + len, r1);
+    for (unsigned i = a + threadIdx.x; i < e; i += 256u)
+        atomicAdd(&s_h[(unsigned)(tmeta[i] >> 32) & ((1u << bshift) - 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < (1u << bshift) && s_h[threadIdx.x] != 0u)
+        atomicAdd(&counts[((size_t)b << bshift) + threadIdx.x], s_h[threadIdx.x]);
+}
+
+// C2: a bucket's records to their places in the layout: what knn_cells_scatter_frag_kernel writes for a row (same
+// arithmetic, same outlier rule).  All CELL_PLACE_PARTS blocks of a bucket run on ONE XCD (blocks go to the XCDs round robin),
+// 32 buckets per XCD one after the other.  A block walks its records in runs of 4096: cells counted in LDS, the run's room
+// in every cell reserved with one atomic per cell, ranks from LDS.
+__global__ __launch_bounds__(256) void knn_cells_place_kernel(
+    const float *__restrict__ trows, const u64 *__restrict__ tmeta, const unsigned *__restrict__ bucket_start, int k, int bshift,
+    const unsigned *__restrict__ tile_start, unsigned *__restrict__ fill, const float *__restrict__ center, float sigma,
+    h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ norms2, unsigned *__restrict__ perm,
+    unsigned *__restrict__ out, unsigned *__restrict__ olist, unsigned ocap)
+{
+    __shared__ unsigned s_h[256], s_start[256], s_cur[256], s_pos[256], s_wsum[4];
+    __shared__ unsigned short s_order[CELL_BUILD_ROWS];
+    __shared__ float s_c[16];
+    const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
+    const unsigned b = (jb / CELL_PLACE_PARTS) * 8u + xcd, part = jb % CELL_PLACE_PARTS;
+    const unsigned r0 = bucket_start[b], r1 = bucket_start[b + 1];
+    const unsigned len = (r1 - r0 + CELL_PLACE_PARTS - 1u) / CELL_PLACE_PARTS;
+    const unsigned a = min(r0 + part * len, r1), e = min(a + len, r1);
+    const unsigned cmask = (1u << bshift) - 1u;
+    if (threadIdx.x < 16)
+        s_c[threadIdx.x] = threadIdx.x < (unsigned)k ? center[threadIdx.x] : 0.0f;
+    float vmax = 0.0f, nmaxv = 0.0f;
+    for (unsigned run = a; run < e; run += CELL_BUILD_ROWS) {   // (block-uniform)
+        __syncthreads();   // the previous run's tables are done with
+        s_h[threadIdx.x] = 0u;
+        __syncthreads();
+        unsigned cl[CELL_BUILD_ROWS / 256];
+#pragma unroll
+        for (int it = 0; it < CELL_BUILD_ROWS / 256; ++it) {
+            const unsigned i = run + it * 256 + threadIdx.x;
+            cl[it] = i < e ? (unsigned)(tmeta[i] >> 32) & cmask : 0u;
+            if (i < e)
+                atomicAdd(&s_h[cl[it]], 1u);
+        }
+        __syncthreads();
+        block_prefix_256(s_h, s_start, s_wsum);
+        {
+            const unsigned cnt = s_h[threadIdx.x];   // thread t: cell t of the bucket
+            const unsigned c = (b << bshift) + threadIdx.x;
+            s_pos[threadIdx.x] = cnt != 0u ? tile_start[c] * 32u + atomicAdd(&fill[c], cnt) : 0u;
+            s_cur[threadIdx.x] = s_start[threadIdx.x];
+        }
+        __syncthreads();
+        // the run's records in CELL order (counting sort of their numbers): the ~16 a cell gets go to consecutive places
+#pragma unroll
+        for (int it = 0; it < CELL_BUILD_ROWS / 256; ++it)
+            if (run + it * 256 + threadIdx.x < e)
+                s_order[atomicAdd(&s_cur[cl[it]], 1u)] = (unsigned short)(it * 256 + threadIdx.x);
+        __syncthreads();
+        const unsigned nrec = min((unsigned)CELL_BUILD_ROWS, e - run);
+        for (unsigned slot = threadIdx.x; slot < nrec; slot += 256u) {
+            const unsigned i = run + s_order[slot];
+            const u64 meta = tmeta[i];
+            const unsigned c = (unsigned)(meta >> 32), row = (unsigned)meta;
+            const f4v *__restrict__ x4 = (const f4v *)(trows + (size_t)i * 16);
+            bool real = true;
+            float nrm = 0.0f, vm = 0.0f;
+            h8 v[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f4v xa = x4[2 * half], xb = x4[2 * half + 1];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int d = half * 8 + jj;
+                    const float xv = jj < 4 ? xa[jj] : xb[jj - 4];
+                    const float sc = d < k ? (xv - s_c[d]) * sigma : 0.0f;   // fp32 subtract, exact power-of-two scale
+                    const _Float16 hval = (_Float16)sc;                      // round to nearest even
+                    const float back = (float)hval;
+                    real = real && fabsf(back) <= 1.0f;                      // outside the robust box, NaN included
+                    vm = fmaxf(vm, fabsf(back));
+                    nrm = nrm + back * back;                                 // exact products, fp32 sum
+                    v[half][jj] = hval;
+                }
+            }
+            if (!real) {   // out of the filter (zero fragment, +INF norm), into the exact list
+                const unsigned opos = atomicAdd(&out[3], 1u);
+                if (opos < ocap)
+                    olist[opos] = row;
+                v[0] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+                v[1] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+                vm = 0.0f;
+                nrm = 0.0f;
+            }
+            const size_t pos = (size_t)s_pos[c & cmask] + (slot - s_start[c & cmask]);
+            frag[(pos >> 5) * 64 + (pos & 31)] = v[0];
+            frag[(pos >> 5) * 64 + 32 + (pos & 31)] = v[1];
+            norms[pos] = real ? nrm : INFINITY;
+            norms2[pos] = pack_norm22(real ? nrm : INFINITY);
+            perm[pos] = row;
+            vmax = fmaxf(vmax, vm);
+            nmaxv = fmaxf(nmaxv, nrm);
+        }
+    }
+    vmax = wave_max_f(vmax);
+    nmaxv = wave_max_f(nmaxv);
+    __shared__ float s_v[4], s_n[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = vmax;
+        s_n[threadIdx.x >> 6] = nmaxv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        guarded_atomic_max(&out[0], __float_as_uint(fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]))));
+        guarded_atomic_max(&out[1], __float_as_uint(fmaxf(fmaxf(s_n[0], s_n[1]), fmaxf(s_n[2], s_n[3]))));
+    }
+}
+
 __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
 {
     const float m0 = min3f(x[0], x[1], x[2]);
@@ -1464,6 +1739,9 @@ void knn_cells_free(CellIndex *&c)
     (void)KNN_DEV_FREE(c->tile_start);
     (void)KNN_DEV_FREE(c->perm);
     (void)KNN_DEV_FREE(c->items);
+    (void)KNN_DEV_FREE(c->tmp_rows);
+    (void)KNN_DEV_FREE(c->tmp_meta);
+    (void)KNN_DEV_FREE(c->bucket_start);
     delete c;
     c = nullptr;
 }
@@ -1545,14 +1823,78 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     if (e == hipSuccess)
         e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(knn_cells_code_kernel, dim3(blocks), dim3(256), 0, s, r, n, g, c->bounds, code, counts);
-        e = hipGetLastError();
+    // Two-pass build (see the kernels): needs n x 72 bytes of scratch; without it (or with KNN_MI355X_BUILD_ONE_PASS set, for
+    // A/B timing) the one-pass placement serves.
+    static const bool one_pass_env = getenv("KNN_MI355X_BUILD_ONE_PASS") != nullptr;
+    const int bshift = bits - 8;   // bits >= 9: a bucket = 2^bshift consecutive cells
+    const unsigned bblocks = (unsigned)((n + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS);
+    unsigned *bucket_counts = nullptr, *bucket_fill = nullptr;
+    bool two_pass = e == hipSuccess && !one_pass_env;
+    if (two_pass) {
+        hipError_t a = KNN_DEV_ALLOC((void **)&c->tmp_rows, (size_t)n * 16 * sizeof(float));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->tmp_meta, (size_t)n * sizeof(u64));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->bucket_start, (CELL_BUCKETS + 1) * sizeof(unsigned));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&bucket_counts, 2 * CELL_BUCKETS * sizeof(unsigned));
+        if (a != hipSuccess) {   // no room for the scratch: one pass
+            (void)hipGetLastError();
+            (void)KNN_DEV_FREE(c->tmp_rows);
+            (void)KNN_DEV_FREE(c->tmp_meta);
+            (void)KNN_DEV_FREE(c->bucket_start);
+            (void)KNN_DEV_FREE(bucket_counts);
+            c->tmp_rows = nullptr;
+            c->tmp_meta = nullptr;
+            c->bucket_start = nullptr;
+            bucket_counts = nullptr;
+            two_pass = false;
+        } else
+            bucket_fill = bucket_counts + CELL_BUCKETS;
     }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(s);   // (also keeps `bounds` alive until its copy is done)
+    if (two_pass) {
+        unsigned hb[CELL_BUCKETS], hbs[CELL_BUCKETS + 1];
+        e = hipMemsetAsync(bucket_counts, 0, 2 * CELL_BUCKETS * sizeof(unsigned), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(knn_cells_bucket_count_kernel, dim3(bblocks), dim3(256), 0, s, r, n, g, c->bounds, bshift, code,
+                               bucket_counts);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(hb, bucket_counts, sizeof hb, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            unsigned acc = 0u;
+            for (int b = 0; b < CELL_BUCKETS; ++b) {
+                hbs[b] = acc;
+                acc += hb[b];
+            }
+            hbs[CELL_BUCKETS] = acc;
+            e = hipMemcpyAsync(c->bucket_start, hbs, sizeof hbs, hipMemcpyHostToDevice, s);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(knn_cells_bucket_scatter_kernel, dim3(bblocks), dim3(256), 0, s, r, n, k, bshift, code, c->bucket_start,
+                               bucket_fill, c->tmp_rows, c->tmp_meta);
+            hipLaunchKernelGGL(knn_cells_bucket_cellcount_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, c->tmp_meta,
+                               c->bucket_start, bshift, counts);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);   // (hbs has been copied; also keeps `bounds` alive until its copy is done)
+        (void)KNN_DEV_FREE(bucket_counts);
+    } else {
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(knn_cells_code_kernel, dim3(blocks), dim3(256), 0, s, r, n, g, c->bounds, code, counts);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);   // (also keeps `bounds` alive until its copy is done)
+    }
     bool keep = e == hipSuccess;
     long long tiles = 0;
     if (keep) {
@@ -1617,9 +1959,14 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
     FTRY(hipMemsetAsync(st.ref_frags, 0, (size_t)st.ntiles * 64 * 16, s));
     FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms, 0x7F800000, (size_t)rows_padded, s));
     FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms2, 0x00007C00, (size_t)rows_padded, s));
-    hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
-                       st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,
-                       st.cells->perm, out, st.outliers, ocap);
+    if (st.cells->tmp_rows)
+        hipLaunchKernelGGL(knn_cells_place_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, st.cells->tmp_rows,
+                           st.cells->tmp_meta, st.cells->bucket_start, st.k, st.cells->bits - 8, st.cells->tile_start, fill, st.center, st.sigma,
+                           (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, out, st.outliers, ocap);
+    else
+        hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
+                           st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,
+                           st.cells->perm, out, st.outliers, ocap);
     return hipGetLastError();
 }
 

@@ -132,6 +132,11 @@ struct CellIndex {
     // quantile cuts do not spread) has several, all scored against the same list
     unsigned long long *items = nullptr;
     unsigned nitems = 0;
+    // build only (freed once the rows are placed): the shard's rows grouped by the top 8 bits of their cell code — 256
+    // buckets of consecutive cells — as 64-byte records + (code << 32 | row); null: the one-pass placement is used
+    float *tmp_rows = nullptr;
+    unsigned long long *tmp_meta = nullptr;
+    unsigned *bucket_start = nullptr;   // device [257]: first record of each bucket
 };
 
 struct FilterState {

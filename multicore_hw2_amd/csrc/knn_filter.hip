@@ -1447,6 +1447,14 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     lap("fragment kernel + sync");
     (void)KNN_DEV_FREE(cell_code);
     (void)KNN_DEV_FREE(cell_fill);
+    if (st.cells) {   // the two-pass build's scratch (the stream has been synchronised: the placement kernel is done)
+        (void)KNN_DEV_FREE(st.cells->tmp_rows);
+        (void)KNN_DEV_FREE(st.cells->tmp_meta);
+        (void)KNN_DEV_FREE(st.cells->bucket_start);
+        st.cells->tmp_rows = nullptr;
+        st.cells->tmp_meta = nullptr;
+        st.cells->bucket_start = nullptr;
+    }
     (void)KNN_DEV_FREE(dout);
     if (e != hipSuccess) {
         knn_filter_free(st);
