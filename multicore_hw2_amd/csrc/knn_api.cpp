@@ -74,6 +74,7 @@ std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pru
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
 std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
 std::atomic<long long> g_graph_replays{0};       // batches answered by hipGraphLaunch (tests)
+std::atomic<long long> g_opt_cells_build{0};     // cell-sorted layout: 0 two-pass build, 1 the one-pass placement (A/B, tests)
 std::atomic<long long> g_opt_graphs{0};          // cell-pruned path: replay a batch's launches as a hipGraph when a call repeats the previous one's arguments
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
@@ -361,6 +362,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_scan_blocks = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "cells_build")) {
+        if (value < 0 || value > 1)
+            return fail(KNN_EINVAL, "knn_set_option: cells_build must be 0 (two-pass) or 1 (one-pass placement)");
+        g_opt_cells_build = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "graphs")) {
         if (value < 0 || value > 1)
             return fail(KNN_EINVAL, "knn_set_option: graphs must be 0 or 1");
@@ -434,6 +441,8 @@ long long knn_get_option(const char *name)
         return g_opt_scan_deal;
     if (name && !strcmp(name, "graphs"))
         return g_opt_graphs;
+    if (name && !strcmp(name, "cells_build"))
+        return g_opt_cells_build;
     if (name && !strcmp(name, "graph_replays"))
         return g_graph_replays;
     if (name && !strcmp(name, "deepk"))
@@ -560,7 +569,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
             want_layouts = false;
     }
     if (want_layouts && !layouts_done) {
-        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s, want_cells ? 1 : 0);
+        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s, want_cells ? (g_opt_cells_build == 1 ? 2 : 1) : 0);
         if (e == hipErrorOutOfMemory) {
             // no room for the fp16 layouts beside the rows: the index still works, exact kernels only
             (void)hipGetLastError();

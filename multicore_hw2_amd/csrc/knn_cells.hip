@@ -1751,7 +1751,7 @@ void knn_cells_free(CellIndex *&c)
 // of the build (samples x k).  Synchronous.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                           unsigned **fill_out)
+                           unsigned **fill_out, bool one_pass)
 {
     *out = nullptr;
     *code_out = nullptr;
@@ -1823,9 +1823,9 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     if (e == hipSuccess)
         e = hipMemsetAsync(counts, 0, hcounts.size() * sizeof(unsigned), s);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    // Two-pass build (see the kernels): needs n x 72 bytes of scratch; without it (or with KNN_MI355X_BUILD_ONE_PASS set, for
-    // A/B timing) the one-pass placement serves.
-    static const bool one_pass_env = getenv("KNN_MI355X_BUILD_ONE_PASS") != nullptr;
+    // Two-pass build (see the kernels): needs n x 72 bytes of scratch; without it (or with option `cells_build` = 1, for A/B
+    // timing and tests) the one-pass placement serves.
+    const bool one_pass_env = one_pass;
     const int bshift = bits - 8;   // bits >= 9: a bucket = 2^bshift consecutive cells
     const unsigned bblocks = (unsigned)((n + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS);
     unsigned *bucket_counts = nullptr, *bucket_fill = nullptr;

@@ -181,7 +181,7 @@ struct FilterState {
 // shard does not suit; else *code_out / *fill_out (device; the caller frees them) feed knn_cells_place_rows.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r_dev, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                           unsigned **fill_out);
+                           unsigned **fill_out, bool one_pass = false);
 #endif
 hipError_t knn_cells_place_rows(FilterState &st, const float *r_dev, const unsigned *code, unsigned *fill, unsigned *out,
                                 unsigned ocap, hipStream_t s);

@@ -1397,7 +1397,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     // 1c. cell-sorted layout (k <= 16, resident indexes): ntiles becomes the padded tile count
     unsigned *cell_code = nullptr, *cell_fill = nullptr;
     if (want_cells && kt == 1) {
-        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles, &cell_code, &cell_fill));
+        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples_used, s, &ntiles, &cell_code, &cell_fill, want_cells == 2));
         lap(st.cells ? "cell codes + counts" : "cell codes (not kept)");
     }
 

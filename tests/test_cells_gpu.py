@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells", "cells_variant", "scan_deal", "graphs"):
+    for name in ("path", "shards", "cells", "cells_variant", "scan_deal", "graphs", "cells_build"):
         pkg.set_option(name, 0)
 
 
@@ -462,3 +462,24 @@ def test_graph_replay_of_a_batch_answers_like_the_launches_it_recorded(oracle, s
     finally:
         pkg.set_option("cells", 0)
         pkg.set_option("graphs", 0)
+
+
+@pytest.mark.parametrize("k,dist,n", [(16, "uniform", (1 << 18) + 77), (5, "clustered", 1 << 17), (12, "queries_outside", (1 << 17) + 4097),
+                                      (16, "tight_clusters", 1 << 19)])
+def test_one_pass_placement_still_builds_a_correct_layout(oracle, k, dist, n):
+    """`cells_build` 1: the build the two-pass one falls back to when its scratch (n x 72 bytes) does not fit."""
+    m = 500
+    rng = np.random.default_rng(k + len(dist))
+    Q, R = _off_the_cube(rng, dist, k, m, n) if dist == "tight_clusters" else _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("cells_build", 1)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("cells_build", 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"{dist} k={k} stats={st}")
+    assert st[0] == 4, st
