@@ -75,6 +75,15 @@ def test_option_hooks_reject_unknown_names():
         assert pkg.get_option("cells") == v
     with pytest.raises(pkg.KnnError):
         pkg.set_option("cells", 3)
+    # round 3's switches: every legal value round-trips, the first illegal one is refused
+    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_variant", (1, 2, 3, 0)),
+                        ("graphs", (1, 0)), ("cells_build", (1, 0)), ("deepk", (1, 2, 3, 4, 0))):
+        for v in legal:
+            pkg.set_option(name, v)
+            assert pkg.get_option(name) == v, name
+        with pytest.raises(pkg.KnnError):
+            pkg.set_option(name, max(legal) + 1)
+    assert pkg.get_option("graph_replays") >= 0
 
 
 def test_product_does_not_link_or_reference_the_oracle():
