@@ -131,6 +131,8 @@ def main():
     # with four batch streams plus the default stream two of them then share a queue and serialise (4 in flight: 0.053 ms
     # per step at n_local 2^21 against 0.044 for 3).  Eight queues: 4 in flight 0.042.  Must be set before HIP starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (ranks started by an outside torchrun: the host driver only supports dmabuf IPC, RCCL fails without this)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     if args.selftest_launcher:
