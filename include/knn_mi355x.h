@@ -194,8 +194,8 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             time, 1 once a workspace slot other than 0 has been used (batches in flight fill each other's gaps; the
  *             fixed deal's cheaper prologue then gives the shorter step)
  *   "cells_build" how the cell-sorted layout is built: 0 = two passes (rows grouped into 256 buckets of consecutive cells, then
- *             placed bucket by bucket out of one XCD's L2: 3.4 ms for 2^24 rows of 16 floats; needs n x 72 bytes of scratch and
- *             falls back when that does not fit), 1 = the one-pass placement (4.7 ms).  Read when an index is created
+ *             placed bucket by bucket out of one XCD's L2: 3.4 ms for 2^24 rows of 16 floats; needs n x 72 bytes of scratch: used for
+ *             shards of up to 2^25 rows, and falls back when the scratch does not fit), 1 = the one-pass placement (4.7 ms).  Read when an index is created
  *   "graphs"  1 = on the cell-pruned path (batches of up to 1024 queries, a non-null stream) the second call that repeats the
  *             previous call's arguments on a slot records the batch's launches as a hipGraph from the caller's stream, and
  *             later ones replay it with one hipGraphLaunch (knn_get_option("graph_replays") counts them).  0 = plain

@@ -1829,7 +1829,10 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     const int bshift = bits - 8;   // bits >= 9: a bucket = 2^bshift consecutive cells
     const unsigned bblocks = (unsigned)((n + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS);
     unsigned *bucket_counts = nullptr, *bucket_fill = nullptr;
-    bool two_pass = e == hipSuccess && !one_pass_env;
+    // (shards of up to 2^25 rows: beyond, the scratch is gigabytes that the buffer pool does not keep between builds, and one
+    // hipMalloc / hipFree pair of that size in eight took 2.2 SECONDS on a 2^27-row shard — tools/build_repeat.py: 30 20 19 19
+    // 19 19 2208 21 ms — where the one-pass placement's 33 ms are steady)
+    bool two_pass = e == hipSuccess && !one_pass_env && (size_t)n * 64 <= ((size_t)2 << 30);
     if (two_pass) {
         hipError_t a = KNN_DEV_ALLOC((void **)&c->tmp_rows, (size_t)n * 16 * sizeof(float));
         if (a == hipSuccess)
