@@ -790,6 +790,21 @@ int knn_index_timing(knn_index *idx, int enable)
     idx->timing = enable > 0 ? enable : 0;
     idx->timing_seq = 0;
     idx->events_used = 0;
+    if (enable > 0) {
+        // The event pairs are made HERE, not at the launches they bracket: the first bracketed launch of a run used to create
+        // its pair on the spot — 0.2-0.3 ms of hipEventCreate inside the caller's timed region (a 20-step bench run read 0.141 ms
+        // per step where the same 20 batches take 0.126 without the instrumentation; tools/fill_drain.py).
+        DeviceGuard guard(idx->device);
+        while (idx->events.size() < 64) {
+            std::pair<hipEvent_t, hipEvent_t> fresh;
+            HIP_TRY(hipEventCreate(&fresh.first));
+            if (hipEventCreate(&fresh.second) != hipSuccess) {
+                (void)hipEventDestroy(fresh.first);
+                return fail(KNN_EHIP, "knn_index_timing: hipEventCreate failed");
+            }
+            idx->events.push_back(fresh);
+        }
+    }
     return KNN_OK;
 }
 
