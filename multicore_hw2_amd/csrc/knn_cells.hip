@@ -2246,7 +2246,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // flight on several slots the next batch's kernels fill the gaps early finishers leave, and the fixed deal's cheaper prologue
     // and moving window win: the step is 1-4 % SHORTER with it (0.0415 / 0.0549 / 0.0794 / 0.1233 against 0.0425 / 0.0568 /
     // 0.0831 / 0.1249) — so that is what pipelined callers get.
-    const bool dyn = st.scan_deal == 2 || (st.scan_deal == 0 && !st.several_slots);
+    // (below two items per wave the counter has nothing to even out: 2^21 rows, one batch at a time, 0.0786 ms fixed / 0.0800 counter)
+    const bool dyn = st.scan_deal == 2 || (st.scan_deal == 0 && !st.several_slots && c.nitems >= 2u * w.nlists);
     if (variant == 2)
         hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
                            st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
