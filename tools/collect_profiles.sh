@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_j/ — a fresh directory: gpurun MERGES into
+# Round-end evidence run on the GPU box (everything lands under gpurun_out/r03_final_k/ — a fresh directory: gpurun MERGES into
 # gpurun_out/, and an earlier collection's files would mix with this one's; tools/pmc_traffic.py and the
 # copy into profiles/ happen afterwards in the build container).  usage: gpurun -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03_final_j
+O=$R/gpurun_out/r03_final_k
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
