@@ -52,11 +52,7 @@ def parse_args():
     ap.add_argument("--filter-chain", type=int, default=0, help="0 auto, 1 scans of different slots chained, 2 free")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every N-th launch of the dominant kernel with HIP events (roofline.kernel_avg_ms)")
-    ap.add_argument("--deepk", type=int, default=0, help="A/B: deep-K LDS-tiled scan, 0 = auto, 1 = 8 waves per block, 2 / 4 = tiles per barrier (LDS-DMA), 3 = round-2 kernel")
     ap.add_argument("--cells", type=int, default=0, help="A/B: cell-sorted layouts, 0 = library policy, 1 = always (k <= 16), 2 = never")
-    ap.add_argument("--cells-variant", type=int, default=0,
-                    help="A/B: kernels of the cell-pruned path, 0 = prep + match + scan, 1 = the round-2 chain, 2 = as 0 with MFMA norms, "
-                         "3 = prep + sweep (one persistent kernel)")
     ap.add_argument("--separate-init", action="store_true",
                     help="A/B: start the keys with a knn_keys_init launch per step instead of KNN_QUERY_INIT_KEYS")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -188,12 +184,8 @@ def main():
         pkg.set_option("filter_rounds", args.filter_rounds)
     if args.filter_chain:
         pkg.set_option("filter_chain", args.filter_chain)
-    if args.deepk:
-        pkg.set_option("deepk", args.deepk)
     if args.cells:
         pkg.set_option("cells", args.cells)
-    if args.cells_variant:
-        pkg.set_option("cells_variant", args.cells_variant)
 
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)
@@ -429,10 +421,7 @@ def main():
             # 32 B of fragment + 4 B of norm per position, cells padded to whole tiles (~4 %)
             phys = 36.0 * n_local * 1.04
             roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
-                    "kernel": {0: "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",
-                               1: "knn_cells_scan (behind the round-2 chain: fragments, seed, match)",
-                               2: "knn_cells_scan (norm tile out of an extra MFMA)",
-                               3: "knn_cells_sweep (match + scan + re-rank in one persistent kernel)"}[args.cells_variant],
+                    "kernel": "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",
                     "bytes_per_launch": phys, "bytes_source": "layout size (36 B per position, 4 % padding)"}
         else:
             roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
@@ -456,7 +445,7 @@ def main():
                 pmc_doc = json.load(f)
             if pmc_doc.get("kernel_source_sha256") == kernel_source_sha():
                 kname = {2: ("_Z17knn_filter", "void knn_filter_kernel"),
-                         4: ("_Z22knn_cells_sweep", "void knn_cells_sweep_kernel", "_Z21knn_cells_scan", "void knn_cells_scan_kernel")
+                         4: ("_Z21knn_cells_scan", "void knn_cells_scan_kernel")
                          }.get(path_taken, ("void knn_exact_qreg<16, 2>",))
                 best = None
                 for name, ent in pmc_doc["kernels"].items():
@@ -531,7 +520,6 @@ def main():
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "index_prep_first_in_process_ms": prep_first_ms,
                        "batches_in_flight": nstreams, "setup_steps": setup_steps,
-                       "cells_variant": args.cells_variant if path_taken == 4 else None,
                        "keys_init": "separate launch" if args.separate_init else "inside the query (KNN_QUERY_INIT_KEYS)",
                        "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %
                                       ("gloo (one-GPU rehearsal)" if rehearse else "rccl", nbuf, m, nbuf))

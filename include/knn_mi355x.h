@@ -154,11 +154,6 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
  *             with the exact kernels: 0 = when the cost model says so, 1 = never, 2 = always
  *             (shards of at least 64 MiB)
- *   "deepk"   tuning / A-B: the LDS-tiled filter scan for 32 < k <= 128 with >= 512 queries (128 < k <= 512 always run its
- *             one-tile-per-barrier form with 2 / 1 blocks of queries per wave, 512 < k <= 4096 the chunked-K kernel): 0 = auto (4 waves x 4
- *             query tiles share every staged reference tile; for k > 64 four reference tiles are staged per barrier by
- *             LDS-DMA), 1 = 8 waves per block, 2 / 4 = that many reference tiles per barrier, 3 = one tile per
- *             barrier through registers (the round-2 kernel)
  *   "ingest"  indexes created from HOST rows (knn_index_create with refs_on_device = 0, and the
  *             staged-filter case of cudaCallback): 0 = the rows go over in chunks and every chunk's
  *             MFMA layouts are built as soon as it has landed (robust box from a strided host
@@ -181,10 +176,6 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             record buffers (rows of a cluster tighter than the fp16 step) by the exact arithmetic over its
  *             listed (cell, query) pairs only; the next batch is back on the pruned path.  Results are
  *             bit-exact either way
- *   "cells_variant" A/B of the pruned path's kernels: 0 = prep (one block per query: fragments, seed scores,
- *             thresholds, pruning tables, keys) + match + scan; 1 = the round-2 chain (query fragments, seed, match,
- *             scan); 2 = as 0 with the scan's norm tile out of an extra MFMA instead of LDS; 3 = prep + sweep
- *             (match, scan and exact re-rank in one persistent kernel; an experiment, slower than 0)
  *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^15 cells once a query has
  *             used a workspace slot other than 0 — batches in flight side by side: the scan alone gets 10-20 % longer and
  *             the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
@@ -197,11 +188,6 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "cells_build" how the cell-sorted layout is built: 0 = two passes (rows grouped into 256 buckets of consecutive cells, then
  *             placed bucket by bucket out of one XCD's L2: 3.4 ms for 2^24 rows of 16 floats; needs n x 72 bytes of scratch: used for
  *             shards of up to 2^25 rows, and falls back when the scratch does not fit), 1 = the one-pass placement (4.7 ms).  Read when an index is created
- *   "graphs"  1 = on the cell-pruned path (batches of up to 1024 queries, a non-null stream) the second call that repeats the
- *             previous call's arguments on a slot records the batch's launches as a hipGraph from the caller's stream, and
- *             later ones replay it with one hipGraphLaunch (knn_get_option("graph_replays") counts them).  0 = plain
- *             launches (default: measured on ROCm 7.2 the replay is SLOWER than the six launches it replaces — one batch at
- *             a time 0.078 -> 0.085 ms at 2^21 rows, 0.160 -> 0.167 at C3; equal with batches in flight)
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

@@ -69,13 +69,9 @@ std::atomic<long long> g_opt_filter_qt{0};
 std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
-std::atomic<long long> g_opt_deepk{0};
-std::atomic<long long> g_opt_cells_variant{0};   // A/B: kernels of the cell-pruned path (knn_cells_query)
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
 std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
-std::atomic<long long> g_graph_replays{0};       // batches answered by hipGraphLaunch (tests)
 std::atomic<long long> g_opt_cells_build{0};     // cell-sorted layout: 0 two-pass build, 1 the one-pass placement (A/B, tests)
-std::atomic<long long> g_opt_graphs{0};          // cell-pruned path: replay a batch's launches as a hipGraph when a call repeats the previous one's arguments
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
@@ -266,17 +262,6 @@ struct knn_index {
     // work of different slots still overlaps): the workspaces' lazily grown buffers, the event list, the statistics and
     // the chain events are plain members.  Recursive: knn_index_query_host calls the keyed entry points.
     std::recursive_mutex mu;
-    // Option `graphs`: the launches of one batch on the cell-pruned path (prep, match, scan, re-rank, the two gated
-    // fallbacks), captured from the caller's stream the second time a call repeats the previous call's arguments on a slot
-    // and replayed with ONE hipGraphLaunch from then on.  Two graphs per slot: the control words alternate between two
-    // blocks from batch to batch (knn_cells_query), and a graph has its block baked in.
-    struct GraphCache {
-        hipGraphExec_t exec[2] = {nullptr, nullptr};
-        int m = -1;
-        const float *q = nullptr;
-        const void *keys = nullptr;
-        long long opts = -1;   // init flag, kernel variants, several_slots: what else the launches have baked in
-    } graphs[KNN_SLOTS];
 };
 
 extern "C" {
@@ -350,12 +335,6 @@ int knn_set_option(const char *name, long long value)
         g_opt_stream = value;
         return KNN_OK;
     }
-    if (!strcmp(name, "deepk")) {
-        if (value < 0 || value > 4)
-            return fail(KNN_EINVAL, "knn_set_option: deepk must be 0 (auto), 1 (8 waves per block), 2 or 4 (tiles per barrier, LDS-DMA) or 3 (one tile per barrier)");
-        g_opt_deepk = value;
-        return KNN_OK;
-    }
     if (!strcmp(name, "scan_blocks")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: scan_blocks must be 0 (auto), 1 or 2");
@@ -368,22 +347,10 @@ int knn_set_option(const char *name, long long value)
         g_opt_cells_build = value;
         return KNN_OK;
     }
-    if (!strcmp(name, "graphs")) {
-        if (value < 0 || value > 1)
-            return fail(KNN_EINVAL, "knn_set_option: graphs must be 0 or 1");
-        g_opt_graphs = value;
-        return KNN_OK;
-    }
     if (!strcmp(name, "scan_deal")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: scan_deal must be 0 (auto), 1 (fixed deal) or 2 (block counter)");
         g_opt_scan_deal = value;
-        return KNN_OK;
-    }
-    if (!strcmp(name, "cells_variant")) {
-        if (value < 0 || value > 3)
-            return fail(KNN_EINVAL, "knn_set_option: cells_variant must be 0 .. 3");
-        g_opt_cells_variant = value;
         return KNN_OK;
     }
     if (!strcmp(name, "cells")) {
@@ -433,20 +400,12 @@ long long knn_get_option(const char *name)
         return g_opt_ingest;
     if (name && !strcmp(name, "cells"))
         return g_opt_cells;
-    if (name && !strcmp(name, "cells_variant"))
-        return g_opt_cells_variant;
     if (name && !strcmp(name, "scan_blocks"))
         return g_opt_scan_blocks;
     if (name && !strcmp(name, "scan_deal"))
         return g_opt_scan_deal;
-    if (name && !strcmp(name, "graphs"))
-        return g_opt_graphs;
     if (name && !strcmp(name, "cells_build"))
         return g_opt_cells_build;
-    if (name && !strcmp(name, "graph_replays"))
-        return g_graph_replays;
-    if (name && !strcmp(name, "deepk"))
-        return g_opt_deepk;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
         return g_rccl_reductions;
     if (name && !strcmp(name, "rccl_version"))      // read-only: NCCL_VERSION_CODE of the loaded RCCL, 0 if none
@@ -606,10 +565,6 @@ void knn_index_destroy(knn_index *idx)
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
-        for (auto &gc : idx->graphs)
-            for (auto &e : gc.exec)
-                if (e)
-                    (void)hipGraphExecDestroy(e);
     }
     delete idx;
 }
@@ -697,9 +652,7 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         idx->filter.force_qt = (int)g_opt_filter_qt;
         idx->filter.force_rounds = (int)g_opt_filter_rounds;
         idx->filter.chain_policy = (int)g_opt_filter_chain;
-        idx->filter.deepk_variant = (int)g_opt_deepk;
         idx->filter.cells_policy = (int)g_opt_cells;
-        idx->filter.cells_variant = (int)g_opt_cells_variant;
         // batches in flight on several workspace slots = a caller after throughput: the pruned scan of a small shard then
         // takes ONE block per CU, so that the next batch's preparation kernels find registers beside it (knn_cells_query)
         if (slot != 0)
@@ -707,52 +660,6 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         idx->filter.scan_blocks = (int)g_opt_scan_blocks;
         idx->filter.scan_deal = (int)g_opt_scan_deal;
         idx->last_slot = slot;
-        FilterState &fs = idx->filter;
-        const bool graph_ok = g_opt_graphs != 0 && !ev && s != nullptr && fs.cells && fs.cells_policy != 2 && fs.kt == 1 &&
-                              m <= KNN_CELL_BATCH && (fs.cells_variant == 0 || fs.cells_variant == 2);
-        if (graph_ok) {
-            knn_index::GraphCache &gc = idx->graphs[slot];
-            FilterWorkspace &w = fs.ws[slot];
-            const long long opts = (init_keys ? 1 : 0) | (fs.cells_variant << 1) | (fs.scan_blocks << 4) | (fs.scan_deal << 7) |
-                                   (fs.several_slots ? 1 << 10 : 0);
-            if (gc.m == m && gc.q == queries_dev && gc.keys == (const void *)keys_dev && gc.opts == opts) {
-                const unsigned parity = w.cell_batches & 1u;
-                if (!gc.exec[parity]) {
-                    // second (third) call with these arguments: record this batch's launches instead of issuing them.  The
-                    // first call ran the ordinary way, so every buffer the launches name exists already.
-                    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                    const hipError_t qe = knn_filter_query(fs, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
-                                                           idx->num_cu, s, nullptr, nullptr, init_keys);
-                    hipGraph_t graph = nullptr;
-                    const hipError_t ce = hipStreamEndCapture(s, &graph);
-                    hipError_t ie = hipSuccess;
-                    if (qe == hipSuccess && ce == hipSuccess && graph)
-                        ie = hipGraphInstantiate(&gc.exec[parity], graph, nullptr, nullptr, 0);
-                    if (graph)
-                        (void)hipGraphDestroy(graph);
-                    HIP_TRY(qe);
-                    HIP_TRY(ce);
-                    HIP_TRY(ie);
-                } else {
-                    ++w.cell_batches;   // what knn_cells_query does on the host for a batch
-                    w.ctl_cur = w.ctl + KNN_CTL_WORDS * (1u + parity);
-                    w.last_used_cells = true;
-                }
-                HIP_TRY(hipGraphLaunch(gc.exec[parity], s));
-                ++g_graph_replays;
-                idx->stats[0] = 4;
-                return KNN_OK;
-            }
-            for (auto &e : gc.exec)
-                if (e) {
-                    (void)hipGraphExecDestroy(e);
-                    e = nullptr;
-                }
-            gc.m = m;
-            gc.q = queries_dev;
-            gc.keys = (const void *)keys_dev;
-            gc.opts = opts;
-        }
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys));
         if (idx->filter.ws[slot].last_used_cells)
@@ -844,8 +751,8 @@ int knn_index_last_stats(knn_index *idx, long long stats[4])
         long long records = 0;
         for (unsigned c : counts)
             records += c < w.slice ? c : w.slice;
-        if (idx->stats[0] == 4)   // + the shared overflow area (variant 3: the sweep re-ranks its hits itself and counts them here)
-            records += w.nlists == 0 ? ctl[KNN_CTL_RECORDS] : (ctl[KNN_CTL_RECORDS] < w.ovf_cap ? ctl[KNN_CTL_RECORDS] : w.ovf_cap);
+        if (idx->stats[0] == 4)   // + the shared overflow area
+            records += ctl[KNN_CTL_RECORDS] < w.ovf_cap ? ctl[KNN_CTL_RECORDS] : w.ovf_cap;
         idx->stats[1] = records;
         idx->stats[2] = ctl[KNN_CTL_FALLBACK] ? 1 : ctl[KNN_CTL_EXACT_CELLS] ? 2 : 0;   // 2: the batch's listed (cell, query) pairs were evaluated exactly
         idx->stats[3] = idx->filter.n_outliers;

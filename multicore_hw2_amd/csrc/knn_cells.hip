@@ -40,11 +40,8 @@
 //             with the exact arithmetic — the geometry's verdict stands, it never depended on fp16; a query nothing bounds
 //             (not finite, far away, no real row seen) -> the exact scan of the whole shard.  Nothing switches the cells off
 //             for later batches.
-// A/B arms kept selectable with their parity tests (`cells_variant`): 1 = the round-2 chain (query fragments, seed, match,
-// scan); 2 = the scan's C tile (reference norms) out of one extra MFMA on norms kept as two fp16 halves (ref_norms2:
-// N ~ hi + mid 2^-11, exact to 2^-22 N, folded into rho) instead of four broadcast ds_read_b128; 3 = prep + "sweep": match,
-// scan and exact re-rank fused into one persistent kernel with the lists in LDS.  2 and 3 lose to the lean scan at every
-// size (profiles/r03_sweep_experiments.txt): registers per wave are what the path is short of.
+// (The round-2 chain, the scan with its norm tile out of an extra MFMA and the fused match + scan + re-rank kernel of round 3
+// all lost their A/B against this chain and live on as records under tools/arms/ and profiles/r03_sweep_experiments.txt.)
 // Uniform data in 16 dimensions, n = 2^24: ~1600 of 65536 cells survive per query, 25 queries per cell.
 // ------------------------------------------------------------------------------------------
 #define CELL_MAX_BINS 16
@@ -473,218 +470,6 @@ __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
     return min3f(m5, m6, seed);
 }
 
-// One block per query.  umin[q] = minimum score over the seed cells; lo_tab[q][e] / hi_tab[e][q] = the
-// separable halves of the cell lower bound (scaled units, rounded down).
-__global__ __launch_bounds__(256) void knn_cells_seed_kernel(
-    const float *__restrict__ Q, int m, CellGeom g, const float *__restrict__ bounds, double sigma2,
-    const unsigned *__restrict__ tile_start, const h8 *__restrict__ rf, const float *__restrict__ rn,
-    const h8 *__restrict__ qfg, float *__restrict__ lo_tab, float *__restrict__ hi_tab, int m_padded,
-    // thresholds (what knn_thr_kernel does for the full scan, here per block = per query)
-    const float *__restrict__ qnorm, const float *__restrict__ qamax, const unsigned *__restrict__ qpart, int qblocks,
-    int kt, float sigma, float bmax, float nmax, float amax_limit, float *__restrict__ thr, float *__restrict__ dup_out,
-    unsigned *__restrict__ ctl, unsigned *__restrict__ counts, unsigned nlists)
-{
-    __shared__ float s_gap[16][CELL_MAX_BINS];
-    __shared__ f4v s_nrm[4][CELL_TILES_PER_PASS * 8];
-    __shared__ unsigned s_tb[CELL_SEEDS];
-    __shared__ unsigned s_tiles[CELL_SEEDS];
-    __shared__ float s_red[4];
-    const int qi = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {
-        const int d = tid >> 4, b = tid & 15;
-        float v = 0.0f;
-        if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
-            const int nbins = 1 << g.nb[d];
-            const float *__restrict__ bnd = bounds + d * (CELL_MAX_BINS - 1);
-            const double q = (double)Q[(size_t)qi * g.k + d];
-            double gap = 0.0;
-            if (b > 0 && (double)bnd[b - 1] > q)
-                gap = (double)bnd[b - 1] - q;        // rows of the bin have x >= bnd[b-1] > q
-            if (b < nbins - 1 && q > (double)bnd[b])
-                gap = q - (double)bnd[b];            // rows of the bin have x < bnd[b] < q
-            v = __double2float_rd(gap * gap * sigma2);
-        }
-        s_gap[d][b] = v;
-    }
-    // loads nothing below depends on, issued first: this query's B operand, and (thread 0) what the threshold needs
-    const h8 bq = qfg[(size_t)(qi >> 5) * 64 + (lane >> 5) * 32 + (qi & 31)];  // every column = this query
-    float pre_amax = 0.0f, pre_qnorm = 0.0f, pre_qamax = 0.0f;
-    unsigned pre_qbad = 0u;
-    if (tid == 0) {
-        for (int bq2 = 0; bq2 < qblocks; ++bq2) {  // per-block partials of the query fragment kernel
-            pre_amax = fmaxf(pre_amax, __uint_as_float(qpart[3 * bq2]));
-            pre_qbad |= qpart[3 * bq2 + 2];
-        }
-        pre_qnorm = qnorm[qi];
-        pre_qamax = qamax[qi];
-    }
-    if (wib == 0) {
-        // wave 0, dimensions on the lanes: the query's own bin, and the neighbouring bin nearest to it
-        unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
-        float ag = INFINITY;
-        if (lane < g.k) {
-            nbl = g.nb[lane];
-            shl = g.shift[lane];
-        }
-        if (nbl) {
-            const int nbins = 1 << nbl;
-            const float *__restrict__ bnd = bounds + lane * (CELL_MAX_BINS - 1);
-            const float q = Q[(size_t)qi * g.k + lane];
-            bin = cell_bin(bnd, nbins, q);
-            if (bin > 0u) {
-                alt = bin - 1u;
-                ag = q - bnd[bin - 1];
-            }
-            if (bin + 1u < (unsigned)nbins && !(bnd[bin] - q >= ag)) {
-                alt = bin + 1u;
-                ag = bnd[bin] - q;
-            }
-            if (!(ag >= 0.0f))
-                ag = 0.0f;
-        }
-        unsigned own = bin << shl;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-            own |= (unsigned)__shfl_xor((int)own, off, KNN_WAVE);
-        own = (unsigned)__shfl((int)own, 0, KNN_WAVE);
-        // the CELL_SEED_DIMS dimensions whose next bin is nearest: arg-min over the lanes, twice
-        int pick[CELL_SEED_DIMS];
-        u64 key = alt != 0xFFFFFFFFu ? ((u64)__float_as_uint(ag) << 32) | (u64)lane : ~0ull;
-#pragma unroll
-        for (int j = 0; j < CELL_SEED_DIMS; ++j) {
-            u64 best = key;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const u64 o = __shfl_xor(best, off, KNN_WAVE);
-                best = o < best ? o : best;
-            }
-            pick[j] = best == ~0ull ? -1 : (int)(best & 0xFFFFFFFFull);
-            if (lane == pick[j])
-                key = ~0ull;
-        }
-        // seed cell c (on lane c): the own cell with the picked dimensions moved to their neighbouring bin
-        unsigned code = own;
-        bool ok = lane < CELL_SEEDS;
-#pragma unroll
-        for (int j = 0; j < CELL_SEED_DIMS; ++j) {
-            const int pj = pick[j] < 0 ? 0 : pick[j];
-            const unsigned pa = (unsigned)__shfl((int)alt, pj, KNN_WAVE), pn = (unsigned)__shfl((int)nbl, pj, KNN_WAVE),
-                           ps = (unsigned)__shfl((int)shl, pj, KNN_WAVE);
-            if ((lane >> j) & 1) {
-                if (pick[j] < 0)
-                    ok = false;
-                else
-                    code = (code & ~(((1u << pn) - 1u) << ps)) | (pa << ps);
-            }
-        }
-        if (lane < CELL_SEEDS) {
-            const unsigned tb = tile_start[code];
-            s_tb[lane] = tb;
-            s_tiles[lane] = ok ? tile_start[code + 1] - tb : 0u;   // tiles of seed cell `lane`
-        }
-    }
-    __syncthreads();
-    // the tables (independent of the seed cells): double sums of the rounded-down gaps, rounded down again
-    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);
-    for (int e = tid; e < nl + nh; e += 256) {
-        const bool low = e < nl;
-        const unsigned code = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
-        double sum = 0.0;
-        for (int d = 0; d < g.k; ++d)
-            if (g.nb[d] && ((int)g.shift[d] < g.sa) == low)
-                sum += (double)s_gap[d][(code >> g.shift[d]) & ((1u << g.nb[d]) - 1u)];
-        const float v = __double2float_rd(sum);
-        if (low)
-            lo_tab[(size_t)qi * nl + e] = v;
-        else
-            hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
-    }
-    __syncthreads();
-    // housekeeping folded in here to save a launch: zero the record counters of the scan
-    for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < nlists; i += gridDim.x * 256u)
-        counts[i] = 0u;
-    // one seed cell per wave, all its tiles in flight at once (like the scan: one round trip)
-    float um = INFINITY;
-    for (int ci = wib; ci < CELL_SEEDS; ci += 4) {
-        const unsigned ntile = s_tiles[ci], tb = s_tb[ci];
-        for (unsigned t0 = 0u; t0 < ntile; t0 += CELL_TILES_PER_PASS) {
-            const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, ntile - t0);
-            h8 ar[CELL_TILES_PER_PASS];
-#pragma unroll
-            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                if (p < nt)
-                    ar[p] = rf[(size_t)(tb + t0 + (unsigned)p) * 64 + lane];
-            const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)(tb + t0) * 8;
-            const f4v n0 = lane < nt * 8 ? rn4[lane] : (f4v){0.f, 0.f, 0.f, 0.f};
-            const f4v n1 = 64 + lane < nt * 8 ? rn4[64 + lane] : (f4v){0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_wave_barrier();
-            s_nrm[wib][lane] = n0;
-            if (lane < CELL_TILES_PER_PASS * 8 - 64)
-                s_nrm[wib][64 + lane] = n1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                if (p < nt) {
-                    f16v c;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const f4v v = s_nrm[wib][p * 8 + 2 * gq + (lane >> 5)];
-                        c[4 * gq + 0] = v[0];
-                        c[4 * gq + 1] = v[1];
-                        c[4 * gq + 2] = v[2];
-                        c[4 * gq + 3] = v[3];
-                    }
-                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], bq, c, 0, 0, 0);
-                    um = min_tree16(d, um);
-                }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
-    if (lane == 0)
-        s_red[wib] = um;
-    __syncthreads();
-    if (tid == 0) {
-        const float u = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-        const float amax = pre_amax;
-        const unsigned qbad = pre_qbad;
-        if (qi == 0) {
-            ctl[KNN_CTL_AMAX] = __float_as_uint(amax);
-            ctl[KNN_CTL_QBAD] = qbad;
-            for (int i = m; i < m_padded; ++i) {   // padding queries never pass
-                thr[i] = -INFINITY;
-                dup_out[i] = -INFINITY;
-            }
-        }
-        bool bad = qbad != 0u || !(amax <= amax_limit);
-        float t = -INFINITY, dupf = -INFINITY;
-        if (!bad && !(u < INFINITY))
-            bad = true;        // the seed cells held no row of the filter: cannot bound
-        if (!bad) {
-            const BoundConsts cst = knn_bound_consts(g.k, kt, sigma, pre_qamax, bmax, nmax);
-            double dup = 0.0;
-            t = knn_threshold(cst, u, pre_qnorm, &dup);
-            if (!(t < INFINITY))
-                bad = true;
-            else {
-                dup *= 1.0 + 1e-6;
-                dupf = (float)dup;
-                if ((double)dupf < dup)
-                    dupf = nextafterf(dupf, INFINITY);
-            }
-        }
-        thr[qi] = bad ? -INFINITY : t;
-        dup_out[qi] = bad ? -INFINITY : dupf;
-        if (bad)
-            ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
-    }
-}
-
 // Cell-major matching: a block of 8 waves owns cells 64b .. 64b+63 (one high-table entry, 64 consecutive
 // low-table entries).  Pass 1 (queries on the lanes, an eighth of the batch per wave): which queries get past
 // the high table alone — about a third for uniform data — compacted into an LDS queue.  Pass 2 (cells on
@@ -824,33 +609,25 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     }
 }
 
-// The scan (round-2 form, kept as the A/B arm `cells_variant` 1 / 2).  A block's waves share the batch's B operands
-// and thresholds in LDS; wave w takes cells w, w + W, ...  Per cell a wave issues every load it needs at once (tiles,
-// norms, list: one round trip), and the kernel is written lean (~80 VGPRs, 12 waves per block) so that 5-6 waves per
-// SIMD each have a cell in flight.
-//   NORM_MFMA = false: the C tile (norms) goes through a per-wave LDS window, four broadcast ds_read_b128 per tile
-//                      and block of queries (round 2: 0.113 ms at C3, the LDS pipe busy 0.081 ms of it)
-//   NORM_MFMA = true : the C tile comes out of one extra MFMA on the split norms (see the head of this file)
+// The scan.  A block's waves share the batch's B operands and thresholds in LDS.  Per item a wave issues every load it
+// needs at once (tiles, norms, list: one round trip), and the kernel is written lean (~80 VGPRs, 12 waves per block) so
+// that 5-6 waves per SIMD each have an item in flight.  The C tile (norms) goes through a per-wave LDS window, four
+// broadcast ds_read_b128 per tile and block of queries.  (Round 3 measured the C tile out of one extra MFMA on split norms
+// instead: 115-138 VGPRs, slower at every size — tools/arms/README.md.)
 #define CELL_SCAN_WAVES 12
 #define CELL_SCAN_CHUNK 256   // items of a block's run whose tile ranges and list lengths sit in LDS at a time (DYN)
 
 // One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
-template <bool NORM_MFMA>
-__device__ __forceinline__ u64 cell_tile_step(const h8 &a, unsigned nw, const f4v *__restrict__ my_nrm, int p, int half,
-                                              const h8 &b, float th)
+__device__ __forceinline__ u64 cell_tile_step(const h8 &a, const f4v *__restrict__ my_nrm, int p, int half, const h8 &b, float th)
 {
     f16v c;
-    if constexpr (NORM_MFMA) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw), norm_b_operand(), zero_acc(), 0, 0, 0);
-    } else {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f4v v = my_nrm[p * 8 + 2 * gq + half];
-            c[4 * gq + 0] = v[0];
-            c[4 * gq + 1] = v[1];
-            c[4 * gq + 2] = v[2];
-            c[4 * gq + 3] = v[3];
-        }
+    for (int gq = 0; gq < 4; ++gq) {
+        const f4v v = my_nrm[p * 8 + 2 * gq + half];
+        c[4 * gq + 0] = v[0];
+        c[4 * gq + 1] = v[1];
+        c[4 * gq + 2] = v[2];
+        c[4 * gq + 3] = v[3];
     }
     const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     const float mn = min_tree16(d, th);
@@ -1132,406 +909,12 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Round 3, kernel 2 of 2: match + scan + exact re-rank.  One block of W waves per CU (or fewer, larger shares on small
-// shards); block b owns C = 2^cshift consecutive cells [b C, (b + 1) C): one entry of the high table, C consecutive
-// entries of the low table.
-//   phase A  pass 1: every query of the batch against the block's high-table entry -> a queue in LDS (about a third
-//            survive on uniform data); pass 2: queue entries on the lanes, the block's low-table entries of an entry
-//            are one contiguous run, 16 cells (64 bytes) per load; survivors are appended to per-cell lists in LDS, the
-//            16 list counters of a run advanced by ONE LDS atomic (16 lanes, one counter each).
-//   phase B  waves take cells from a block-wide counter.  Per cell: tiles + norm words (HBM, once) and the listed
-//            queries' B operands + thresholds (gathered from L2, 32 per block of columns, up to 4 blocks at a time) are
-//            requested together; per tile ONE norm MFMA serves the 4 blocks of queries, each block = one scoring MFMA +
-//            the 8-op min3 tree + one compare.
-//   hits     (rare: ~3 per 1000 tile steps) are re-ranked on the spot: 16 lanes evaluate the 16 rows of the hit with
-//            the exact v0 arithmetic (reference core.cu:44-49) on the original fp32 rows and fold the best into the
-//            query's packed key — no record buffers, no second kernel.
-// ------------------------------------------------------------------------------------------
-#define SWEEP_HITQ 256   // pending hits a wave can hold between two re-rank passes
-#define SWEEP_QB 2   // blocks of 32 listed queries scored per norm MFMA (4: 64 accumulator registers — with the second tile set that is more than 2 waves per SIMD can hold)
-
-template <int W>
-__global__ __launch_bounds__(64 * W, (W <= 8 ? 2 : W <= 12 ? 3 : 4)) void knn_cells_sweep_kernel(   // (HIP: the second number is waves per SIMD)
-    const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, const unsigned *__restrict__ tile_start, int cshift,
-    const h8 *__restrict__ qfg, const float *__restrict__ thrg, const float *__restrict__ dupg, int m, int m_padded,
-    const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, int sa, unsigned lcap,
-    const float *__restrict__ Q, const float *__restrict__ R, const unsigned *__restrict__ perm, long long npos, int k,
-    long long base, u64 *__restrict__ keys, unsigned *__restrict__ ctl, u64 *__restrict__ stamps, unsigned dbg)
-{
-#pragma clang fp contract(off)
-    // (stamps: development aid, normally null — per wave the 100 MHz wall clock at the phase boundaries)
-#define SWEEP_STAMP(i)                                                                  \
-    do {                                                                                \
-        if (stamps && (threadIdx.x & 63) == 0)                                          \
-            stamps[((size_t)blockIdx.x * W + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); \
-    } while (0)
-    extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];
-    // [m_padded / 32][64] B operands | [m_padded] thresholds | [C + 1] first tile of each cell | [C] list lengths |
-    // queue: [m_padded] hi value, [m_padded] Dup, [m_padded] query | [W][64] pending hits | [C][lcap] lists
-    const int C = 1 << cshift;
-    h8 *s_qf = (h8 *)s_dyn;
-    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);
-    unsigned *s_tile = (unsigned *)(s_thr + m_padded);
-    unsigned *s_cnt = s_tile + (C + 64);
-    unsigned short *s_order = (unsigned short *)(s_cnt + C);   // [C] cells in the order they are handed out
-    float *s_hv = (float *)(s_order + 2 * C);
-    float *s_dq = s_hv + m_padded;
-    u64 *s_hits = (u64 *)(s_dq + m_padded);
-    u64 *s_mq = s_hits + W * SWEEP_HITQ;   // [W][2 * CELL_TILES_PER_PASS * SWEEP_QB]: (mask, tile << 1 | block) of the steps that had hits
-    unsigned short *s_q = (unsigned short *)(s_mq + W * 2 * CELL_TILES_PER_PASS * SWEEP_QB);
-    unsigned short *s_list = s_q + m_padded;
-    __shared__ unsigned s_npass, s_flag, s_next;
-    constexpr int T = 64 * W;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned c0 = blockIdx.x << cshift;
-    SWEEP_STAMP(0);
-    const unsigned long long clk0 = stamps ? __builtin_readcyclecounter() : 0ull;   // shader clock (s_memtime)
-    // ---- everything phase A needs from memory, requested at once
-    if (tid == 0) {
-        s_flag = ctl[KNN_CTL_FALLBACK];   // ONCE per block (set by the prep kernel only: bad or unboundable queries)
-        s_npass = 0u;
-        s_next = 0u;
-    }
-    for (int i = tid; i <= C; i += T)
-        s_tile[i] = tile_start[c0 + (unsigned)i];
-    for (int i = tid; i < C; i += T)
-        s_cnt[i] = 0u;
-    for (int i = tid; i < m_padded * 2; i += T)   // the batch's B operands and thresholds: gathered per cell below
-        s_qf[i] = qfg[i];
-    for (int i = tid; i < m_padded; i += T)
-        s_thr[i] = thrg[i];
-    const int nl = 1 << sa;
-    const float *__restrict__ hrow = hi_tab + (size_t)(c0 >> sa) * m_padded;
-    constexpr int U = (KNN_CELL_BATCH + T - 1) / T;
-    float hv[U], dq[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int q = u * T + tid;
-        hv[u] = q < m ? hrow[q] : INFINITY;
-        dq[u] = q < m ? dupg[q] : -INFINITY;
-    }
-    __syncthreads();
-    SWEEP_STAMP(1);
-    if (__builtin_amdgcn_readfirstlane((int)s_flag) != 0)
-        return;        // block-uniform: the gated exact scan answers this batch
-    // ---- phase A, pass 1
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int q = u * T + tid;
-        const bool pass = q < m && !(hv[u] > dq[u]);
-        const u64 mask = __ballot(pass);
-        if (mask != 0ull) {   // wave-uniform
-            unsigned at = 0u;
-            if (lane == 0)
-                at = atomicAdd(&s_npass, (unsigned)__popcll(mask));
-            at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-            if (pass) {
-                const unsigned pos = at + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                s_q[pos] = (unsigned short)q;
-                s_hv[pos] = hv[u];
-                s_dq[pos] = dq[u];
-            }
-        }
-    }
-    __syncthreads();
-    SWEEP_STAMP(2);
-    // ---- phase A, pass 2
-    const unsigned npass = (unsigned)__builtin_amdgcn_readfirstlane((int)s_npass);
-    const unsigned l0 = c0 & (unsigned)(nl - 1);
-    for (unsigned e0 = (unsigned)wib * 64u; e0 < npass; e0 += 64u * W) {
-        const unsigned e = e0 + (unsigned)lane;
-        const bool live = e < npass;
-        const unsigned q = live ? s_q[e] : 0u;
-        const float ehv = live ? s_hv[e] : INFINITY;
-        const float edq = live ? s_dq[e] : -INFINITY;
-        const f4v *__restrict__ lrow = (const f4v *)(lo_tab + (size_t)q * nl + l0);
-        for (int cc = 0; cc < C; cc += 32) {   // C is a multiple of 16; 32 cells = 128 bytes of the entry's run per round trip
-            f4v v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = cc + 4 * j < C ? lrow[cc / 4 + j] : (f4v){INFINITY, INFINITY, INFINITY, INFINITY};
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (cc + 16 * hh >= C)   // wave-uniform
-                    break;
-                u64 mk[16];
-                unsigned mycount = 0u;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    mk[j] = __ballot(live && !(v[4 * hh + (j >> 2)][j & 3] + ehv > edq));
-                    if (lane == j)
-                        mycount = (unsigned)__popcll(mk[j]);
-                }
-                unsigned mybase = 0u;
-                if (lane < 16 && mycount != 0u)
-                    mybase = atomicAdd(&s_cnt[cc + 16 * hh + lane], mycount);   // one LDS atomic instruction for the 16 counters
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (mk[j] != 0ull) {   // wave-uniform
-                        const unsigned bj = (unsigned)__builtin_amdgcn_readlane((int)mybase, j);
-                        if ((mk[j] >> lane) & 1ull) {
-                            const unsigned pos = bj + __builtin_amdgcn_mbcnt_hi((unsigned)(mk[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[j], 0u));
-                            if (pos < lcap)
-                                s_list[(unsigned)(cc + 16 * hh + j) * lcap + pos] = (unsigned short)q;
-                        }
-                    }
-            }
-        }
-    }
-    // Longest first: the cells are handed out in descending order of work (listed queries x tiles), so that the last
-    // cells taken are the short ones and the waves of a block finish together (lists run from a few dozen to a few
-    // hundred queries; in index order the slowest wave of a block finished at twice the median)
-    __syncthreads();
-    for (int i = tid; i < C; i += T) {
-        const unsigned wi = min(s_cnt[i], lcap + 1u) * (s_tile[i + 1] - s_tile[i]);
-        unsigned rank = 0u;
-        for (int j = 0; j < C; ++j) {
-            const unsigned wj = min(s_cnt[j], lcap + 1u) * (s_tile[j + 1] - s_tile[j]);
-            rank += (wj > wi || (wj == wi && j < i)) ? 1u : 0u;
-        }
-        s_order[rank] = (unsigned short)i;
-    }
-    __syncthreads();
-    SWEEP_STAMP(3);
-
-    // ---- phase B: work items = (cell, pass of up to CELL_TILES_PER_PASS tiles), cells taken from a block-wide counter
-    const int col = lane & 31, half = lane >> 5;
-    unsigned nhits = 0u;
-    // Hits wait in a per-wave queue — (query << 32) | (tile << 1) | half, the record format of the full scan — and are
-    // re-ranked four at a time (16 lanes each) right after the NEXT item's loads have been requested, so that the two
-    // dependent round trips of a re-rank (position -> row number -> row) run beside a round trip the wave makes anyway.
-    u64 *my_hits = s_hits + wib * SWEEP_HITQ;
-    unsigned pending = 0u;   // wave-uniform
-    u64 *my_mq = s_mq + wib * (2 * CELL_TILES_PER_PASS * SWEEP_QB);
-    auto drain = [&]() {
-        for (unsigned h0 = 0u; h0 < pending; h0 += 4u) {
-            const unsigned h = h0 + ((unsigned)lane >> 4);
-            u64 key = ~0ull;
-            unsigned hq = 0u;
-            if (h < pending) {
-                const u64 e = my_hits[h];
-                hq = (unsigned)(e >> 32);
-                const unsigned lo32 = (unsigned)e, reg = (unsigned)lane & 15u;
-                const size_t pos = (size_t)(lo32 >> 1) * 32 + 8u * (reg >> 2) + 4u * (lo32 & 1u) + (reg & 3u);
-                const unsigned row = (long long)pos < npos && hq < (unsigned)m ? perm[pos] : 0xFFFFFFFFu;   // (belt and braces: a record is never out of range)
-                if (row != 0xFFFFFFFFu) {   // padding positions hold ~0u
-                    const float *__restrict__ qr = Q + (size_t)hq * k;
-                    const float *__restrict__ rr = R + (size_t)row * k;
-                    float acc = 0.0f;
-                    for (int d0 = 0; d0 < k; ++d0) {   // v0: (q - r)^2 summed in dimension order, one rounding per operation
-                        const float diff = qr[d0] - rr[d0];
-                        const float sq = diff * diff;
-                        acc = acc + sq;
-                    }
-                    if (acc < INFINITY)   // false for NaN too: v0 never selects those
-                        key = ((u64)__float_as_uint(acc) << 32) | (u64)(unsigned)(base + (long long)row);
-                }
-            }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const u64 o = __shfl_xor(key, off, KNN_WAVE);
-                key = o < key ? o : key;
-            }
-            // keys[] only ever decreases, so a stale (larger) read can only cause a spare atomic
-            if ((lane & 15) == 0 && key != ~0ull && key < keys[hq])
-                __hip_atomic_fetch_min(&keys[hq], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        nhits += pending;
-        pending = 0u;
-    };
-    // the operands of the norm MFMA: built once, kept opaque so that they stay in registers (left alone the compiler
-    // puts both together again for every tile: six moves per tile in a loop that is bound by vector issue)
-    u4v norm_a = {0u, 0u, 0u, 0u};
-    h8 norm_b = norm_b_operand();
-    asm volatile("" : "+v"(norm_a), "+v"(norm_b));
-    unsigned long long listed = 0;   // (stamps only)
-    // generator of work items (all wave-uniform)
-    unsigned g_ci = 0u, g_t0 = 0u, g_te = 0u, g_nq = 0u;
-    bool g_dense = false;
-    struct Item {
-        unsigned ci, t0, nq;
-        int nt;
-        bool dense;
-    };
-    auto next_item = [&](Item &it) __attribute__((always_inline)) -> bool {
-        for (;;) {
-            if (g_t0 < g_te) {
-                it.ci = g_ci;
-                it.t0 = g_t0;
-                it.nt = (int)min((unsigned)CELL_TILES_PER_PASS, g_te - g_t0);
-                it.nq = g_nq;
-                it.dense = g_dense;
-                g_t0 += CELL_TILES_PER_PASS;
-                return true;
-            }
-            unsigned ci = 0u;
-            if (lane == 0)
-                ci = atomicAdd(&s_next, 1u);
-            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
-            if (ci >= (unsigned)C)
-                return false;
-            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)s_order[ci]);
-            // (values read from LDS are wave-uniform but the compiler cannot know: without the readfirstlane every test on
-            // them below became an exec-mask dance — v_cmp / s_and_saveexec per tile — and tripled the vector instructions)
-            unsigned nq = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[ci]);
-            const bool dense = nq > lcap;   // the list did not fit its LDS room: score every query of the batch
-            if (dense) {
-                nq = (unsigned)m;
-                if (lane == 0)
-                    atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
-            }
-            const unsigned tb = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tile[ci]);
-            const unsigned te = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tile[ci + 1u]);
-            if (nq == 0u || te == tb)
-                continue;
-            listed += nq;
-            g_ci = ci;
-            g_t0 = tb;
-            g_te = te;
-            g_nq = nq;
-            g_dense = dense;
-        }
-    };
-    auto request = [&](const Item &it, h8(&ar)[CELL_TILES_PER_PASS], unsigned(&nw)[CELL_TILES_PER_PASS]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-            nw[p] = 0u;
-            if (p < it.nt) {
-                if (dbg & 4u) {   // experiment: no tile loads
-                    ar[p] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-                    continue;
-                }
-                ar[p] = __builtin_nontemporal_load(&rf[(size_t)(it.t0 + (unsigned)p) * 64 + lane]);
-                if (lane < 32)
-                    nw[p] = __builtin_nontemporal_load(&rn2[(size_t)(it.t0 + (unsigned)p) * 32 + lane]);
-            }
-        }
-    };
-    auto process = [&](const Item &it, h8(&ar)[CELL_TILES_PER_PASS], unsigned(&nw)[CELL_TILES_PER_PASS]) __attribute__((always_inline)) {
-        const unsigned short *list = s_list + it.ci * lcap;
-        const unsigned nq = it.nq;
-        const int nt = it.nt;
-        for (unsigned q0 = 0u; q0 < nq; q0 += 32u * SWEEP_QB) {
-            const int nblk = (int)min((unsigned)SWEEP_QB, (nq - q0 + 31u) / 32u);   // wave-uniform
-            unsigned qid[SWEEP_QB];
-            h8 b[SWEEP_QB];
-            float th[SWEEP_QB];
-#pragma unroll
-            for (int j = 0; j < SWEEP_QB; ++j) {
-                const unsigned idx = q0 + 32u * (unsigned)j + (unsigned)col;
-                const bool valid = j < nblk && idx < nq;
-                qid[j] = valid ? (it.dense ? idx : (unsigned)list[idx]) : 0u;
-                b[j] = s_qf[(qid[j] >> 5) * 64u + (unsigned)half * 32u + (qid[j] & 31u)];
-                th[j] = valid ? s_thr[qid[j]] : -INFINITY;
-            }
-            if (pending != 0u)   // wave-uniform; the tile loads of this item are in flight
-                drain();
-            unsigned nmq = 0u;   // wave-uniform: steps of this group that had hits
-            // NB blocks of queries per tile, straight-line; no branch sits between an MFMA and the reader of its result (the
-            // compiler's cross-block wait-state count was short there: DESIGN 4.2, tools/mfma_hazard_audit.py)
-            auto run = [&](auto nb_tag) __attribute__((always_inline)) {
-                constexpr int NB = decltype(nb_tag)::value;
-#pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                    if (p < nt) {
-                        norm_a[0] = nw[p];
-                        const f16v cn = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, norm_a), norm_b, zero_acc(), 0, 0, 0);
-                        u64 masks[NB];
-                        u64 any = 0ull;
-                        // all NB scoring MFMAs first, back to back on accumulators of their own (the last one continues
-                        // in the norm tile's registers), THEN the min trees: left to itself the scheduler put each tree
-                        // right behind its MFMA on one shared accumulator — 12 idle wait states per block of queries and
-                        // no MFMA in flight under a tree.  The barrier keeps the two groups apart.
-                        f16v d[NB];
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            d[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], b[j], cn, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) {
-                            const float mn = min_tree16(d[j], th[j]);
-                            masks[j] = __ballot(mn < th[j]);
-                            any |= masks[j];
-                        }
-                        if (__builtin_expect(any != 0ull, 0)) {
-                            // (rare: ~3 per 1000 steps) only the masks are parked here — the hot loop stays small; the hits
-                            // are unpacked below, once per group
-#pragma unroll
-                            for (int j = 0; j < NB; ++j)
-                                if (masks[j] != 0ull) {   // wave-uniform
-                                    if (lane == 0) {
-                                        my_mq[2u * nmq] = masks[j];
-                                        my_mq[2u * nmq + 1u] = ((u64)(it.t0 + (unsigned)p) << 1) | (u64)j;
-                                    }
-                                    ++nmq;
-                                }
-                        }
-                    }
-                }
-            };
-            if (dbg & 1u) {   // experiment: no scoring at all (loads are still waited for)
-                float keep = 0.f;
-#pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                    if (p < nt)
-                        keep += (float)ar[p][0] + __uint_as_float(nw[p]);
-                if (keep == 12345.678f)
-                    nmq = 1u;
-            } else if (nblk > 1)
-                run(std::integral_constant<int, SWEEP_QB>());
-            else
-                run(std::integral_constant<int, 1>());
-            if (__builtin_expect(nmq != 0u, 0)) {
-                // hit lane L of a step = (query qid[block] of L, rows 8g + 4 half(L) + i of the tile) -> the pending queue
-                wave_lds_sync();
-                for (unsigned e = 0u; e < nmq; ++e) {
-                    const u64 mask = my_mq[2u * e];
-                    const u64 tj = my_mq[2u * e + 1u];
-                    const unsigned cnt = (unsigned)__popcll(mask);
-                    if (pending + cnt > SWEEP_HITQ)
-                        drain();
-                    if ((mask >> lane) & 1ull) {
-                        const unsigned at = pending + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        const unsigned hq = (tj & 1ull) ? qid[SWEEP_QB - 1] : qid[0];
-                        my_hits[at] = ((u64)hq << 32) | ((tj >> 1) << 1) | (u64)half;
-                    }
-                    pending += cnt;
-                    wave_lds_sync();
-                }
-            }
-        }
-    };
-    {
-        h8 ar[CELL_TILES_PER_PASS];
-        unsigned nw[CELL_TILES_PER_PASS];
-        Item it;
-        while (next_item(it)) {
-            request(it, ar, nw);
-            process(it, ar, nw);
-        }
-    }
-    if (pending != 0u)
-        drain();
-    if (lane == 0 && nhits != 0u)
-        atomicAdd(&ctl[KNN_CTL_RECORDS], nhits);   // statistics: candidates re-ranked
-    SWEEP_STAMP(4);
-    if (stamps && lane == 0) {
-        stamps[((size_t)blockIdx.x * W + wib) * 8 + 5] = __builtin_readcyclecounter() - clk0;
-        stamps[((size_t)blockIdx.x * W + wib) * 8 + 6] = (u64)npass | ((u64)__builtin_amdgcn_s_getreg(63492) << 32);   // HW_ID
-        stamps[((size_t)blockIdx.x * W + wib) * 8 + 7] = listed;
-    }
-#undef SWEEP_STAMP
-}
-
 // (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512)
 // (HIP's second launch bound is waves per SIMD: 6 = at most 80 registers.  Left at 2 the allocator settled at 96-98 once the
 // dense-cell and overflow paths were in — 4 waves per SIMD, and the kernel alone went from 0.035 to 0.042 ms at 2^21 rows)
-template <bool NORM_MFMA, bool DYN = false>
-__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn_cells_scan_kernel(
-    const h8 *__restrict__ rf, const float *__restrict__ rn, const unsigned *__restrict__ rn2,
-    const u64 *__restrict__ items, unsigned nitems,
+template <bool DYN>
+__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel(
+    const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
     u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice,
@@ -1540,7 +923,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
     extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
-    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8] (LDS norms only)
+    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
     __shared__ unsigned s_flag;
     if (threadIdx.x == 0)
         s_flag = ctl[KNN_CTL_FALLBACK];   // read once per block: see knn_cells_match_kernel
@@ -1635,17 +1018,11 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
             for (unsigned t0 = tb; t0 < te && !dead; t0 += CELL_TILES_PER_PASS) {
                 const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
                 h8 ar[CELL_TILES_PER_PASS];
-                unsigned nw[CELL_TILES_PER_PASS];
 #pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
-                    nw[p] = 0u;
-                    if (p < nt) {
+                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
+                    if (p < nt)
                         ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
-                        if (NORM_MFMA && lane < 32)
-                            nw[p] = __builtin_nontemporal_load(&rn2[(size_t)(t0 + (unsigned)p) * 32 + lane]);
-                    }
-                }
-                if constexpr (!NORM_MFMA) {
+                {
                     const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
                     const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
                     const f4v n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
@@ -1675,7 +1052,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, (NORM_MFMA ? 3 : 6)) void knn
 #pragma unroll
                     for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
                         if (p < nt) {
-                            const u64 mask = cell_tile_step<NORM_MFMA>(ar[p], nw[p], my_nrm, p, half, b, th);
+                            const u64 mask = cell_tile_step(ar[p], my_nrm, p, half, b, th);
                             if (__builtin_expect(mask != 0ull, 0)) {
                                 const bool hit = (mask >> lane) & 1ull;
                                 const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
@@ -1988,15 +1365,13 @@ void knn_cells_workspace_free(FilterWorkspace &w)
 
 // ---- per batch ---------------------------------------------------------------------------------
 
-static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m, bool lists_in_memory)
+static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, int m)
 {
     const CellIndex &c = *st.cells;
-    if (lists_in_memory) {   // the round-2 kernels (A/B arms) hand the lists over through memory
-        if (!w.cell_counts)
-            FTRY(KNN_DEV_ALLOC((void **)&w.cell_counts, (size_t)c.ncells * sizeof(unsigned)));
-        if (!w.cell_lists)
-            FTRY(KNN_DEV_ALLOC((void **)&w.cell_lists, (size_t)c.ncells * c.cap * sizeof(unsigned short)));
-    }
+    if (!w.cell_counts)
+        FTRY(KNN_DEV_ALLOC((void **)&w.cell_counts, (size_t)c.ncells * sizeof(unsigned)));
+    if (!w.cell_lists)
+        FTRY(KNN_DEV_ALLOC((void **)&w.cell_lists, (size_t)c.ncells * c.cap * sizeof(unsigned short)));
     const int m_padded = (m + 31) / 32 * 32;
     if (m_padded > w.cell_m_cap) {
         (void)KNN_DEV_FREE(w.dup);
@@ -2012,130 +1387,37 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
     return hipSuccess;
 }
 
-// Sweep geometry: one block per CU when the shard has the cells for it — cells per block = a power of two between 16
-// and the width of the low table — and list entries per cell in LDS: 32768 u16 entries = 64 KiB per block in all, which
-// is the whole batch per list up to 32 cells per block (2^13 cells on 256 CUs) and 128 queries at 256 cells per block
-// (2^16 cells; uniform data lists 25 there).  A longer list turns its cell `dense`.
-static void sweep_geometry(const CellIndex &c, int num_cu, int *cshift, unsigned *lcap)
+// Every size the scan launch and the re-rank behind it index with, in one place (tests/test_cells_logic.py checks the
+// arithmetic on the CPU through knn_debug_scan_plan):
+//   blocks   scan grid: blocks_per_cu per CU, fewer when the index has fewer items than that many waves
+//   nlists   = blocks x CELL_SCAN_WAVES record lists, one per wave: counts[nlists] (the workspace holds kMaxLists = 2^16)
+//   slice    records [w x slice, (w + 1) x slice) belong to wave w
+//   ovf      records [ovf_base, ovf_base + ovf_cap) are the area all waves share; nlists x slice <= ovf_base
+//   lds      dynamic LDS of the scan: m_padded x (32 B operand + 4 B threshold) + one norm window per wave
+CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded)
 {
-    int cs = 4;
-    while ((c.ncells >> (cs + 1)) >= (unsigned)num_cu && cs + 1 <= c.sa)
-        ++cs;
-    *cshift = cs;
-    *lcap = std::min((unsigned)KNN_CELL_BATCH, 32768u >> cs);
+    CellScanPlan p;
+    p.blocks = (unsigned)num_cu * (unsigned)blocks_per_cu;
+    if (p.blocks * CELL_SCAN_WAVES > nitems)
+        p.blocks = std::max(1u, nitems / CELL_SCAN_WAVES);
+    p.nlists = p.blocks * CELL_SCAN_WAVES;
+    // the tail of the record buffer is shared by all waves: what a wave's own slice cannot hold goes there.  2^16 records:
+    // room for a batch whose queries crowd into a few cells (1024 copies of one query leave ~2000 records there), and small
+    // enough that a batch the fp16 scores cannot separate at all (a cluster tighter than the fp16 step: millions of
+    // candidates, one atomic on ONE word per overflowing step) over-fills it — and stops scanning — within microseconds
+    p.ovf_cap = std::min(rec_cap / 4u, 1u << 16);
+    p.ovf_base = rec_cap - p.ovf_cap;
+    p.slice = p.ovf_base / p.nlists;
+    p.lds_bytes = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    return p;
 }
 
-#define CELL_SWEEP_WAVES 12
-
-static hipError_t launch_sweep(FilterState &st, FilterWorkspace &w, int m, int m_padded, int cshift, unsigned lcap, const float *q,
-                               const float *r, long long base, u64 *keys, hipStream_t s)
-{
-    constexpr int W = CELL_SWEEP_WAVES;
-    const CellIndex &c = *st.cells;
-    const size_t C = (size_t)1 << cshift;
-    const size_t lds = (size_t)m_padded * 36 + (C + 64 + C + C) * 4 + (size_t)m_padded * 4 * 2 + (size_t)W * SWEEP_HITQ * 8 + (size_t)W * 2 * CELL_TILES_PER_PASS * SWEEP_QB * 8 + (size_t)m_padded * 2 +
-                       (C * lcap) * 2;
-    static u64 *stamps = nullptr;
-    static const bool want_stamps = getenv("KNN_MI355X_SWEEP_STAMPS") != nullptr;
-    if (want_stamps && !stamps)
-        FTRY(hipMalloc((void **)&stamps, (size_t)65536 * 8 * sizeof(u64)));
-    // (dynamic LDS beyond the default limit must be asked for, per device: remembered so that the call is made once)
-    static std::atomic<size_t> lds_allowed[64];
-    int dev = 0;
-    FTRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || lds > lds_allowed[dev].load(std::memory_order_relaxed)) {
-        FTRY(hipFuncSetAttribute((const void *)knn_cells_sweep_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64)
-            lds_allowed[dev].store(lds, std::memory_order_relaxed);
-    }
-    hipLaunchKernelGGL(knn_cells_sweep_kernel<W>, dim3(c.ncells >> cshift), dim3(64 * W), lds, s, (const h8 *)st.ref_frags,
-                       st.ref_norms2, c.tile_start, cshift, (const h8 *)w.qry_frags, w.thr, w.dup, m, m_padded, w.lo_tab, w.hi_tab,
-                       c.sa, lcap, q, r, c.perm, st.ntiles * 32, st.k, base, keys, w.ctl_cur, stamps,
-                       getenv("KNN_MI355X_SWEEP_DBG") ? (unsigned)atoi(getenv("KNN_MI355X_SWEEP_DBG")) : 0u);
-    FTRY(hipGetLastError());
-    if (stamps) {   // development aid (KNN_MI355X_SWEEP_STAMPS=1): synchronises and prints where the waves spent their time
-        const size_t nw = (size_t)(c.ncells >> cshift) * W;
-        std::vector<u64> h(nw * 8);
-        FTRY(hipStreamSynchronize(s));
-        FTRY(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
-        u64 tmin = ~0ull, tmax = 0;
-        for (size_t i = 0; i < nw; ++i) {
-            tmin = std::min(tmin, h[i * 8]);
-            tmax = std::max(tmax, h[i * 8 + 4]);
-        }
-        const char *names[4] = {"loads + barrier", "pass 1 + barrier", "pass 2 + barrier", "cells scanned"};
-        fprintf(stderr, "[knn sweep] %zu waves, C = %zu, lcap %u, LDS %zu B, first start -> last end %.2f us\n", nw, C, lcap, lds, (tmax - tmin) * 0.01);
-        std::vector<double> v(nw);
-        for (int ph = 0; ph < 4; ++ph) {
-            for (size_t i = 0; i < nw; ++i)
-                v[i] = (double)(h[i * 8 + ph + 1] - h[i * 8 + ph]) * 0.01;
-            std::sort(v.begin(), v.end());
-            fprintf(stderr, "[knn sweep]   %-18s median %7.2f  p90 %7.2f  max %7.2f us\n", names[ph], v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
-        }
-        for (size_t i = 0; i < nw; ++i)
-            v[i] = (double)(h[i * 8] - tmin) * 0.01;
-        std::sort(v.begin(), v.end());
-        double np = 0, tot = 0, mhz = 0;
-        for (size_t i = 0; i < nw; ++i) {
-            np += (double)(h[i * 8 + 6] & 0xFFFFFFFFull);
-            tot += (double)h[i * 8 + 7];
-            mhz += (double)h[i * 8 + 5] / ((double)(h[i * 8 + 4] - h[i * 8]) * 0.01);
-        }
-        fprintf(stderr, "[knn sweep]   shader clock while the waves ran: %.0f MHz\n", mhz / nw);
-        {   // per block: time in phase B (slowest wave) against the queries listed in the block, by XCD (block % 8)
-            const size_t nb = nw / W;
-            double xs[8] = {0}, xl[8] = {0};
-            int xn[8] = {0};
-            std::vector<std::pair<double, double>> bl;
-            for (size_t b = 0; b < nb; ++b) {
-                double t = 0, l = 0;
-                for (int wv = 0; wv < W; ++wv) {
-                    t = std::max(t, (double)(h[(b * W + wv) * 8 + 4] - h[(b * W + wv) * 8 + 3]) * 0.01);
-                    l += (double)h[(b * W + wv) * 8 + 7];
-                }
-                xs[b % 8] += t;
-                xl[b % 8] += l;
-                ++xn[b % 8];
-                bl.push_back({t, l});
-            }
-            std::sort(bl.begin(), bl.end());
-            fprintf(stderr, "[knn sweep]   blocks by phase-B time: fastest %.1f us (%.0f listed)  median %.1f (%.0f)  slowest %.1f (%.0f) %.1f (%.0f)\n",
-                    bl[0].first, bl[0].second, bl[nb / 2].first, bl[nb / 2].second, bl[nb - 2].first, bl[nb - 2].second, bl[nb - 1].first, bl[nb - 1].second);
-            {   // where the hardware put the waves of block 0 .. 2: SIMD of each wave (HW_ID bits 5:4), CU (11:8), SE (15:13)
-                for (size_t b = 0; b < 3 && b < nb; ++b) {
-                    fprintf(stderr, "[knn sweep]   block %zu waves on (se.cu.simd):", b);
-                    for (int wv = 0; wv < W; ++wv) {
-                        const unsigned id = (unsigned)(h[(b * W + wv) * 8 + 6] >> 32);
-                        fprintf(stderr, " %u.%u.%u", (id >> 13) & 7u, (id >> 8) & 15u, (id >> 4) & 3u);
-                    }
-                    fprintf(stderr, "\n");
-                }
-            }
-            fprintf(stderr, "[knn sweep]   by XCD:");
-            for (int x = 0; x < 8; ++x)
-                fprintf(stderr, " %.1f us/%.0f", xs[x] / std::max(xn[x], 1), xl[x] / std::max(xn[x], 1));
-            fprintf(stderr, "\n");
-        }
-        fprintf(stderr, "[knn sweep]   wave start after first: median %.2f p90 %.2f max %.2f us; queue %.0f per block, listed queries per wave %.1f\n",
-                v[nw / 2], v[nw * 9 / 10], v[nw - 1], np / nw, tot / nw);
-    }
-    return hipSuccess;
-}
-
-// One batch of <= KNN_CELL_BATCH queries.  `cells_variant`: 0 = prep + match + scan (the default chain), 1 = the round-2
-// chain (query fragments by the caller, seed, match, scan), 2 = as 0 with the scan's norm tile out of an extra MFMA instead
-// of LDS, 3 = prep + sweep (match, scan and re-rank in one persistent kernel: an experiment that did not pay).
-// Records in w, as the full scan leaves them (variant 3: none, w.nlists = 0).
+// One batch of <= KNN_CELL_BATCH queries: prep + match + scan.  Records in w, as the full scan leaves them.
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, const float *r, long long base,
                            u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys)
 {
     u64 *keys_init = init_keys ? keys : nullptr;
-    // (the fused sweep kernel — an experiment arm — gives a cell to ONE wave and re-ranks its hits inline: on a set whose rows
-    // crowd into a few cells it runs for minutes (190 s for 2^21 copies of one point, tools/fuzz_parity.py).  Such indexes —
-    // the ones round 2 declined: largest cell > 16x the average — take the default chain whatever the option says.)
-    const bool fat_cells = (long long)st.cells->max_cell_rows * (long long)st.cells->ncells > 16ll * st.n;
-    const int variant = st.cells_variant == 3 && fat_cells ? 0 : st.cells_variant;
-    FTRY(ensure_cells_workspace(st, w, m, variant != 3));
+    FTRY(ensure_cells_workspace(st, w, m));
     const CellIndex &c = *st.cells;
     const int m_padded = (m + 31) / 32 * 32;
     CellGeom g;
@@ -2155,60 +1437,30 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // (2^15 cells, n = 2^23: step 0.0795 -> 0.0777 with one, three runs each on one box; 2^16 cells, C3: 0.1237 -> 0.1223, not
     // worth the 8 % the launch itself gets longer)
     const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 32768u);
-    unsigned gx = (unsigned)num_cu * (one_block ? 1u : 2u);
-    if (gx * CELL_SCAN_WAVES > c.nitems)
-        gx = std::max(1u, c.nitems / CELL_SCAN_WAVES);
-    w.nlists = gx * CELL_SCAN_WAVES;
-    // the tail of the record buffer is shared by all waves: what a wave's own slice cannot hold goes there.  2^16 records:
-    // room for a batch whose queries crowd into a few cells (1024 copies of one query leave ~2000 records there), and small
-    // enough that a batch the fp16 scores cannot separate at all (a cluster tighter than the fp16 step: millions of
-    // candidates, one atomic on ONE word per overflowing step) over-fills it — and stops scanning — within microseconds
-    w.ovf_cap = std::min(w.rec_cap / 4u, 1u << 16);
-    w.ovf_base = w.rec_cap - w.ovf_cap;
-    w.slice = (w.rec_cap - w.ovf_cap) / w.nlists;
+    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded);
+    const unsigned gx = plan.blocks;
+    w.nlists = plan.nlists;
+    w.ovf_cap = plan.ovf_cap;
+    w.ovf_base = plan.ovf_base;
+    w.slice = plan.slice;
 
-    if (variant == 1) {
-        // round 2: the caller has run the query-fragment kernel (which also reset block 0 of the control words)
-        w.ctl_cur = w.ctl;
-        hipLaunchKernelGGL(knn_cells_seed_kernel, dim3((unsigned)m), dim3(256), 0, s, q, m, g, c.bounds, sigma2, c.tile_start,
-                           (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.lo_tab, w.hi_tab, m_padded,
-                           w.qry_norms, w.qry_amax, w.qpart, (m_padded + 255) / 256, st.kt, st.sigma, st.bmax, st.nmax,
-                           kAmaxLimit, w.thr, w.dup, w.ctl, w.counts, w.nlists);
-        FTRY(hipGetLastError());
-    } else {
-        // the control words of this batch were cleared by the previous batch on this slot (or at allocation)
-        const unsigned parity = w.cell_batches++ & 1u;
-        w.ctl_cur = w.ctl + KNN_CTL_WORDS * (1u + parity);
-        unsigned *ctl_next = w.ctl + KNN_CTL_WORDS * (2u - parity);
-        if (variant == 3) {
-            w.nlists = 0u;   // no record lists: the sweep re-ranks its hits itself
-            w.slice = w.ovf_base = w.ovf_cap = 0u;
-        }
-        // batches in flight side by side: two waves per query (two seed cells each) — half the registers the launch holds,
-        // 0.0421 -> 0.0408 ms per step at n_local 2^21 for 2 us more when a batch runs alone; else four waves per query
-        if (st.several_slots)
-            hipLaunchKernelGGL(knn_cells_prep_kernel<2>, dim3((unsigned)m_padded), dim3(64 * 2), 0, s, q, m,
-                               m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
-                               st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
-                               w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
-        else
-            hipLaunchKernelGGL(knn_cells_prep_kernel<4>, dim3((unsigned)m_padded), dim3(64 * 4), 0, s, q, m,
-                               m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
-                               st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
-                               w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
-        FTRY(hipGetLastError());
-        if (variant == 3) {
-            int cshift = 0;
-            unsigned lcap = 0;
-            sweep_geometry(c, num_cu, &cshift, &lcap);
-            if (timed && w.ev_begin)
-                FTRY(hipEventRecord(w.ev_begin, s));
-            FTRY(launch_sweep(st, w, m, m_padded, cshift, lcap, q, r, base, keys, s));
-            if (timed && w.ev_end)
-                FTRY(hipEventRecord(w.ev_end, s));
-            return hipSuccess;
-        }
-    }
+    // the control words of this batch were cleared by the previous batch on this slot (or at allocation)
+    const unsigned parity = w.cell_batches++ & 1u;
+    w.ctl_cur = w.ctl + KNN_CTL_WORDS * (1u + parity);
+    unsigned *ctl_next = w.ctl + KNN_CTL_WORDS * (2u - parity);
+    // batches in flight side by side: two waves per query (two seed cells each) — half the registers the launch holds,
+    // 0.0421 -> 0.0408 ms per step at n_local 2^21 for 2 us more when a batch runs alone; else four waves per query
+    if (st.several_slots)
+        hipLaunchKernelGGL(knn_cells_prep_kernel<2>, dim3((unsigned)m_padded), dim3(64 * 2), 0, s, q, m,
+                           m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
+                           st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
+                           w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+    else
+        hipLaunchKernelGGL(knn_cells_prep_kernel<4>, dim3((unsigned)m_padded), dim3(64 * 4), 0, s, q, m,
+                           m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
+                           st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
+                           w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+    FTRY(hipGetLastError());
     if (c.ncells <= 16384u)
         hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
                            m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
@@ -2216,7 +1468,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
                            m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
     FTRY(hipGetLastError());
-    if (getenv("KNN_MI355X_TRACE_CELLS")) {   // development aid: the lists of this batch and how evenly the scan's waves are loaded (synchronises)
+    static const bool trace_cells = getenv("KNN_MI355X_TRACE_CELLS") != nullptr;   // (read once: a query may run beside a thread that changes the environment)
+    if (trace_cells) {   // development aid: the lists of this batch and how evenly the scan's waves are loaded (synchronises)
         std::vector<unsigned> hc((size_t)c.ncells), ht((size_t)c.ncells + 1);
         FTRY(hipStreamSynchronize(s));
         FTRY(hipMemcpy(hc.data(), w.cell_counts, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -2239,7 +1492,7 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     }
     if (timed && w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    const size_t lds = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    const size_t lds = plan.lds_bytes;
     // Items handed out inside the block (LDS counter, see the kernel) when batches come one at a time: the launch is as long as
     // its busiest wave, and evening the waves out takes 6-8 % off it (alone, ms: 0.0433 -> 0.0408 at 2^21 rows, 0.060 -> 0.055 at
     // 2^22, 0.1176 -> 0.1094 at C3; one batch at a time 0.0855 -> 0.0828, 0.102 -> 0.097, 0.1677 -> 0.160).  With batches in
@@ -2248,17 +1501,13 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // 0.0831 / 0.1249) — so that is what pipelined callers get.
     // (below two items per wave the counter has nothing to even out: 2^21 rows, one batch at a time, 0.0786 ms fixed / 0.0800 counter)
     const bool dyn = st.scan_deal == 2 || (st.scan_deal == 0 && !st.several_slots && c.nitems >= 2u * w.nlists);
-    if (variant == 2)
+    if (dyn)
         hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
-                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
-    else if (dyn)
-        hipLaunchKernelGGL((knn_cells_scan_kernel<false, true>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
                            w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
     else
         hipLaunchKernelGGL(knn_cells_scan_kernel<false>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, st.ref_norms2, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
+                           st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
                            w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
     FTRY(hipGetLastError());
     if (timed && w.ev_end)

@@ -151,12 +151,11 @@ struct FilterState {
     void *ref_frags = nullptr; // device [ntiles][kt][64] x 16 B: A operands in MFMA lane order
     float *ref_norms = nullptr;// device [ntiles*32] (+INF for padding rows)
     unsigned *ref_norms2 = nullptr; // cell-sorted layouts only, device [ntiles*32]: the same norms as two fp16 halves
-                               // (hi | mid * 2^11 << 16) — the scan rebuilds its C tile from them with one extra MFMA
-                               // instead of four LDS reads (knn_cells.hip)
+                               // (hi | mid * 2^11 << 16) — the prep kernel rebuilds the C tile of its seed scores from
+                               // them with one extra MFMA: one register per tile in flight instead of 16 (knn_cells.hip)
     int force_qt = 0;          // tuning hook: query tiles per wave (0 = pick by m)
     int force_rounds = 0;      // tuning hook: filter blocks per resident slot (0 = default)
     int chain_policy = 0;      // scans of different slots: 0 auto (chained when long), 1 always chained, 2 never
-    int deepk_variant = 0;     // k > 32 tiled scans: 0 = 4 waves per block, 1 = 8 waves per block (A/B hook)
     unsigned *outliers = nullptr; // device: rows outside the robust box (excluded from the filter, scanned exactly)
     unsigned n_outliers = 0;
     CellIndex *cells = nullptr;   // non-null: the layout is cell-sorted (ntiles counts its padded tiles)
@@ -164,8 +163,6 @@ struct FilterState {
     bool several_slots = false;   // a query has used a workspace slot other than 0: batches are in flight side by side
     int scan_deal = 0;            // pruned scan: 0 auto (block counter unless several_slots), 1 fixed deal, 2 items from a block counter
     int scan_blocks = 0;          // pruned scan, blocks per CU: 0 auto (one for small shards when several_slots, else two), 1, 2
-    int cells_variant = 0;        // A/B hook: 0 = prep + fused match/scan (default), 1 = round-2 kernels (fragments, seed,
-                                  // match, scan with LDS norms), 2 = prep + match + scan with MFMA norms
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
     // 15 % slower than back to back; only the small preparation kernels are meant to overlap.
@@ -183,14 +180,19 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r_d
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
                            unsigned **fill_out, bool one_pass = false);
 #endif
+// Sizes of one scan launch of the cell-pruned path (knn_cells.hip; host arithmetic only).
+struct CellScanPlan {
+    unsigned blocks = 0, nlists = 0, slice = 0, ovf_base = 0, ovf_cap = 0;
+    size_t lds_bytes = 0;
+};
+CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded);
 hipError_t knn_cells_place_rows(FilterState &st, const float *r_dev, const unsigned *code, unsigned *fill, unsigned *out,
                                 unsigned ocap, hipStream_t s);
 void knn_cells_free(CellIndex *&c);
 void knn_cells_workspace_free(FilterWorkspace &w);
 // One batch of <= KNN_CELL_BATCH queries already prepared by the filter's query-fragment kernel: seed, thresholds,
 // match, scan (records in w, as the full scan leaves them).  Asynchronous.
-// init_keys: the batch's keys are set to (+INF, 0) by the first kernel of the chain (variants 0 and 2).  Variant 0 folds
-// its answers into keys itself (no records left for a re-rank launch: w.nlists = 0).
+// init_keys: the batch's keys are set to (+INF, 0) by the first kernel of the chain.
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q_dev, const float *r_dev, long long base,
                            u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys);
 

@@ -1940,20 +1940,7 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         gx = (gx + 1) / 2;
     if ((size_t)gx * 4 * gy > kMaxLists)
         return hipErrorInvalidValue;
-    // `deepk` = 1 (A/B arm): the same kernel with 8 waves per block — each staged reference tile feeds 32 query
-    // tiles, half the L2 -> LDS traffic.  Measured equal to the 4-wave form (profiles/r02_c5_variants.txt).
-    const bool wide_scan = st.deepk_variant == 1 && KT <= 8;
-    unsigned wgy = (unsigned)((qtiles + 8 * QT - 1) / (8 * QT)), wgx = 1;
-    if (wide_scan) {
-        wgx = ((unsigned)num_cu * 4 + wgy - 1) / wgy;    // ~4 rounds of one block per CU
-        if ((long long)wgx > st.ntiles)
-            wgx = (unsigned)st.ntiles;
-        if (wgx < 1)
-            wgx = 1;
-        while ((size_t)wgx * 8 * wgy > kMaxLists && wgx > 1)
-            wgx = (wgx + 1) / 2;
-    }
-    w.nlists = wide_scan ? wgx * 8 * wgy : gx * 4 * gy;
+    w.nlists = gx * 4 * gy;
     w.slice = w.rec_cap / w.nlists;
 
     long long stride = st.ntiles / 256;
@@ -1996,32 +1983,15 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         FTRY(hipStreamWaitEvent(s, st.scan_done, 0));
     if (w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    // `deepk`: 0 = auto (k > 64: four reference tiles per barrier staged by LDS-DMA, -2.4 % at C5; else one), 1 = 8 waves per
-    // block, 2 / 4 = that many tiles per barrier, 3 = one tile per barrier (the round-2 kernel)
-    // (k > 128: one tile per barrier, 4 waves — a tile is 16 or 32 KiB there, four of them twice over do not fit the LDS)
-    const int tpb = KT > 8 ? 1 : st.deepk_variant == 2 ? 2 : (st.deepk_variant == 4 || (st.deepk_variant == 0 && KT == 8)) ? 4 : 1;
-    if constexpr (KT > 8) {
-        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+    // k > 64 (KT = 8): four reference tiles per barrier staged by LDS-DMA (-2.4 % at C5 against one tile per barrier through
+    // registers); k > 128: one tile per barrier — a tile is 16 or 32 KiB there, four of them twice over do not fit the LDS.
+    // (8 waves per block and two tiles per barrier were measured too: profiles/r02_c5_variants.txt, r03_deepk.txt.)
+    if constexpr (KT == 8)
+        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
                            (unsigned short *)(w.records + w.rec_cap));
-    } else if (tpb > 1 && !wide_scan) {
-        if (tpb == 2)
-            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 2>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                               (unsigned short *)(w.records + w.rec_cap));
-        else
-            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                               (unsigned short *)(w.records + w.rec_cap));
-    } else if (wide_scan) {
-        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, 512>), dim3(wgx, wgy), dim3(512), 0, s,
-                           (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                           1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                           (unsigned short *)(w.records + w.rec_cap));
-    } else
+    else
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
@@ -2111,24 +2081,18 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     w.ev_end = ev_end;
     if (cells) {
         FTRY(ensure_workspace(st, w, std::min(m, KNN_CELL_BATCH)));
-        const bool prep_inits = st.cells_variant != 1;   // the prep kernel starts the keys itself
-        if (init_keys && !prep_inits)
-            FTRY(knn_keys_fill_launch(keys, m, s));
         for (int q0 = 0; q0 < m; q0 += KNN_CELL_BATCH) {
             const int mb = std::min(KNN_CELL_BATCH, m - q0);
             const float *qb = q + (size_t)q0 * st.k;
             u64 *kb = keys + q0;
-            if (st.cells_variant == 1)
-                FTRY(prep_queries(st, w, mb, qb, s));
-            FTRY(knn_cells_query(st, w, mb, qb, r, base, kb, num_cu, q0 == 0, s, init_keys && prep_inits));
+            FTRY(knn_cells_query(st, w, mb, qb, r, base, kb, num_cu, q0 == 0, s, init_keys));   // (the prep kernel starts the keys)
             FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl_cur,
                                    kb, w.pieces, s, perm, w.ovf_base, w.ovf_cap));
             FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
             // gated on the device, both: the listed pairs exactly when the records overflowed, the whole shard when the
             // batch has a query nothing bounds
-            if (w.nlists != 0u)   // (0: the sweep arm re-ranked its hits itself: no record buffers to overflow)
-                FTRY(knn_cells_exact_launch(st.k, mb, base, qb, r, st.cells->items, st.cells->nitems, w.cell_counts, w.cell_lists,
-                                            st.cells->cap, perm, w.ctl_cur, kb, num_cu, s));
+            FTRY(knn_cells_exact_launch(st.k, mb, base, qb, r, st.cells->items, st.cells->nitems, w.cell_counts, w.cell_lists,
+                                        st.cells->cap, perm, w.ctl_cur, kb, num_cu, s));
             FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
         }
         return hipSuccess;

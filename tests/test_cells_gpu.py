@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells", "cells_variant", "scan_deal", "graphs", "cells_build"):
+    for name in ("path", "shards", "cells", "scan_deal", "cells_build"):
         pkg.set_option(name, 0)
 
 
@@ -170,28 +170,6 @@ def test_batches_longer_than_one_pass_and_single_queries(oracle):
         ix.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
-@pytest.mark.parametrize("k,dist", [(16, "uniform"), (16, "lattice"), (5, "copies"), (12, "queries_outside"), (8, "skewed")])
-def test_ab_arms_of_the_pruned_path_are_bit_exact_too(oracle, variant, k, dist):
-    """`cells_variant` 1 (the round-2 chain), 2 (MFMA norms in the scan) and 3 (prep + sweep) stay selectable for A/B
-    timing: they must answer like the default."""
-    m, n = 700, (1 << 17) + 99
-    rng = np.random.default_rng(k * 77 + variant)
-    Q, R = _cases(rng, dist, k, m, n)
-    want = oracle.v0(k, Q, R, threads=THREADS)
-    pkg.set_option("cells", 1)
-    pkg.set_option("cells_variant", variant)
-    try:
-        ix = pkg.KnnIndex(k, R)
-        got, st = _query(ix, Q)
-        ix.close()
-    finally:
-        pkg.set_option("cells", 0)
-        pkg.set_option("cells_variant", 0)
-    np.testing.assert_array_equal(got, want, err_msg=f"variant {variant} {dist} k={k} stats={st}")
-    assert st[0] == 4, st
-
-
 @pytest.mark.parametrize("deal", [1, 2], ids=["fixed_deal", "block_counter"])
 @pytest.mark.parametrize("k,dist,n", [(16, "uniform", (1 << 18) + 5), (16, "clustered", 1 << 17), (8, "lattice", (1 << 17) + 99),
                                       (16, "tight_clusters", 1 << 20), (16, "low_rank", 1 << 19)])
@@ -213,27 +191,6 @@ def test_both_ways_of_dealing_items_to_the_scan_waves_are_bit_exact(oracle, deal
         pkg.set_option("cells", 0)
         pkg.set_option("scan_deal", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"deal {deal} {dist} k={k} stats={st}")
-    assert st[0] == 4 and st[2] in (0, 2), st
-
-
-def test_the_sweep_arm_steps_aside_on_indexes_with_fat_cells(oracle):
-    """`cells_variant` 3 hands a cell to one wave: 2^18 copies of one point kept it busy for minutes (found by
-    tools/fuzz_parity.py).  Indexes whose largest cell holds more than 16x the average take the default chain instead —
-    including its exact evaluation of the listed cells when the records overflow."""
-    k, m, n = 8, 600, 1 << 18
-    rng = np.random.default_rng(9)
-    Q, R = _off_the_cube(rng, "one_point", k, m, n)
-    want = oracle.v0(k, Q, R, threads=THREADS)
-    pkg.set_option("cells", 1)
-    pkg.set_option("cells_variant", 3)
-    try:
-        ix = pkg.KnnIndex(k, R)
-        got, st = _query(ix, Q)
-        ix.close()
-    finally:
-        pkg.set_option("cells", 0)
-        pkg.set_option("cells_variant", 0)
-    np.testing.assert_array_equal(got, want)
     assert st[0] == 4 and st[2] in (0, 2), st
 
 
@@ -420,48 +377,6 @@ def test_c3_full_shape_every_query_against_the_oracle(oracle):
     assert st[0] == 4 and st[2] == 0, st
     want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
     np.testing.assert_array_equal(got, want)
-
-
-@pytest.mark.parametrize("slots", [1, 3])
-def test_graph_replay_of_a_batch_answers_like_the_launches_it_recorded(oracle, slots):
-    """Option `graphs`: the second call that repeats the previous call's arguments on a slot records the batch's launches
-    from the caller's stream, later ones replay them with one hipGraphLaunch.  Same buffers, NEW contents every round
-    (a serving loop): every answer is v0's; a batch with a NaN query still takes the gated exact scan inside the graph."""
-    k, m, n = 16, 777, 1 << 18
-    R = oracle.synth(n * k, 41)
-    dev = torch.device("cuda:0")
-    r_d = torch.from_numpy(R).to(dev)
-    pkg.set_option("cells", 1)
-    pkg.set_option("graphs", 1)
-    try:
-        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
-        q_d = [torch.empty((m, k), dtype=torch.float32, device=dev) for _ in range(slots)]
-        keys = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(slots)]
-        outs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(slots)]
-        before = pkg.get_option("graph_replays")
-        for rnd in range(7):
-            wants = []
-            for b in range(slots):
-                Q = oracle.synth(m * k, 1000 + 10 * rnd + b).reshape(m, k).copy()
-                if rnd == 5 and b == 0:
-                    Q[3, 2] = np.nan          # the whole batch falls back to the exact scan, on the device
-                wants.append(oracle.v0(k, Q, R, threads=THREADS))
-                q_d[b].copy_(torch.from_numpy(Q))
-            torch.cuda.synchronize()
-            for b in range(slots):
-                ix.query_keys(m, q_d[b].data_ptr(), keys[b].data_ptr(), stream=streams[b].cuda_stream, slot=b, init_keys=True)
-                pkg.keys_to_indices(keys[b].data_ptr(), m, outs[b].data_ptr(), stream=streams[b].cuda_stream)
-            torch.cuda.synchronize()
-            for b in range(slots):
-                np.testing.assert_array_equal(outs[b].cpu().numpy(), wants[b], err_msg=f"round {rnd} slot {b}")
-            st = ix.last_stats()
-            assert st[0] == 4 and st[2] == (1 if rnd == 5 and slots == 1 else st[2])
-        assert pkg.get_option("graph_replays") - before >= 3 * slots     # rounds 0 (and 1 after the slot switch) ran the ordinary way
-        ix.close()
-    finally:
-        pkg.set_option("cells", 0)
-        pkg.set_option("graphs", 0)
 
 
 @pytest.mark.parametrize("k,dist,n", [(16, "uniform", (1 << 18) + 77), (5, "clustered", 1 << 17), (12, "queries_outside", (1 << 17) + 4097),

@@ -76,14 +76,17 @@ def test_option_hooks_reject_unknown_names():
     with pytest.raises(pkg.KnnError):
         pkg.set_option("cells", 3)
     # round 3's switches: every legal value round-trips, the first illegal one is refused
-    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_variant", (1, 2, 3, 0)),
-                        ("graphs", (1, 0)), ("cells_build", (1, 0)), ("deepk", (1, 2, 3, 4, 0))):
+    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_build", (1, 0))):
         for v in legal:
             pkg.set_option(name, v)
             assert pkg.get_option(name) == v, name
         with pytest.raises(pkg.KnnError):
             pkg.set_option(name, max(legal) + 1)
-    assert pkg.get_option("graph_replays") >= 0
+    # round 3's experiment arms left the product library in round 4 (tools/arms/): their switches are gone with them
+    for name in ("cells_variant", "graphs", "deepk"):
+        with pytest.raises(pkg.KnnError):
+            pkg.set_option(name, 0)
+        assert pkg.get_option(name) == -1
 
 
 def test_product_does_not_link_or_reference_the_oracle():
@@ -108,7 +111,7 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
     hold v_sub/v_mul/v_add (or their packed forms), never an FMA."""
     found = 0
     # (a kernel's body runs to its .Lfunc_end label: kernels with early returns hold several s_endpgm)
-    for fname, pattern, least in (("knn_exact.hip", r"knn_exact|knn_rerank|knn_cells_exact", 13), ("knn_cells.hip", r"knn_cells_sweep", 1)):
+    for fname, pattern, least in (("knn_exact.hip", r"knn_exact|knn_rerank|knn_cells_exact", 13),):
         src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", fname)
         asm = tmp_path / (fname + ".s")
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
@@ -121,7 +124,7 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
             assert not bad, (name, bad[:3])
             assert re.search(r"v_(pk_)?mul_f32", body), name
             found += 1
-    assert found >= 14, found
+    assert found >= 13, found
 
 
 

@@ -917,13 +917,11 @@ def test_grid_index_is_the_resident_path_at_c2_scale_and_steps_aside_for_bad_dat
     assert path != 3
 
 
-@pytest.mark.parametrize("deepk", [1, 2, 3, 4], ids=["tiled_8_waves", "2_tiles_per_barrier_lds_dma", "1_tile_per_barrier_registers", "4_tiles_per_barrier_lds_dma"])
-def test_deep_k_scan_variants_behind_the_deepk_option_stay_bit_exact(oracle, deepk):
-    """The A/B arm of the deep-K scan that is kept selectable (8 waves per block; profiles/r02_c5_variants.txt:
-    no faster than the default 4-wave kernel) must give the same indices, row masks included."""
-    pkg.set_option("deepk", deepk)
+def test_deep_k_scan_is_bit_exact_on_ragged_shapes(oracle):
+    """The LDS-tiled scan for 32 < k <= 128 (four reference tiles per barrier by LDS-DMA above k = 64): indices and row
+    masks on shapes that leave tiles, query groups and K-steps ragged."""
     try:
-        for (k, m, n) in [(128, 2048, 40000), (100, 1000, 70001), (65, 600, 9000)]:
+        for (k, m, n) in [(128, 2048, 40000), (100, 1000, 70001), (65, 600, 9000), (40, 1500, 33333)]:
             Q, R = oracle.synth(m * k, 81), oracle.synth(n * k, 82)
             dev = torch.device("cuda:0")
             q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
@@ -941,7 +939,6 @@ def test_deep_k_scan_variants_behind_the_deepk_option_stay_bit_exact(oracle, dee
             np.testing.assert_array_equal(out.cpu().numpy(), oracle.v0(k, Q, R), err_msg=str((k, m, n)))
             assert st[0] in (2, 4) and st[2] == 0, st
     finally:
-        pkg.set_option("deepk", 0)
         pkg.set_option("path", 0)
 
 

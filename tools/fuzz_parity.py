@@ -121,8 +121,7 @@ def cells_case(o, rng, case):
         Q = (R[rng.integers(0, n, m)] + rng.normal(0, float(rng.choice([0.0, 1e-4, 1e-2])), (m, k))).astype(np.float32)
     else:
         Q = make_data(rng, kind, m, k)
-    variant, deal, blocks = int(rng.choice([0, 0, 0, 1, 2, 3])), int(rng.integers(0, 3)), int(rng.integers(0, 3))
-    pkg.set_option("cells_variant", variant)
+    deal, blocks = int(rng.integers(0, 3)), int(rng.integers(0, 3))
     pkg.set_option("scan_deal", deal)
     pkg.set_option("scan_blocks", blocks)
     Q2 = make_data(rng, "uniform" if kind in ("tight", "lowrank", "mixture", "onepoint") else str(rng.choice(["uniform", kind])), m, k)
@@ -132,7 +131,7 @@ def cells_case(o, rng, case):
         R[rng.integers(0, n), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3e38]))
     if rng.random() < 0.1:
         Q2[rng.integers(0, m), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, 1e30]))
-    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, variant=variant, deal=deal, blocks=blocks)
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, deal=deal, blocks=blocks)
     if os.environ.get("FUZZ_VERBOSE") == "1":
         print("case", desc, "%.1f s" % time.time(), flush=True)
     pkg.set_option("cells", 1)
@@ -167,7 +166,7 @@ def main():
             if case % 25 == 24:
                 print("%d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
     finally:
-        for name in ("path", "shards", "stream", "cells", "cells_variant", "scan_deal", "scan_blocks"):
+        for name in ("path", "shards", "stream", "cells", "scan_deal", "scan_blocks"):
             pkg.set_option(name, 0)
     print("all %d cases bit-exact (seed %d)" % (cases, seed))
     return 0
