@@ -121,7 +121,8 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
 
 /* The path's one exchange step, for callers that keep one index per GPU in ONE process: min-reduce the
  * GPUs' key arrays with RCCL — ncclAllReduce(ncclUint64, ncclMin) per device inside
- * ncclGroupStart/End over xGMI, communicators from ncclCommInitAll created once per device set.
+ * ncclGroupStart/End over xGMI, communicators from ncclCommInitAll created ONCE per process: the first call
+ * fixes the device list, a later call with another list returns KNN_EHIP (merge those keys on the host).
  * Replaces the reference's host gather + CPU re-rank (core.cu:925-957).
  *   devices[g]    HIP device of key array g (each device at most once)
  *   keys_dev[g]   m packed keys on devices[g]; on completion every array holds the elementwise
@@ -146,9 +147,11 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             where k <= 4 and the data allows it (else the exact kernels).  Auto: resident shards
  *             with k <= 4 and >= 16384 rows get the grid index at creation and are served by it
  *   "shards"  cudaCallback only: split the reference set into this many
- *             shards (0 = one per visible GPU).  Shards beyond the GPU count
- *             wrap around the devices — exercises the partition + merge logic
- *             on a single GPU.
+ *             shards.  0 = the library's rule: ONE GPU when n <= min(2^18, m << 10) (the reference's rule,
+ *             core.cu:871-872: every case of the TA harness), else as many of the visible GPUs as the cost
+ *             model says repay their fan-out (knn_debug_shard_policy; knn_get_option("last_shards") tells what the
+ *             most recent call used).  Shards beyond the GPU count wrap around the devices — exercises the
+ *             partition + merge logic on a single GPU.
  *   "filter_qt" tuning: query tiles (of 32) each filter wave keeps in registers: 8, 16 or 32
  *             (0 = chosen from m)
  *   "stream"  cudaCallback only: scan each shard chunk by chunk under its host-to-device copy
@@ -159,8 +162,10 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             MFMA layouts are built as soon as it has landed (robust box from a strided host
  *             sample), 1 = copy everything, then build (the box from full-range statistics)
  *   "rccl"    cudaCallback only: how the shards' keys are merged: 0 = RCCL all-reduce when the set
- *             is split over several GPUs (one shard each), host merge otherwise; 1 = RCCL always
- *             (also with one GPU: a 1-rank communicator); 2 = host merge always.
+ *             is split over ALL visible GPUs (one shard each), host merge otherwise (a process holds ONE
+ *             communicator set, for all its GPUs: knn_get_option("rccl_comm_sets") is 0 or 1); 1 = RCCL
+ *             whenever the shards are one per visible GPU (also with one GPU: a 1-rank communicator);
+ *             2 = host merge always.
  *             knn_get_option("rccl_reductions") counts the merges RCCL has done,
  *             knn_get_option("rccl_version") is the loaded library's NCCL_VERSION_CODE (0: none)
  *   "cells"   the MFMA filter's cell-pruned form (k <= 16): the index sorts the shard into 2^B cells (every
@@ -212,6 +217,16 @@ int knn_index_last_stats(knn_index *idx, long long stats[4]);
  * layout), [1] cells whose query list outgrew its on-chip room (scored against the whole batch instead),
  * [2] cells of the index, [3] rows of its largest cell. */
 int knn_index_debug_counters(knn_index *idx, long long out[4]);
+
+/* Test hook (host arithmetic only, no GPU needed): the number of GPUs a cudaCallback(k, m, n, ...) is split over on a
+ * node with ndev visible devices — the reference's rule (core.cu:865-872) plus the library's cost model. */
+int knn_debug_shard_policy(int k, int m, long long n, int ndev);
+
+/* Test hook (host arithmetic only, no GPU needed): every size one scan launch of the cell-pruned path and the re-rank behind
+ * it index with, for an index of `nitems` work items on a device of num_cu CUs and a batch of m <= 1024 queries:
+ * out = {scan blocks, record lists (= scan waves), records per list, first record of the shared overflow area, its
+ * capacity, dynamic LDS bytes of the scan, records a workspace holds, list counters a workspace holds}. */
+int knn_debug_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, int m, long long out[8]);
 
 /* Test hook for the filter's error bound: raw MFMA filter scores S[m][n_local] (row-major,
  * device) for a query batch, the fp32 squared norms M[m] of the fp16 query rows (device), and

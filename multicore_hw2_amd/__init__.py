@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
     "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim", "knn_keys_allreduce_min",
-    "knn_index_query_keys_ex", "knn_index_debug_counters",
+    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_shard_policy",
 ]
 QUERY_INIT_KEYS = 1   # KNN_QUERY_INIT_KEYS
 
@@ -109,6 +109,25 @@ def trim():
     f = lib().knn_trim
     f.restype = ctypes.c_longlong
     return int(f())
+
+
+def debug_shard_policy(k, m, n, ndev):
+    """knn_debug_shard_policy: GPUs a cudaCallback(k, m, n) uses on a node with ndev devices (host arithmetic)."""
+    f = lib().knn_debug_shard_policy
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+    rc = f(int(k), int(m), int(n), int(ndev))
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
+def debug_scan_plan(num_cu, blocks_per_cu, nitems, m):
+    """knn_debug_scan_plan: sizes of one scan launch of the cell-pruned path (host arithmetic; works without a GPU)."""
+    out = (ctypes.c_longlong * 8)()
+    f = lib().knn_debug_scan_plan
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
+    _check(f(int(num_cu), int(blocks_per_cu), int(nitems), int(m), out))
+    return dict(zip(("blocks", "nlists", "slice", "ovf_base", "ovf_cap", "lds_bytes", "rec_cap", "max_lists"), list(out)))
 
 
 def shard_bounds(n, shards):

@@ -76,6 +76,7 @@ std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
 std::atomic<long long> g_rccl_reductions{0}; // cudaCallback merges done by the RCCL all-reduce
+std::atomic<long long> g_last_shards{0};     // shards of the most recent cudaCallback (tests, KNN_MI355X_TRACE_CALL)
 
 struct DeviceGuard {
     int prev = -1;
@@ -408,6 +409,10 @@ long long knn_get_option(const char *name)
         return g_opt_cells_build;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
         return g_rccl_reductions;
+    if (name && !strcmp(name, "rccl_comm_sets"))    // read-only: RCCL communicator sets created by this process (at most one)
+        return knn_rccl_comm_sets();
+    if (name && !strcmp(name, "last_shards"))       // read-only: GPUs / shards the most recent cudaCallback was split over
+        return g_last_shards;
     if (name && !strcmp(name, "rccl_version"))      // read-only: NCCL_VERSION_CODE of the loaded RCCL, 0 if none
         return knn_rccl_version();
     return -1;
@@ -780,6 +785,23 @@ int knn_index_debug_counters(knn_index *idx, long long out[4])
     return KNN_OK;
 }
 
+int knn_debug_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, int m, long long out[8])
+{
+    if (!out || num_cu < 1 || blocks_per_cu < 1 || blocks_per_cu > 2 || m < 1 || m > KNN_CELL_BATCH)
+        return fail(KNN_EINVAL, "knn_debug_scan_plan: bad arguments");
+    const int m_padded = (m + 31) / 32 * 32;
+    const CellScanPlan p = knn_cells_scan_plan(num_cu, blocks_per_cu, nitems, KNN_RECORD_CAPACITY, m_padded);
+    out[0] = p.blocks;
+    out[1] = p.nlists;
+    out[2] = p.slice;
+    out[3] = p.ovf_base;
+    out[4] = p.ovf_cap;
+    out[5] = (long long)p.lds_bytes;
+    out[6] = KNN_RECORD_CAPACITY;
+    out[7] = KNN_MAX_LISTS;
+    return KNN_OK;
+}
+
 int knn_keys_to_indices(int device, const unsigned long long *keys_dev, int m, int *out_dev,
                         void *stream)
 {
@@ -975,6 +997,95 @@ int run_shard_streamed(int device, int k, int m, long long rows, long long base,
 
 }  // namespace
 
+namespace {
+
+// Cost model of ONE shard of a one-shot call (host rows in, keys out) on one MI355X: which of the three ways serves it
+// and what it is expected to take.  Constants measured on one box: pageable H2D 50-55 GB/s with ~0.25 ms of
+// fixed cost per copy call; exact kernels 58e12 lane-ops/s with a compile-time K (or m < 48), 45e12 / 22e12 with a run-time
+// k up to 64 / 128 (knn_exact_qregn), 5e12 on the row-per-lane kernels beyond; the MFMA filter ~3.4e-14 s per pair and
+// K-step plus its layouts (built under the copy unless option `ingest` = 1); the grid index (k <= 4) four passes over the
+// rows to build (~0.1 ms + 0.15 ns per row) and one wave per query.
+struct ShardPlan {
+    bool streamed = false;   // exact scan chunk by chunk under the copy (run_shard_streamed)
+    int want_filter = 0;     // staged: build the MFMA layouts
+    bool want_grid = false;  // staged: build the grid index (k <= 4)
+    int nchunks = 2;         // streamed: copy calls
+    double t_streamed = 0.0, t_staged = 0.0;
+    double seconds = 0.0;    // the chosen way
+};
+
+ShardPlan plan_shard(int k, int m, long long rows)
+{
+    ShardPlan p;
+    const double pairs = (double)m * (double)rows;
+    const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
+    const double exact_rate = (fast_k || m < 48) ? 58e12 : k <= 64 ? 45e12 : k <= 128 ? 22e12 : 5e12;
+    const double t_exact = (3.0 * k + 3.0) * pairs / exact_rate;
+    const int kt = knn_kt_of(k);   // 0: no fp16 layouts for this k (k > 4096)
+    const double t_filter = kt == 0 ? 1e30 : 1.0e-3 + 2.5 * 4.0 * k * (double)rows / 4e12 + 3.4e-14 * kt * pairs + 1e-4;
+    const double t_filter_under_copy = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // host rows: layouts built under the copy
+    p.want_filter = g_opt_path == 2 ||
+                    (g_opt_path == 0 && m >= 5 && kt != 0 && (g_opt_ingest == 1 ? t_filter : t_filter_under_copy) < t_exact);
+    // Third option: the exact scan chunk by chunk under the copy: costs the longer of the two plus one chunk's scan.  The
+    // staged alternatives pay the copy in one piece; the filter layouts are then built under the copy's tail
+    // (knn_filter_build_from_host), leaving the query itself.
+    const double bytes = 4.0 * k * (double)rows;
+    const double t_h2d = bytes / 52e9;
+    const double kCopyCall = 2.5e-4;
+    double nchunks = floor(sqrt(t_exact / kCopyCall) + 0.5);
+    nchunks = std::max(2.0, std::min(16.0, std::min(nchunks, floor(bytes / (double)(32u << 20)))));
+    p.nchunks = (int)nchunks;
+    p.t_streamed = std::max(t_h2d, t_exact) + t_exact / nchunks + kCopyCall * nchunks + 1e-4;
+    const double t_filter_query = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // layouts under the copy + query
+    const double t_query = p.want_filter ? (g_opt_ingest == 1 ? t_filter : t_filter_query) : t_exact;
+    const double t_grid = k <= 4 ? 1.5e-4 + 1.5e-10 * (double)rows + 2e-8 * m : 1e30;
+    p.want_grid = k <= 4 && (g_opt_path == 3 || (g_opt_path == 0 && rows >= 65536 && t_grid < t_query));
+    p.t_staged = t_h2d + kCopyCall + (p.want_grid ? t_grid : t_query);
+    p.streamed = g_opt_path != 2 && !p.want_grid && g_opt_stream != 1 && bytes >= (double)(64u << 20) &&
+                 (g_opt_stream == 2 || p.t_streamed < p.t_staged);
+    p.seconds = p.streamed ? p.t_streamed : p.t_staged;
+    return p;
+}
+
+// How many GPUs a one-shot call is split over (reference core.cu:865-872: every GPU, never more than n, ONE when
+// n <= min(2^18, m << 10) — which is every case of the TA harness).  Here the reference's small-n rule stands,
+// and beyond it the cost model decides: a call fans out over G GPUs when the shards' expected time (each GPU has its own
+// PCIe link and copies its own range) plus what fanning out costs — a host thread, an index create / query / destroy and
+// a share of the key exchange per GPU — is lowest; of the counts within 10 % of the best the smallest is taken.  The fan-out constants (0.2 ms + 0.02 ms per GPU)
+// are estimates: no multi-GPU node was available to measure them.
+int shard_policy(int k, int m, long long n, int ndev)
+{
+    long long cap = std::min<long long>(ndev, n);                           // core.cu:867-868
+    if (cap <= 1 || n <= std::min<long long>(1ll << 18, (long long)m << 10))   // core.cu:871-872
+        return 1;
+    // candidates: 1, 2, 4, ... and every visible GPU; of those within 10 % of the best, the fewest
+    std::vector<int> cand;
+    for (int g = 1; g < (int)cap; g *= 2)
+        cand.push_back(g);
+    cand.push_back((int)cap);
+    std::vector<double> t(cand.size(), 0.0);
+    double t_min = 1e30;
+    for (size_t i = 0; i < cand.size(); ++i) {
+        const int g = cand[i];
+        t[i] = plan_shard(k, m, (n + g - 1) / g).seconds + (g > 1 ? 2e-4 + 2e-5 * g : 0.0);
+        t_min = std::min(t_min, t[i]);
+    }
+    size_t pick = 0;
+    while (t[pick] > 1.1 * t_min)
+        ++pick;
+    const int best = cand[pick];
+    return best;
+}
+
+}  // namespace
+
+extern "C" int knn_debug_shard_policy(int k, int m, long long n, int ndev)
+{
+    if (k < 1 || m < 1 || n < 1 || ndev < 1)
+        return fail(KNN_EINVAL, "knn_debug_shard_policy: bad arguments");
+    return shard_policy(k, m, n, ndev);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The drop-in entry point (reference core.h:71, core.cu:1282-1297 -> v8, core.cu:856-958).
 // ---------------------------------------------------------------------------------------------
@@ -991,10 +1102,16 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         fail(KNN_ENODEV, "cudaCallback: no HIP device visible (this library has no CPU fallback)");
         die(__FILE__, __LINE__, KNN_ENODEV, g_err.c_str());
     }
-    // core.cu:865-868: one shard per GPU, never more shards than points.
-    long long shards = g_opt_shards > 0 ? (long long)g_opt_shards : (long long)ndev;
+    // core.cu:865-872: how many GPUs take part (never more shards than points; one GPU for the small sets of the TA
+    // harness; beyond that by the cost model: shard_policy).  Option `shards` forces a count (test hook).
+    long long shards = g_opt_shards > 0 ? (long long)g_opt_shards : (long long)shard_policy(k, m, n, ndev);
     if (shards > n)
         shards = n;
+    g_last_shards = shards;
+    static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
+    if (trace)
+        fprintf(stderr, "[knn call] k %d m %d n %d: %d GPU(s) visible -> %lld shard(s)%s\n", k, m, n, ndev, shards,
+                g_opt_shards > 0 ? " (option shards)" : "");
     // core.cu:875: thread_n = divup(n, num_gpus); the last shard takes what is left.  A shard
     // past the end is empty here (the reference patches it to one overlapping point,
     // core.cu:881-882; an empty shard gives the same minimum).
@@ -1008,8 +1125,10 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
     // (knn_rccl.cpp); device 0's copy comes back to the host.  More shards than devices (the single-GPU
     // test hook), a single device, `rccl` = 2, or no usable librccl: the keys come back per shard and are
     // min-merged on the host — the same unsigned minimum.
+    // ONE communicator set per process, for all visible devices (ncclCommInitAll takes seconds on an 8-GPU node): a call
+    // that uses fewer GPUs than are visible merges on the host instead of creating a second set.
     std::string rccl_why;
-    const bool rccl_wanted = g_opt_rccl != 2 && shards <= ndev && (g_opt_rccl == 1 || shards > 1);
+    const bool rccl_wanted = g_opt_rccl != 2 && shards == ndev && (g_opt_rccl == 1 || shards > 1);
     const bool use_rccl = rccl_wanted && knn_rccl_available(&rccl_why) != 0;
     if (rccl_wanted && !use_rccl && g_opt_rccl == 1) {
         fail(KNN_EHIP, "cudaCallback: option rccl = 1 but RCCL cannot be used", rccl_why.c_str());
@@ -1044,43 +1163,13 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
             return;
         }
         knn_index *idx = nullptr;
-        // One-shot call: the filter layouts cost two extra passes over the shard plus a few
-        // allocations, so build them only where that is cheaper than the exact VALU scan
-        // (~3.4e-14 s per filtered pair and K-step).
-        // Exact rates measured on MI355X (lane-ops/s): compile-time K 58e12; run-time k in chunks of 16
-        // (knn_exact_qregn) ~45e12 packed (k <= 64), ~22e12 one query per lane (k <= 128); beyond that,
-        // and for m < 48 at any k, the row-per-lane kernels.  The filter costs kt MFMAs per tile pair.
-        const double pairs = (double)m * (double)(hi - lo);
-        const bool fast_k = k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16;
-        const double exact_rate = (fast_k || m < 48) ? 58e12 : k <= 64 ? 45e12 : k <= 128 ? 22e12 : 5e12;
-        const double t_exact = (3.0 * k + 3.0) * pairs / exact_rate;
-        const int kt = knn_kt_of(k);   // 0: no fp16 layouts for this k (k > 4096)
-        const double t_filter = kt == 0 ? 1e30
-                                        : 1.0e-3 + 2.5 * 4.0 * k * (double)(hi - lo) / 4e12 + 3.4e-14 * kt * pairs + 1e-4;
-        const double t_filter_under_copy = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // host rows: layouts built under the copy
-        int want_filter = g_opt_path == 2 ||
-                          (g_opt_path == 0 && m >= 5 && kt != 0 && (g_opt_ingest == 1 ? t_filter : t_filter_under_copy) < t_exact);
-        static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
+        // which of the three ways serves this shard: plan_shard (cost model)
+        const ShardPlan plan = plan_shard(k, m, hi - lo);
+        const int want_filter = plan.want_filter;
+        const bool want_grid = plan.want_grid, streamed = plan.streamed;
+        const double t_streamed = plan.t_streamed, t_staged = plan.t_staged;
+        const double nchunks = plan.nchunks;
         const auto t0 = std::chrono::steady_clock::now();
-        // Third option: the exact scan chunk by chunk under the copy (pageable H2D measured at 50-55 GB/s,
-        // ~0.25 ms of fixed cost per copy call): costs the longer of the two plus one chunk's scan.  The
-        // staged alternatives pay the copy in one piece; the filter layouts are then built under the copy's
-        // tail (knn_filter_build_from_host), leaving the query itself.
-        const double bytes = 4.0 * k * (double)(hi - lo);
-        const double t_h2d = bytes / 52e9;
-        const double kCopyCall = 2.5e-4;
-        double nchunks = floor(sqrt(t_exact / kCopyCall) + 0.5);
-        nchunks = std::max(2.0, std::min(16.0, std::min(nchunks, floor(bytes / (double)(32u << 20)))));
-        const double t_streamed = std::max(t_h2d, t_exact) + t_exact / nchunks + kCopyCall * nchunks + 1e-4;
-        const double t_filter_query = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // layouts under the copy + query
-        const double t_staged = t_h2d + kCopyCall + (want_filter ? (g_opt_ingest == 1 ? t_filter : t_filter_query) : t_exact);
-        // k <= 4: the grid index — four passes over the rows to build (~0.1 ms + 0.15 ns per row measured at
-        // n = 2^20), then one wave per query — against the scans above
-        const double t_grid = k <= 4 ? 1.5e-4 + 1.5e-10 * (double)(hi - lo) + 2e-8 * m : 1e30;
-        const bool want_grid = k <= 4 && (g_opt_path == 3 || (g_opt_path == 0 && hi - lo >= 65536 &&
-                                                              t_grid < (want_filter ? t_filter_query : t_exact)));
-        const bool streamed = g_opt_path != 2 && !want_grid && g_opt_stream != 1 && bytes >= (double)(64u << 20) &&
-                              (g_opt_stream == 2 || t_streamed < t_staged);
         if (streamed) {
             const int rc = run_shard_streamed((int)(g % ndev), k, m, hi - lo, lo, searchPoints,
                                               referencePoints + (size_t)lo * (size_t)k, keys.data(), keep_dev, (int)nchunks);

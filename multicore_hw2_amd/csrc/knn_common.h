@@ -72,6 +72,8 @@ enum {
 };
 
 #define KNN_SLOTS 8  // independent query workspaces per index: up to eight batches may be in flight
+#define KNN_RECORD_CAPACITY (1u << 22)   // records a workspace holds (FilterWorkspace::records: 8 B each + 2 B row mask)
+#define KNN_MAX_LISTS (1u << 16)         // record lists (= scan waves) a workspace has counters for (FilterWorkspace::counts)
 
 // Per-batch scratch of the filter path (one per slot).
 struct FilterWorkspace {
@@ -221,6 +223,7 @@ void knn_grid_info(const GridState *gs, long long info[4]);
 #include <string>
 int knn_rccl_available(std::string *why);
 int knn_rccl_version();
+int knn_rccl_comm_sets();   // communicator sets this process has created (0 or 1)
 int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m, const hipStream_t *streams,
                            std::string &err, u64 *const *recv = nullptr);
 #endif

@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(64) void knn_filter_scores_rt_kernel(const h8 *__re
 // Host side.
 // ------------------------------------------------------------------------------------------
 
-static const unsigned kRecordCapacity = 1u << 22;  // 4M records = 32 MiB, split evenly over the waves
-static const unsigned kMaxLists = 1u << 16;
+static const unsigned kRecordCapacity = KNN_RECORD_CAPACITY;  // 4M records = 32 MiB, split evenly over the waves
+static const unsigned kMaxLists = KNN_MAX_LISTS;
 static const unsigned kSampleBlocks = 512;           // most blocks the sample pass uses (x 4 waves)
 
 void knn_filter_free(FilterState &st)

@@ -5,7 +5,7 @@
 // key[m] = (float_bits(d2) << 32) | global_index for its shard, and ONE
 // ncclAllReduce(ncclUint64, ncclMin) per GPU inside ncclGroupStart/End leaves the global answer on all of
 // them: unsigned order of the key = lexicographic (distance, index) = v0's first strict minimum.
-// Single process, one communicator per device (ncclCommInitAll), created once per device set.
+// Single process, one communicator per device (ncclCommInitAll), created ONCE per process.
 //
 // RCCL is opened with dlopen at first use, not linked: librccl.so is 570 MB, a single-GPU caller never
 // needs it, and a host program that already carries an RCCL (PyTorch bundles one under the same SONAME)
@@ -15,7 +15,6 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -37,7 +36,13 @@ struct RcclApi {
 std::mutex g_mu;
 RcclApi g_api;
 bool g_tried = false;
-std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;   // one communicator set per device list
+// ONE communicator set per process: ncclCommInitAll costs seconds on an 8-GPU node, and a caller that varied its device
+// list from call to call (the round-3 drop-in did: {0,1} for n = 2, {0..7} for larger sets) would pay that every time.
+// The first reduction fixes the device list; a later call with another list is refused (the drop-in then merges on the
+// host, index-API callers get the error).
+std::vector<int> g_comm_devs;
+std::vector<ncclComm_t> g_comms;
+int g_comm_sets = 0;   // communicator sets created so far (0 or 1): knn_get_option("rccl_comm_sets")
 
 bool load_api_locked()
 {
@@ -99,6 +104,12 @@ int knn_rccl_version()
     return 0;
 }
 
+int knn_rccl_comm_sets()
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return g_comm_sets;
+}
+
 // recv[g] (null array: keys[g] itself, in place) <- elementwise unsigned minimum over g of keys[g] (m packed keys on
 // devices[g]), enqueued on streams[g] (null = the device's default stream).  Returns 0, or -1 with a message in err;
 // with a separate recv the keys are never written, so a caller can still merge them another way after a failure.
@@ -117,17 +128,22 @@ int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m
         return -1;
     }
     const std::vector<int> devs(devices, devices + ndev);
-    auto it = g_comms.find(devs);
-    if (it == g_comms.end()) {
+    if (g_comms.empty()) {
         std::vector<ncclComm_t> comms((size_t)ndev);
         const ncclResult_t r = g_api.CommInitAll(comms.data(), ndev, devs.data());
         if (r != ncclSuccess) {
             err = std::string("ncclCommInitAll: ") + g_api.GetErrorString(r);
             return -1;
         }
-        it = g_comms.emplace(devs, std::move(comms)).first;
+        g_comms = std::move(comms);
+        g_comm_devs = devs;
+        ++g_comm_sets;
+    } else if (devs != g_comm_devs) {
+        err = "this process already holds an RCCL communicator set for another device list (one set per process: "
+              "reduce over the same GPUs every time, or merge the keys on the host)";
+        return -1;
     }
-    const std::vector<ncclComm_t> &comms = it->second;
+    const std::vector<ncclComm_t> &comms = g_comms;
     int prev = -1;
     (void)hipGetDevice(&prev);
     ncclResult_t r = g_api.GroupStart();

@@ -109,3 +109,39 @@ def test_norm_kept_as_two_fp16_halves_is_within_the_allowance_rho_carries():
     assert (s32.astype(np.float64) == back).all()
     # what rho allows
     assert (np.maximum(err, err_flush) <= 2.0 ** -21 * 16.0 + 2.0 ** -24).all()
+
+
+# ---- sizes of the scan launch (every size the kernels index with, checked on the CPU) -------------
+CELL_SCAN_WAVES, CELL_TILES_PER_PASS = 12, 9          # knn_cells.hip
+DEFAULT_DYNAMIC_LDS_LIMIT = 64 * 1024                 # what a launch may ask for without hipFuncSetAttribute
+
+
+@pytest.mark.parametrize("m", [1, 31, 1000, 1024])     # (longer batches run as passes of <= 1024: 1025 = 1024 + 1, 4096 = 4 x 1024)
+@pytest.mark.parametrize("cells_log2", [9, 13, 14, 15, 16])
+@pytest.mark.parametrize("blocks_per_cu", [1, 2])
+@pytest.mark.parametrize("num_cu", [256, 304, 8])
+def test_scan_launch_sizes_fit_the_buffers_the_kernels_index(m, cells_log2, blocks_per_cu, num_cu):
+    """knn_cells_scan_plan is the one place the scan grid, the record lists, the shared overflow area and the dynamic LDS of
+    a batch are sized; the scan, the prep kernel's counter reset and the re-rank all index with these numbers."""
+    import multicore_hw2_amd as pkg
+    for nitems in (1 << cells_log2, (1 << cells_log2) * 3 + 7, 5, 1):     # uniform data, fat cells cut into several items, tiny
+        p = pkg.debug_scan_plan(num_cu, blocks_per_cu, nitems, m)
+        m_padded = (m + 31) // 32 * 32
+        assert 1 <= p["blocks"] <= num_cu * blocks_per_cu
+        assert p["nlists"] == p["blocks"] * CELL_SCAN_WAVES
+        assert p["nlists"] <= p["max_lists"]                              # counts[nlists], zeroed by the prep kernel
+        assert p["nlists"] <= max(nitems, CELL_SCAN_WAVES)                # never more waves than items (one block at least)
+        assert p["slice"] >= 1 and p["nlists"] * p["slice"] <= p["ovf_base"]   # the waves' slices end where the shared area starts
+        assert p["ovf_base"] + p["ovf_cap"] == p["rec_cap"]               # ... which ends with the buffer
+        assert p["ovf_cap"] * 16 < 1 << 32                                # the re-rank numbers (record, row) pairs in 32 bits
+        # dynamic LDS: B operands (32 B) + thresholds (4 B) per padded query, one norm window of 9 tiles x 8 float4 per wave
+        assert p["lds_bytes"] == m_padded * 36 + CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * 16
+        assert p["lds_bytes"] + 4 * (3 * 256 + 8) <= DEFAULT_DYNAMIC_LDS_LIMIT   # + the kernel's static tables
+        assert p["lds_bytes"] % 16 == 0 and (m_padded * 36) % 16 == 0     # the window is read with ds_read_b128
+
+
+def test_scan_plan_refuses_batches_longer_than_one_pass():
+    import multicore_hw2_amd as pkg
+    for bad in ((256, 2, 100, 1025), (256, 3, 100, 64), (0, 1, 100, 64), (256, 1, 100, 0)):
+        with pytest.raises(pkg.KnnError):
+            pkg.debug_scan_plan(*bad)

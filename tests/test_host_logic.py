@@ -373,6 +373,42 @@ def test_drop_in_entry_prints_the_reference_error_line_and_exits_1():
         assert m and "code:-2" in m.group(0) and "no CPU fallback" in m.group(0), r.stdout
 
 
+TA_SHAPES = [(3, 1, 2), (3, 2, 8), (3, 1, 1024), (3, 1, 65536), (16, 1, 65536), (3, 1024, 1024), (3, 1024, 65536),
+             (16, 1024, 65536)]      # reference main.cu:28-39
+
+
+def test_shard_count_policy_of_the_drop_in_on_a_faked_eight_gpu_node():
+    """VERDICT r03 item 2.  The reference sends n <= min(2^18, m << 10) to ONE GPU (core.cu:871-872) — every case of the TA
+    harness — and never uses more GPUs than points (core.cu:867-868); round 3 fanned every call out over every visible
+    GPU.  knn_debug_shard_policy is the function cudaCallback asks (host arithmetic: no GPU needed)."""
+    _built_lib()
+    import multicore_hw2_amd as pkg
+    for ndev in (1, 2, 4, 8):
+        for (k, m, n) in TA_SHAPES:
+            assert pkg.debug_shard_policy(k, m, n, ndev) == 1, (k, m, n, ndev)
+    # the reference's threshold itself, at its edge
+    for (k, m, n) in [(16, 1024, 1 << 18), (16, 100, 100 << 10), (3, 1, 1024)]:
+        assert pkg.debug_shard_policy(k, m, n, 8) == 1, (k, m, n)
+    # the metric's shape and C4's: PCIe-bound on one GPU, every GPU's own link is worth having
+    for ndev in (1, 2, 4, 8):
+        assert pkg.debug_shard_policy(16, 1024, 1 << 24, ndev) == ndev
+        assert pkg.debug_shard_policy(16, 1024, 1 << 27, ndev) == ndev
+    # C2 (12 MiB of rows): a second GPU does not repay its fan-out on a two-GPU node; C5 (32 MiB, one 1 ms scan): never
+    assert pkg.debug_shard_policy(3, 1024, 1 << 20, 2) == 1
+    assert pkg.debug_shard_policy(128, 65536, 65536, 8) == 1
+    # never more shards than GPUs, a power of two or all of them, and more GPUs never lead to fewer shards
+    for (k, m, n) in [(16, 1024, 1 << 22), (3, 1, 1 << 24), (16, 100, 1 << 19), (64, 5000, 300000), (16, 1024, 5)]:
+        prev = 0
+        for ndev in range(1, 9):
+            g = pkg.debug_shard_policy(k, m, n, ndev)
+            assert 1 <= g <= min(ndev, n)
+            assert g == ndev or g & (g - 1) == 0, (k, m, n, ndev, g)
+            assert g >= prev or g == ndev, (k, m, n, ndev, g, prev)
+            prev = g
+    assert pkg.lib().knn_debug_shard_policy(0, 1, 1, 1) == -1
+    assert pkg.get_option("rccl_comm_sets") == 0 and pkg.get_option("last_shards") == 0   # nothing has run in this process
+
+
 def test_rccl_entry_point_validates_its_arguments_without_a_gpu():
     """knn_keys_allreduce_min: argument errors come back as KNN_EINVAL before RCCL is touched; librccl itself
     is opened lazily (the version query either finds it or returns 0, never raises)."""

@@ -687,6 +687,38 @@ def test_rccl_exchange_step_with_a_one_device_communicator(oracle):
             pkg.set_option(name, 0)
 
 
+def test_ta_sequence_uses_one_gpu_per_call_and_at_most_one_communicator_set(oracle, capfd):
+    """the TA harness' eight samples (n = 2, 8, 1024, 65536, ...) in sequence.  Round 3 fanned each of them
+    out over every visible GPU and kept one RCCL communicator set per device list it met ({0, 1} for n = 2, {0..7} after).
+    Now: every TA sample is one shard (the reference's rule, core.cu:871-872), the trace line says so, and however the
+    calls vary the process holds at most ONE communicator set — also with rccl = 1 forcing the exchange step."""
+    os.environ["KNN_MI355X_TRACE_CALL"] = "1"    # (read once per process: set before the first cudaCallback of the suite matters
+    try:                                         #  only for the trace assertion below, which is skipped when it came too late)
+        for rccl in (0, 1):
+            pkg.set_option("rccl", rccl)
+            for i, (k, m, n, Q, R) in enumerate(oracle.ta_samples()):
+                np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0_serial(k, Q, R), err_msg=f"TA sample {i}")
+                assert pkg.get_option("last_shards") == 1, (i, k, m, n)
+                assert pkg.get_option("rccl_comm_sets") <= 1
+        # a large one-shot call on this node: every visible GPU (here: the one there is)
+        k, m, n = 16, 64, 1200001
+        Q, R = oracle.synth(m * k, 51), oracle.synth(n * k, 52)
+        np.testing.assert_array_equal(pkg.cudaCallback(k, m, n, Q, R), oracle.v0(k, Q, R))
+        assert pkg.get_option("last_shards") == pkg.debug_shard_policy(k, m, n, pkg.device_count())
+        assert pkg.get_option("rccl_comm_sets") <= 1
+        # a reduction over another device list than the process' set is refused, not answered with a second set
+        if pkg.get_option("rccl_comm_sets") == 1 and pkg.device_count() > 1:
+            keys = torch.zeros(8, dtype=torch.int64, device=torch.device("cuda:1"))
+            with pytest.raises(pkg.KnnError):
+                pkg.keys_allreduce_min([1], [keys.data_ptr()], 8)
+        err = capfd.readouterr().err
+        if "[knn call]" in err:
+            assert "-> 1 shard(s)" in err
+    finally:
+        del os.environ["KNN_MI355X_TRACE_CALL"]
+        pkg.set_option("rccl", 0)
+
+
 def test_a_failing_rccl_reduction_falls_back_to_the_host_merge(oracle):
     """in the automatic mode a run-time RCCL failure (communicator creation on a node it does not
     like, a failed collective) must not end the process — the reduction writes to scratch buffers, so the shards' keys are
