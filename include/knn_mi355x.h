@@ -91,6 +91,47 @@ int knn_index_create(knn_index **out, int device, int k, long long n_local, cons
                      int refs_on_device, long long base_index, void *stream);
 void knn_index_destroy(knn_index *idx);
 
+/* ------------------------------------------------------------------------
+ * 2b. Cell-range shards (round 4): how a caller with several GPUs (one process per GPU, or one index per GPU in one process)
+ *     splits the reference set so that the GPUs' scans ADD UP to the scan of one GPU holding everything.
+ *     The reference splits by index range (core.cu:875-883) and so does cudaCallback here — rows arrive in the caller's
+ *     order.  For a resident set that costs work: each range is gridded by itself at 1 / N of the resolution, and the ranks
+ *     together score 3.5x the (cell, query) pairs of one GPU at N = 8 (profiles/r04_shard_sim.txt).  Instead:
+ *       1. every rank takes a strided sample of its rows; the samples are gathered (a few hundred KB) and
+ *          knn_geom_create builds ONE grid from them — identical input, identical grid on every rank;
+ *       2. knn_geom_assign says which rank's cell range each row falls into; the caller moves the rows there (one
+ *          all-to-all at build time, not on the query path) together with their global numbers, ascending per rank;
+ *       3. knn_index_create_sharded sorts a rank's rows into ITS cells of the global grid;
+ *       4. knn_index_seed_export writes the first few tiles of each of the rank's cells into its part of a buffer of
+ *          knn_geom_info()[5] bytes; the caller all-gathers the parts and hands the whole layer to knn_index_seed_attach
+ *          (replicated: 151 MB for 2^16 cells).  A query bounds its answer from 16 seed cells around it — this rank's
+ *          whole, the others' through the layer — so a rank prunes almost as if it saw everybody's rows.
+ *     Queries, keys and the exchange step (min over the ranks' keys) are the same calls as for index-range shards: the
+ *     keys carry global row numbers (gids) when the batch's last kernel has run.
+ * ---------------------------------------------------------------------- */
+typedef struct knn_geom knn_geom;
+/* sample_host: samples x k floats, rows of the GLOBAL set (>= 64; a few thousand is plenty); seed_tiles: tiles of every cell
+ * in the replicated layer (0 = 2).  KNN_EINVAL when the set does not suit (k > 16, too few rows per rank, degenerate sample). */
+int knn_geom_create(knn_geom **out, int k, long long n_global, int nranks, const float *sample_host, long long samples,
+                    int seed_tiles);
+void knn_geom_destroy(knn_geom *g);
+/* out = {bits of the global grid, its cells, cells per rank, seed tiles per cell, bytes of one rank's part of the seed layer,
+ * bytes of the whole layer, bits of the low pruning table, ranks} */
+int knn_geom_info(const knn_geom *g, long long out[8]);
+/* First cell code of `rank`'s range (rank = the number of ranks: the number of cells); ranges start at multiples of 2^sa. */
+long long knn_geom_first_cell(const knn_geom *g, int rank);
+/* owner_dev[i] = rank whose cell range holds rows_dev[i] (device arrays on `device`; synchronous on return). */
+int knn_geom_assign(const knn_geom *g, int device, const float *rows_dev, long long n, int *owner_dev, void *stream);
+/* refs_dev: the rank's rows (device, borrowed); gids_dev[i]: global row number of refs_dev[i], STRICTLY ASCENDING, < 2^31
+ * (device, borrowed) — v0's lowest-index tie-break is decided by local row order.  KNN_EINVAL when a row lies outside the
+ * rank's cell range of the geometry.  The index must be given the seed layer (export on every rank, gather, attach) before
+ * it is queried by more than one rank's worth of queries: without it the bound comes from the rank's own cells only —
+ * still exact, only slower. */
+int knn_index_create_sharded(knn_index **out, int device, const knn_geom *g, int rank, long long n_local, const float *refs_dev,
+                             const unsigned *gids_dev, void *stream);
+int knn_index_seed_export(knn_index *idx, void *layer_dev, void *stream);   /* this rank's part, in place in the whole-layer buffer */
+int knn_index_seed_attach(knn_index *idx, const void *layer_dev);           /* the gathered layer (borrowed until destroy) */
+
 /* Fill keys_dev[0..m) with KNN_KEY_INIT (async on stream). */
 int knn_keys_init(int device, unsigned long long *keys_dev, int m, void *stream);
 
@@ -118,6 +159,14 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
 #define KNN_QUERY_INIT_KEYS 1u
 int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *queries_dev,
                             unsigned long long *keys_dev, void *stream, unsigned flags);
+
+/* Same, and ALSO the int32 indices of the batch: indices_dev[j] = (int)(keys_dev[j] & 0xFFFFFFFF) once the shard's answer has
+ * been folded in (indices_dev may be NULL: then exactly knn_index_query_keys_ex).  For a caller whose answer is this one
+ * shard's (one GPU holds the whole set): on the cell-pruned path the indices are written by the last block of the batch's
+ * last kernel, so the batch costs no knn_keys_to_indices launch; the other paths issue that launch themselves.  Callers that
+ * merge several shards' keys first (min over shards / GPUs) pass NULL and unpack after the merge. */
+int knn_index_query(knn_index *idx, int slot, int m, const float *queries_dev, unsigned long long *keys_dev,
+                    int *indices_dev, void *stream, unsigned flags);
 
 /* The path's one exchange step, for callers that keep one index per GPU in ONE process: min-reduce the
  * GPUs' key arrays with RCCL — ncclAllReduce(ncclUint64, ncclMin) per device inside

@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-__all__ = ["lib", "lib_path", "cudaCallback", "KnnIndex", "KnnError", "KEY_INIT", "set_option",
+__all__ = ["lib", "lib_path", "cudaCallback", "KnnIndex", "KnnGeom", "KnnError", "KEY_INIT", "set_option",
            "get_option", "trim", "device_count", "EXPORTED_SYMBOLS", "shard_bounds"]
 
 KEY_INIT = 0x7F80000000000000
@@ -28,7 +28,9 @@ EXPORTED_SYMBOLS = [
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
     "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim", "knn_keys_allreduce_min",
-    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_shard_policy",
+    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_shard_policy", "knn_index_query",
+    "knn_geom_create", "knn_geom_destroy", "knn_geom_info", "knn_geom_assign", "knn_index_create_sharded",
+    "knn_index_seed_export", "knn_index_seed_attach", "knn_geom_first_cell",
 ]
 QUERY_INIT_KEYS = 1   # KNN_QUERY_INIT_KEYS
 
@@ -73,6 +75,7 @@ def lib():
     L.knn_index_query_keys.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     L.knn_index_query_keys_slot.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp]
     L.knn_index_query_keys_ex.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint]
+    L.knn_index_query.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_uint]
     L.knn_keys_to_indices.argtypes = [c_int, c_vp, c_int, c_vp, c_vp]
     L.knn_index_query_host.argtypes = [c_vp, c_int, c_vp, c_vp]
     L.knn_set_option.argtypes = [ctypes.c_char_p, c_ll]
@@ -83,6 +86,14 @@ def lib():
     L.knn_index_timing.argtypes = [c_vp, c_int]
     L.knn_debug_filter_scores.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_double)]
     L.knn_index_timing_read.argtypes = [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]
+    L.knn_geom_create.argtypes = [ctypes.POINTER(c_vp), c_int, c_ll, c_int, c_vp, c_ll, c_int]
+    L.knn_geom_destroy.argtypes = [c_vp]
+    L.knn_geom_destroy.restype = None
+    L.knn_geom_info.argtypes = [c_vp, ctypes.POINTER(c_ll)]
+    L.knn_geom_assign.argtypes = [c_vp, c_int, c_vp, c_ll, c_vp, c_vp]
+    L.knn_index_create_sharded.argtypes = [ctypes.POINTER(c_vp), c_int, c_vp, c_int, c_ll, c_vp, c_vp, c_vp]
+    L.knn_index_seed_export.argtypes = [c_vp, c_vp, c_vp]
+    L.knn_index_seed_attach.argtypes = [c_vp, c_vp]
     _lib = L
     return L
 
@@ -162,8 +173,63 @@ def cudaCallback(k, m, n, searchPoints, referencePoints):
     return out
 
 
+class KnnGeom:
+    """Global grid of a cell-range sharded set (knn_geom_* in include/knn_mi355x.h): built from a sample of the GLOBAL set,
+    identical on every rank that passes the same sample.  Host arithmetic only: works without a GPU (assign needs one)."""
+
+    def __init__(self, k, n_global, nranks, sample, seed_tiles=0):
+        self._h = ctypes.c_void_p()
+        s = np.ascontiguousarray(sample, dtype=np.float32).reshape(-1)
+        self.k, self.nranks = int(k), int(nranks)
+        _check(lib().knn_geom_create(ctypes.byref(self._h), self.k, int(n_global), self.nranks,
+                                     s.ctypes.data_as(ctypes.c_void_p), s.size // self.k, int(seed_tiles)))
+        out = (ctypes.c_longlong * 8)()
+        _check(lib().knn_geom_info(self._h, out))
+        (self.bits, self.ncells, self.cells_per_rank, self.seed_tiles, self.part_bytes, self.layer_bytes, self.sa, _) = list(out)
+
+    def first_cell(self, rank):
+        f = lib().knn_geom_first_cell
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        f.restype = ctypes.c_longlong
+        return int(f(self._h, int(rank)))
+
+    def assign(self, rows_dev, n, owner_dev, device=0, stream=0):
+        """owner_dev[i] (int32, device) = rank whose cell range holds row i of rows_dev."""
+        _check(lib().knn_geom_assign(self._h, int(device), ctypes.c_void_p(int(rows_dev)), int(n),
+                                     ctypes.c_void_p(int(owner_dev)), ctypes.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib().knn_geom_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class KnnIndex:
     """Device-resident shard of the reference set (knn_index_* in include/knn_mi355x.h)."""
+
+    @classmethod
+    def sharded(cls, geom, rank, refs_dev, gids_dev, n_local, device=0, stream=0):
+        """A cell-range shard (knn_index_create_sharded): this rank's rows of the global grid `geom` (device pointers;
+        gids strictly ascending).  Give it the seed layer (seed_export on every rank, gather, seed_attach) before querying."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.k, self.device, self.base, self.n, self._keep = geom.k, int(device), 0, int(n_local), None
+        _check(lib().knn_index_create_sharded(ctypes.byref(self._h), self.device, geom._h, int(rank), self.n,
+                                              ctypes.c_void_p(int(refs_dev)), ctypes.c_void_p(int(gids_dev)),
+                                              ctypes.c_void_p(stream)))
+        return self
+
+    def seed_export(self, layer_dev, stream=0):
+        _check(lib().knn_index_seed_export(self._h, ctypes.c_void_p(int(layer_dev)), ctypes.c_void_p(stream)))
+
+    def seed_attach(self, layer_dev):
+        _check(lib().knn_index_seed_attach(self._h, ctypes.c_void_p(int(layer_dev))))
 
     def __init__(self, k, refs, n_local=None, device=0, base_index=0, refs_on_device=False, stream=0):
         self._h = ctypes.c_void_p()
@@ -186,11 +252,16 @@ class KnnIndex:
                                       1 if refs_on_device else 0, self.base, ctypes.c_void_p(stream)))
         self._keep = None
 
-    def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0, init_keys=False):
+    def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0, init_keys=False, indices_dev=None):
         """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m].
         slot 0..7 picks one of the index's eight independent query workspaces.  init_keys: the call starts the
-        keys at (+INF, 0) itself (KNN_QUERY_INIT_KEYS) instead of folding into what keys_dev holds."""
-        if init_keys:
+        keys at (+INF, 0) itself (KNN_QUERY_INIT_KEYS) instead of folding into what keys_dev holds.
+        indices_dev: also write the int32 indices there (knn_index_query: no separate knn_keys_to_indices launch)."""
+        if indices_dev is not None:
+            _check(lib().knn_index_query(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
+                                         ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(int(indices_dev)),
+                                         ctypes.c_void_p(stream), QUERY_INIT_KEYS if init_keys else 0))
+        elif init_keys:
             _check(lib().knn_index_query_keys_ex(self._h, int(slot), int(m), ctypes.c_void_p(int(queries_dev)),
                                                  ctypes.c_void_p(int(keys_dev)), ctypes.c_void_p(stream), QUERY_INIT_KEYS))
         else:

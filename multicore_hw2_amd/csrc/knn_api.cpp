@@ -259,6 +259,9 @@ struct knn_index {
     size_t events_used = 0;
     int last_slot = 0;
     bool filter_wanted = false;  // the creator asked for the filter layouts explicitly (one-shot cost model)
+    bool sharded = false;        // a cell-range shard (knn_index_create_sharded): always served by the cell-pruned path
+    ShardGeom geom;              // its copy of the global grid (filter.cells->geom points here)
+    int rank = 0;
     // Calls on one index from several host threads are serialised (enqueueing a batch is ~20 us of host work; the GPU
     // work of different slots still overlaps): the workspaces' lazily grown buffers, the event list, the statistics and
     // the chain events are plain members.  Recursive: knn_index_query_host calls the keyed entry points.
@@ -550,6 +553,178 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Cell-range shards (round 4): one global grid, every rank holds a contiguous range of its cell codes.
+// ---------------------------------------------------------------------------------------------
+struct knn_geom {
+    ShardGeom g;
+};
+
+extern "C" {
+
+int knn_geom_create(knn_geom **out, int k, long long n_global, int nranks, const float *sample_host, long long samples,
+                    int seed_tiles)
+{
+    if (!out)
+        return fail(KNN_EINVAL, "knn_geom_create: null out");
+    *out = nullptr;
+    if (k < 1 || n_global < 1 || nranks < 1 || !sample_host || samples < 1 || seed_tiles < 0)
+        return fail(KNN_EINVAL, "knn_geom_create: bad arguments");
+    knn_geom *g = new (std::nothrow) knn_geom();
+    if (!g)
+        return fail(KNN_ENOMEM, "knn_geom_create: out of host memory");
+    if (!knn_geom_from_sample(g->g, k, n_global, nranks, sample_host, samples, seed_tiles == 0 ? 2 : seed_tiles)) {
+        delete g;
+        return fail(KNN_EINVAL, "knn_geom_create: the set does not suit cell-range shards (k > 16, fewer than 512 cells of >= 144 "
+                                "rows per rank, fewer than 64 sample rows, or a sample that is not finite / has no extent): "
+                                "shard by index range instead (knn_index_create with base_index)");
+    }
+    *out = g;
+    return KNN_OK;
+}
+
+void knn_geom_destroy(knn_geom *g) { delete g; }
+
+int knn_geom_info(const knn_geom *g, long long out[8])
+{
+    if (!g || !out)
+        return fail(KNN_EINVAL, "knn_geom_info: bad arguments");
+    out[0] = g->g.bits;
+    out[1] = g->g.ncells;
+    out[2] = g->g.cells_per_rank;
+    out[3] = g->g.seed_tiles;
+    out[4] = (long long)g->g.part_bytes();
+    out[5] = (long long)g->g.part_bytes() * g->g.nranks;
+    out[6] = g->g.sa;
+    out[7] = g->g.nranks;
+    return KNN_OK;
+}
+
+long long knn_geom_first_cell(const knn_geom *g, int rank)
+{
+    if (!g || rank < 0)
+        return fail(KNN_EINVAL, "knn_geom_first_cell: bad arguments");
+    return (long long)g->g.first_cell(rank);   // (rank >= ranks: the number of cells)
+}
+
+int knn_geom_assign(const knn_geom *g, int device, const float *rows_dev, long long n, int *owner_dev, void *stream)
+{
+    if (!g || n < 0 || (n > 0 && (!rows_dev || !owner_dev)))
+        return fail(KNN_EINVAL, "knn_geom_assign: bad arguments");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_geom_assign: hipSetDevice failed");
+    HIP_TRY(knn_geom_assign_launch(g->g, rows_dev, n, owner_dev, (hipStream_t)stream));
+    return KNN_OK;
+}
+
+int knn_index_create_sharded(knn_index **out, int device, const knn_geom *g, int rank, long long n_local, const float *refs_dev,
+                             const unsigned *gids_dev, void *stream)
+{
+    if (!out)
+        return fail(KNN_EINVAL, "knn_index_create_sharded: null out");
+    *out = nullptr;
+    if (!g || rank < 0 || rank >= g->g.nranks || n_local < 0 || (n_local > 0 && (!refs_dev || !gids_dev)))
+        return fail(KNN_EINVAL, "knn_index_create_sharded: bad geometry, rank, n_local or pointers");
+    const int ndev = knn_device_count();
+    if (ndev < 1)
+        return fail(KNN_ENODEV, "knn_index_create_sharded: no HIP device visible");
+    if (device < 0 || device >= ndev)
+        return fail(KNN_EINVAL, "knn_index_create_sharded: device out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(KNN_EHIP, "knn_index_create_sharded: hipSetDevice failed");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_local > 0) {
+        // the rows' global numbers: strictly ascending (ties between equal distances are decided by LOCAL row order inside
+        // the shard, which then is global order) and inside int32 (results are int)
+        unsigned bad = 0u, last = 0u;
+        HIP_TRY(knn_gids_check(gids_dev, n_local, &bad, s));
+        HIP_TRY(hipMemcpy(&last, gids_dev + (n_local - 1), sizeof last, hipMemcpyDeviceToHost));
+        if (bad != 0u || last > 0x7FFFFFFFu)
+            return fail(KNN_EINVAL, "knn_index_create_sharded: gids must be strictly ascending and below 2^31");
+    }
+    knn_index *idx = new (std::nothrow) knn_index();
+    if (!idx)
+        return fail(KNN_ENOMEM, "knn_index_create_sharded: out of host memory");
+    idx->device = device;
+    idx->k = g->g.k;
+    idx->n = n_local;
+    idx->base = 0;   // keys carry LOCAL rows until the batch's last kernel translates them through gids
+    idx->sharded = true;
+    idx->geom = g->g;
+    idx->rank = rank;
+    idx->refs = refs_dev;
+    idx->filter_wanted = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        idx->num_cu = prop.multiProcessorCount;
+    if (n_local > 0) {
+        unsigned bad_rows = 0u;
+        const hipError_t e = knn_filter_build(idx->filter, idx->k, n_local, refs_dev, s, g_opt_cells_build == 1 ? 2 : 1, &idx->geom,
+                                              rank, &bad_rows);
+        if (e != hipSuccess || !idx->filter.usable || !idx->filter.cells) {
+            char why[160];
+            if (bad_rows != 0u)
+                snprintf(why, sizeof why, "%u row(s) lie outside rank %d's cell range of this geometry (knn_geom_assign says where rows belong)",
+                         bad_rows, rank);
+            else
+                snprintf(why, sizeof why, "%s", e != hipSuccess ? hipGetErrorString(e) : "the rows do not suit the layouts (mostly outside the global box, or not finite)");
+            knn_index_destroy(idx);
+            return fail(e != hipSuccess ? KNN_EHIP : KNN_EINVAL, "knn_index_create_sharded", why);
+        }
+        idx->filter.cells->gids = gids_dev;
+        idx->filter.cells->geom = &idx->geom;
+    }
+    *out = idx;
+    return KNN_OK;
+}
+
+int knn_index_seed_export(knn_index *idx, void *layer_dev, void *stream)
+{
+    if (!idx || !idx->sharded || !layer_dev)
+        return fail(KNN_EINVAL, "knn_index_seed_export: needs a cell-range shard and the layer buffer");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    DeviceGuard guard(idx->device);
+    if (idx->n == 0) {   // a rank without rows: its part is all padding (zero fragments never score: +INF norms)
+        const size_t pb = idx->geom.part_bytes();
+        unsigned char *part = (unsigned char *)layer_dev + (size_t)idx->rank * pb;
+        const size_t frag_bytes = (size_t)idx->geom.cells_per_rank * idx->geom.seed_tiles * 1024u;
+        HIP_TRY(hipMemsetAsync(part, 0, KNN_SEED_HEADER_BYTES + frag_bytes, (hipStream_t)stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(part + KNN_SEED_HEADER_BYTES + frag_bytes), 0x00007C00,
+                                  (size_t)idx->geom.cells_per_rank * idx->geom.seed_tiles * 32u, (hipStream_t)stream));
+        return KNN_OK;
+    }
+    HIP_TRY(knn_cells_seed_export(idx->filter, idx->rank, (unsigned char *)layer_dev, (hipStream_t)stream));
+    return KNN_OK;
+}
+
+int knn_index_seed_attach(knn_index *idx, const void *layer_dev)
+{
+    if (!idx || !idx->sharded || !layer_dev)
+        return fail(KNN_EINVAL, "knn_index_seed_attach: needs a cell-range shard and the complete layer");
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    if (idx->n == 0)
+        return KNN_OK;
+    DeviceGuard guard(idx->device);
+    // the bound constants must cover every rank's fragments: largest coordinate and norm over all parts' headers
+    float bmax = idx->filter.bmax, nmax = idx->filter.nmax;
+    for (int r = 0; r < idx->geom.nranks; ++r) {
+        float hdr[2] = {0.0f, 0.0f};
+        HIP_TRY(hipMemcpy(hdr, (const unsigned char *)layer_dev + (size_t)r * idx->geom.part_bytes(), sizeof hdr, hipMemcpyDeviceToHost));
+        if (!(hdr[0] >= 0.0f) || !(hdr[1] >= 0.0f) || !(hdr[0] < INFINITY) || !(hdr[1] < INFINITY))
+            return fail(KNN_EINVAL, "knn_index_seed_attach: a part of the layer has no valid header (was every rank's part exported and gathered?)");
+        bmax = fmaxf(bmax, hdr[0]);
+        nmax = fmaxf(nmax, hdr[1]);
+    }
+    idx->filter.bmax = bmax;
+    idx->filter.nmax = nmax;
+    idx->filter.cells->seed_layer = (const unsigned char *)layer_dev;
+    return KNN_OK;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 void knn_index_destroy(knn_index *idx)
@@ -600,6 +775,12 @@ int knn_index_query_keys_slot(knn_index *idx, int slot, int m, const float *quer
 int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *queries_dev,
                             unsigned long long *keys_dev, void *stream, unsigned flags)
 {
+    return knn_index_query(idx, slot, m, queries_dev, keys_dev, nullptr, stream, flags);
+}
+
+int knn_index_query(knn_index *idx, int slot, int m, const float *queries_dev, unsigned long long *keys_dev,
+                    int *indices_dev, void *stream, unsigned flags)
+{
     if (!idx || m < 0 || slot < 0 || slot >= KNN_SLOTS || (m > 0 && (!queries_dev || !keys_dev)) ||
         (flags & ~(unsigned)KNN_QUERY_INIT_KEYS) != 0u)
         return fail(KNN_EINVAL, "knn_index_query_keys: bad arguments");
@@ -610,9 +791,14 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
     if (!guard.ok)
         return fail(KNN_EHIP, "knn_index_query_keys: hipSetDevice failed");
     const bool init_keys = (flags & KNN_QUERY_INIT_KEYS) != 0u;
+    if (idx->sharded && !init_keys)
+        return fail(KNN_EINVAL, "knn_index_query: a cell-range shard WRITES its keys (pass KNN_QUERY_INIT_KEYS): they carry local "
+                                "rows until the batch's last kernel, so they cannot fold into keys other shards have written");
     if (idx->n == 0) {   // an empty shard leaves (+INF, 0)
         if (init_keys)
             HIP_TRY(knn_keys_fill_launch((u64 *)keys_dev, m, (hipStream_t)stream));
+        if (indices_dev)
+            HIP_TRY(knn_keys_unpack_launch((const u64 *)keys_dev, m, indices_dev, (hipStream_t)stream));
         return KNN_OK;
     }
     idx->stats[0] = 1;
@@ -630,9 +816,10 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         ev = &idx->events[idx->events_used++];
     }
     const long long path = g_opt_path;
-    const bool cells_live = idx->filter.cells && g_opt_cells != 2;
-    const bool use_filter = idx->filter.usable && !(idx->grid && (path == 0 || path == 3)) &&
-                            (path == 2 || (path == 0 && (m >= 5 || cells_live) && (idx->n >= 65536 || idx->filter_wanted)));
+    const bool cells_live = idx->filter.cells && (g_opt_cells != 2 || idx->sharded);
+    const bool use_filter = idx->sharded ||
+                            (idx->filter.usable && !(idx->grid && (path == 0 || path == 3)) &&
+                             (path == 2 || (path == 0 && (m >= 5 || cells_live) && (idx->n >= 65536 || idx->filter_wanted))));
     // the filter paths start the keys themselves when asked to (the cell-pruned one inside its first kernel)
     if (init_keys && !use_filter)
         HIP_TRY(knn_keys_fill_launch((u64 *)keys_dev, m, s));
@@ -648,6 +835,8 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         if (ev)
             HIP_TRY(hipEventRecord(ev->second, s));
         HIP_TRY(knn_exact_launch(idx->k, m, idx->n, idx->base, queries_dev, idx->refs, (u64 *)keys_dev, idx->num_cu, gate, s));
+        if (indices_dev)
+            HIP_TRY(knn_keys_unpack_launch((const u64 *)keys_dev, m, indices_dev, s));
         return KNN_OK;
     }
     // (with a cell-sorted layout even one query is served faster by the pruned scan than by reading the shard)
@@ -657,7 +846,7 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         idx->filter.force_qt = (int)g_opt_filter_qt;
         idx->filter.force_rounds = (int)g_opt_filter_rounds;
         idx->filter.chain_policy = (int)g_opt_filter_chain;
-        idx->filter.cells_policy = (int)g_opt_cells;
+        idx->filter.cells_policy = idx->sharded ? 0 : (int)g_opt_cells;   // (a cell-range shard has no other layout)
         // batches in flight on several workspace slots = a caller after throughput: the pruned scan of a small shard then
         // takes ONE block per CU, so that the next batch's preparation kernels find registers beside it (knn_cells_query)
         if (slot != 0)
@@ -666,7 +855,7 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
         idx->filter.scan_deal = (int)g_opt_scan_deal;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
-                                 idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys));
+                                 idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys, indices_dev));
         if (idx->filter.ws[slot].last_used_cells)
             idx->stats[0] = 4;
         return KNN_OK;
@@ -677,6 +866,8 @@ int knn_index_query_keys_ex(knn_index *idx, int slot, int m, const float *querie
                              idx->num_cu, nullptr, s));
     if (ev)
         HIP_TRY(hipEventRecord(ev->second, s));
+    if (indices_dev)
+        HIP_TRY(knn_keys_unpack_launch((const u64 *)keys_dev, m, indices_dev, s));
     return KNN_OK;
 }
 

@@ -3,6 +3,7 @@
 // entry point that picks between the two.  Here: the cell index (build), and per batch the kernels that
 // score a query only against the cells it cannot rule out.
 #include "knn_filter_dev.h"
+#include "knn_exact_dev.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,14 +46,81 @@
 // Uniform data in 16 dimensions, n = 2^24: ~1600 of 65536 cells survive per query, 25 queries per cell.
 // ------------------------------------------------------------------------------------------
 #define CELL_MAX_BINS 16
-#define CELL_SEED_DIMS 2                     // own cell + every combination of moves along the 2 nearest cuts
-#define CELL_SEEDS (1 << CELL_SEED_DIMS)
 #define CELL_TILES_PER_PASS 9                 // reference tiles a wave holds in registers at a time (one more costs the sixth wave per SIMD)
 
 struct CellGeom {
     int k, bits, sa;                 // dimensions, total bits, bits of the low table
     unsigned char nb[16], shift[16]; // bits of dimension d (0 = not cut), position of its bin number in the cell code
+    // cell-range shards: `bits` / `nb` / `shift` describe the GLOBAL grid; this index holds codes [cell_base, cell_base + ncells)
+    // of it under local numbers (cell_base is a multiple of 2^sa), nh = its entries of the high table.  Else 0, 2^bits, 2^(bits - sa).
+    unsigned cell_base, ncells, nh;
 };
+
+static CellGeom cell_geom_of(const CellIndex &c, int k)
+{
+    CellGeom g;
+    memset(&g, 0, sizeof g);
+    g.k = k;
+    g.bits = c.bits;
+    g.sa = c.sa;
+    memcpy(g.nb, c.nb, 16);
+    memcpy(g.shift, c.shift, 16);
+    g.cell_base = c.cell_base;
+    g.ncells = c.ncells;
+    g.nh = (c.ncells + (1u << c.sa) - 1u) >> c.sa;
+    return g;
+}
+
+// Shape of a grid of 2^bits cells over k dimensions: bits per dimension (the first bits % k dimensions get one more), the
+// position of each dimension's bin number in the cell code, and sa = the number of low code bits that are whole dimensions
+// and at most 8 (the low pruning table has 2^sa entries).
+static void cell_grid_shape(int k, int bits, unsigned char nb[16], unsigned char shift[16], int *sa_out)
+{
+    int pos = 0, sa = 0;
+    for (int d = 0; d < 16; ++d) {
+        nb[d] = 0;
+        shift[d] = 0;
+    }
+    for (int d = 0; d < k; ++d) {
+        nb[d] = (unsigned char)(bits / k + (d < bits % k ? 1 : 0));
+        shift[d] = (unsigned char)pos;
+        if (pos <= 8)
+            sa = pos;
+        pos += nb[d];
+    }
+    if (pos <= 8)
+        sa = pos;
+    *sa_out = sa;
+}
+
+// Cuts at the sample quantiles: bounds[d][j - 1] = the j-th of 2^nb[d] quantiles of dimension d (+INF beyond).
+static void cell_quantile_cuts(int k, const unsigned char nb[16], const float *samp, long long samples, float *bounds)
+{
+    std::vector<float> col((size_t)samples);
+    for (int i = 0; i < 16 * (CELL_MAX_BINS - 1); ++i)
+        bounds[i] = INFINITY;
+    for (int d = 0; d < k; ++d) {
+        if (!nb[d])
+            continue;
+        for (long long i = 0; i < samples; ++i)
+            col[(size_t)i] = samp[(size_t)i * k + d];
+        std::sort(col.begin(), col.end());
+        const int nbins = 1 << nb[d];
+        for (int j = 1; j < nbins; ++j)
+            bounds[(size_t)d * (CELL_MAX_BINS - 1) + (j - 1)] = col[(size_t)(j * samples / nbins)];
+    }
+}
+
+static int cell_bits_for_rows(long long n)
+{
+    int bits = 0;
+    long long rows_min = 144;            // cells of 144 .. 288 rows on average: 5-9 tiles each
+    if (const char *e = getenv("KNN_MI355X_CELL_ROWS"))   // experiment: other cell sizes
+        rows_min = std::max(32, atoi(e));
+    while ((rows_min << (bits + 1)) <= n)
+        ++bits;
+    return bits;
+}
 
 __device__ __forceinline__ unsigned cell_bin(const float *__restrict__ bnd, int nbins, float x)
 {
@@ -104,9 +172,22 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// the LOCAL number of a cell code; a row outside the index's range of the grid (cell-range shards: the caller's partition
+// was not this geometry's) is counted and parked in cell 0 — the build then fails
+__device__ __forceinline__ unsigned cell_local(unsigned code, const CellGeom &g, unsigned *__restrict__ bad)
+{
+    const unsigned l = code - g.cell_base;
+    if (code < g.cell_base || l >= g.ncells) {
+        atomicAdd(bad, 1u);
+        return 0u;
+    }
+    return l;
+}
+
 __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__restrict__ R, long long n, CellGeom g,
                                                              const float *__restrict__ bounds,
-                                                             unsigned *__restrict__ code, unsigned *__restrict__ counts)
+                                                             unsigned *__restrict__ code, unsigned *__restrict__ counts,
+                                                             unsigned *__restrict__ bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -116,6 +197,7 @@ __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__rest
     for (int d = 0; d < g.k; ++d)
         if (g.nb[d])
             c |= cell_bin(bounds + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], x[d]) << g.shift[d];
+    c = cell_local(c, g, bad);
     code[i] = c;
     atomicAdd(&counts[c], 1u);
 }
@@ -211,7 +293,8 @@ __device__ __forceinline__ unsigned cell_code_of(const float (&x)[16], const Cel
 __global__ __launch_bounds__(256) void knn_cells_bucket_count_kernel(const float *__restrict__ R, long long n, CellGeom g,
                                                                      const float *__restrict__ bounds, int bshift,
                                                                      unsigned *__restrict__ code,
-                                                                     unsigned *__restrict__ bucket_counts)
+                                                                     unsigned *__restrict__ bucket_counts,
+                                                                     unsigned *__restrict__ bad)
 {
     __shared__ unsigned s_h[CELL_BUCKETS];
     __shared__ float s_bnd[16 * (CELL_MAX_BINS - 1)];
@@ -239,7 +322,7 @@ __global__ __launch_bounds__(256) void knn_cells_bucket_count_kernel(const float
                 for (int d = 0; d < 16; ++d)
                     x[d] = d < g.k ? R[(size_t)i * g.k + d] : 0.0f;
             }
-            const unsigned c = cell_code_of(x, g, s_bnd);
+            const unsigned c = cell_local(cell_code_of(x, g, s_bnd), g, bad);
             code[i] = c;
             atomicAdd(&s_h[c >> bshift], 1u);
         }
@@ -647,16 +730,31 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 &a, const f4v *__restrict
 #define CELL_PREP_TILES 9     // seed tiles a wave requests at once (a cell of 144 .. 288 rows: one round trip)
 #define CELL_SEED_MAX_TILES 36u   // tiles of one seed cell a query looks at (a larger cell: every stride-th tile)
 
-template <int PW>   // waves per query: 4 (one seed cell each) or 2 (two each: half the registers held, see knn_cells_query)
+// Where the seed tiles of cells OUTSIDE this index's range come from (cell-range shards; all zero otherwise): every rank's
+// part of the replicated seed layer, `tiles` tiles per cell (ShardGeom::part_bytes).
+struct SeedLayer {
+    const unsigned char *base;
+    unsigned cpr, tiles;             // cells a part has room for (the largest rank's), tiles per cell
+    unsigned ncells, nranks, gran;   // the global grid's cells, the ranks, the granule of their ranges (knn_shard_owner)
+    unsigned long long part_bytes;
+};
+
+// PW: waves per query, 4 or 2 (half the registers held while batches are in flight side by side, see knn_cells_query).
+// SD: seed dimensions — the seeds are the query's own cell and every combination of moves across its SD nearest cuts:
+//     2 (4 cells, each WHOLE) when the index holds the whole grid; 4 for a cell-range shard (16 cells: those of this rank
+//     whole, the others through the seed layer's few tiles — profiles/r04_shard_sim.txt: 236 cells per query and rank
+//     survive at N = 8 against 199 with the bound one GPU would have, 399 with 4 seed cells).
+template <int PW, int SD>
 __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
     const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
     const float *__restrict__ center, float sigma, const unsigned *__restrict__ tile_start, long long ntiles,
-    const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
+    const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, SeedLayer layer, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
     float *__restrict__ hi_tab, float bmax, float nmax, float amax_limit, float *__restrict__ thr,
     float *__restrict__ dup_out, unsigned *__restrict__ ctl, unsigned *__restrict__ ctl_next,
     unsigned *__restrict__ counts, unsigned nlists, u64 *__restrict__ keys_init)
 {
 #pragma clang fp contract(off)
+    constexpr int SEEDS = 1 << SD, NS = SEEDS / PW;   // seed cells in all, per wave
     __shared__ float s_gap[16][CELL_MAX_BINS];
     __shared__ float s_red[PW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -672,6 +770,8 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         ctl_next[KNN_CTL_WIDE_SEEDS] = 0u;
         ctl_next[KNN_CTL_DENSE_CELLS] = 0u;
         ctl_next[KNN_CTL_EXACT_CELLS] = 0u;
+        ctl_next[KNN_CTL_SCAN_DONE] = 0u;
+        ctl_next[KNN_CTL_TAIL_DONE] = 0u;
     }
     const int half = lane >> 5;
     const size_t frag_at = (size_t)(qi >> 5) * 64 + (size_t)half * 32 + (size_t)(qi & 31);
@@ -728,8 +828,8 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         }
         s_gap[d][b] = v;
     }
-    // ---- seed cells (every wave works them out; wave w then takes cell w): dimensions on the lanes — the query's own
-    // bin and the neighbouring bin nearest to it
+    // ---- seed cells (every wave works them out; wave w then takes cells w, w + PW, ...): dimensions on the lanes — the
+    // query's own bin and the neighbouring bin nearest to it
     unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
     float ag = INFINITY;
     if (lane < g.k) {
@@ -757,10 +857,10 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
     for (int off = 8; off > 0; off >>= 1)
         own |= (unsigned)__shfl_xor((int)own, off, KNN_WAVE);
     own = (unsigned)__shfl((int)own, 0, KNN_WAVE);
-    int pick[CELL_SEED_DIMS];
+    int pick[SD];
     u64 key = alt != 0xFFFFFFFFu ? ((u64)__float_as_uint(ag) << 32) | (u64)lane : ~0ull;
 #pragma unroll
-    for (int j = 0; j < CELL_SEED_DIMS; ++j) {
+    for (int j = 0; j < SD; ++j) {
         u64 best = key;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -771,10 +871,10 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         if (lane == pick[j])
             key = ~0ull;
     }
-    unsigned code = own;
-    bool ok = lane < CELL_SEEDS;
+    unsigned code = own;   // lane s < SEEDS: the code of seed cell s (bit j of s = across the j-th nearest cut)
+    bool ok = lane < SEEDS;
 #pragma unroll
-    for (int j = 0; j < CELL_SEED_DIMS; ++j) {
+    for (int j = 0; j < SD; ++j) {
         const int pj = pick[j] < 0 ? 0 : pick[j];
         const unsigned pa = (unsigned)__shfl((int)alt, pj, KNN_WAVE), pn = (unsigned)__shfl((int)nbl, pj, KNN_WAVE),
                        ps = (unsigned)__shfl((int)shl, pj, KNN_WAVE);
@@ -785,20 +885,38 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
                 code = (code & ~(((1u << pn) - 1u) << ps)) | (pa << ps);
         }
     }
-    unsigned v_tb = 0u, v_nt = 0u;
-    if (lane < CELL_SEEDS) {   // tile range of seed cell `lane` (requested now, used after the tables)
-        v_tb = tile_start[code];
-        v_nt = ok ? tile_start[code + 1] - v_tb : 0u;
+    // the tiles of seed cell `lane` (requested now, used after the tables): its first fragment, its first norm word, how many.
+    // A cell of this index: all its tiles, out of the layout; a cell of another rank (cell-range shards): the few tiles of
+    // the replicated seed layer.
+    unsigned long long v_fa = 0ull, v_na = 0ull;
+    unsigned v_nt = 0u;
+    if (ok) {
+        const unsigned l = code - g.cell_base;
+        if (code >= g.cell_base && l < g.ncells) {
+            const unsigned tb = tile_start[l];
+            v_nt = tile_start[l + 1u] - tb;
+            v_fa = (unsigned long long)(rf + (size_t)tb * 64);
+            v_na = (unsigned long long)(rn2 + (size_t)tb * 32);
+        } else if (layer.base) {
+            const unsigned part = knn_shard_owner(code, layer.ncells, layer.nranks, layer.gran);
+            const unsigned cl = code - knn_shard_first_cell(part, layer.ncells, layer.nranks, layer.gran);
+            const unsigned char *pb = layer.base + (size_t)part * layer.part_bytes + KNN_SEED_HEADER_BYTES;
+            v_nt = layer.tiles;
+            v_fa = (unsigned long long)(pb + (size_t)cl * layer.tiles * 1024u);
+            v_na = (unsigned long long)(pb + (size_t)layer.cpr * layer.tiles * 1024u + (size_t)cl * layer.tiles * 128u);
+        }
     }
     __syncthreads();   // s_gap is complete
     // ---- the tables: double sums of the rounded-down gaps, rounded down again.  (Bits and positions of the dimensions
     // come from the lanes that hold them — nbl, shl above — as wave-uniform values: indexing the geometry struct with a
     // run-time d is a dependent scalar load from the kernel arguments per dimension and entry.)
-    const int nl = 1 << g.sa, nh = 1 << (g.bits - g.sa);   // nl >= 64: a wave's entries are all low or all high
+    // Entry e of the high table belongs to local cells [e 2^sa, (e + 1) 2^sa): codes cell_base + that (cell_base is a
+    // multiple of 2^sa; 0 unless the index is a cell-range shard).
+    const int nl = 1 << g.sa, nh = (int)g.nh;   // nl >= 64: a wave's entries are all low or all high
     for (int e0 = 64 * wib; e0 < nl + nh; e0 += 64 * PW) {
         const int e = e0 + lane;
         const bool low = e0 < nl;   // wave-uniform
-        const unsigned ecode = low ? (unsigned)e : (unsigned)(e - nl) << g.sa;
+        const unsigned ecode = low ? (unsigned)e : ((g.cell_base >> g.sa) + (unsigned)(e - nl)) << g.sa;
         double sum = 0.0;
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
@@ -815,41 +933,66 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
                 hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
         }
     }
-    // ---- seed scores: wave w scores the tiles of seed cell w, CELL_PREP_TILES requested per round trip
+    // ---- seed scores.  A wave's seed tiles — those of its NS cells, a cell of many tiles sampled (every stride-th,
+    // at most CELL_SEED_MAX_TILES: any real row's score bounds the answer, and one query per MFMA against the thousands of
+    // tiles of a cluster would cost more than the scan it prepares) — are ONE list, requested CELL_PREP_TILES at a time.
     float um = INFINITY;
-    // stride != 0: tiles first, first + stride, ... instead of a contiguous run
-    auto score_run = [&](unsigned first, unsigned run_tiles, unsigned stride) __attribute__((always_inline)) {
-        for (unsigned v0 = 0u; v0 < run_tiles; v0 += CELL_PREP_TILES) {
+    // (all wave-uniform) run c: `cnt[c]` tiles fa[c] + v stride[c] KiB, norm words na[c] + v stride[c] 128 B
+    auto score_runs = [&](const unsigned long long (&fa)[NS], const unsigned long long (&na)[NS], const unsigned (&cnt)[NS],
+                          const unsigned (&stride)[NS]) __attribute__((always_inline)) {
+        unsigned total = 0u;
+#pragma unroll
+        for (int c = 0; c < NS; ++c)
+            total += cnt[c];
+        for (unsigned v0 = 0u; v0 < total; v0 += CELL_PREP_TILES) {
             h8 ar[CELL_PREP_TILES];
             unsigned nw[CELL_PREP_TILES];
 #pragma unroll
             for (int p = 0; p < CELL_PREP_TILES; ++p) {
-                const unsigned v = v0 + (unsigned)p;   // wave-uniform
+                unsigned v = v0 + (unsigned)p;   // position in the list -> (run, tile of the run)
                 nw[p] = 0u;
-                if (v < run_tiles) {
-                    const unsigned tile = first + v * stride;
-                    ar[p] = rf[(size_t)tile * 64 + lane];
+                if (v < total) {
+                    unsigned long long f = fa[0], nn = na[0];
+                    unsigned st = stride[0];
+#pragma unroll
+                    for (int c = 1; c < NS; ++c)
+                        if (v >= cnt[c - 1]) {   // (runs in order: past run c - 1)
+                            v -= cnt[c - 1];
+                            f = fa[c];
+                            nn = na[c];
+                            st = stride[c];
+                        } else
+                            break;
+                    const size_t t = (size_t)v * st;
+                    ar[p] = ((const h8 *)f)[t * 64 + lane];
                     if (lane < 32)
-                        nw[p] = rn2[(size_t)tile * 32 + lane];
+                        nw[p] = ((const unsigned *)nn)[t * 32 + lane];
                 }
             }
 #pragma unroll
             for (int p = 0; p < CELL_PREP_TILES; ++p)
-                if (v0 + (unsigned)p < run_tiles) {
+                if (v0 + (unsigned)p < total) {
                     const f16v c = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw[p]), norm_b_operand(), zero_acc(), 0, 0, 0);
                     const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], bq, c, 0, 0, 0);
                     um = min_tree16(d, um);
                 }
         }
     };
+    {
+        unsigned long long fa[NS], na[NS];
+        unsigned cnt[NS], stride[NS];
 #pragma unroll
-    for (int c = 0; c < CELL_SEEDS / PW; ++c) {   // this wave's seed cells
-        // (a seed cell of many tiles — clustered data — is sampled: any real row's score bounds the answer, and one query
-        // per MFMA against thousands of tiles would cost more than the scan it prepares)
-        const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, wib + PW * c);
-        const unsigned nt = (unsigned)__builtin_amdgcn_readlane((int)v_nt, wib + PW * c);
-        const unsigned stride = (nt + CELL_SEED_MAX_TILES - 1u) / CELL_SEED_MAX_TILES;   // 1 up to the cap
-        score_run(tb, nt == 0u ? 0u : (nt + stride - 1u) / stride, stride);
+        for (int c = 0; c < NS; ++c) {   // this wave's seed cells
+            const int sl = wib + PW * c;
+            const unsigned nt = (unsigned)__builtin_amdgcn_readlane((int)v_nt, sl);
+            fa[c] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v_fa >> 32), sl) << 32) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v_fa, sl);
+            na[c] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v_na >> 32), sl) << 32) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v_na, sl);
+            stride[c] = (nt + CELL_SEED_MAX_TILES - 1u) / CELL_SEED_MAX_TILES;   // 1 up to the cap
+            cnt[c] = nt == 0u ? 0u : (nt + stride[c] - 1u) / stride[c];
+        }
+        score_runs(fa, na, cnt, stride);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)   // (every column is this query; the halves hold different rows)
@@ -866,11 +1009,24 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         // loose, bound — look at 64 tiles spread over the whole layout, 64 / PW per wave
         __syncthreads();   // s_red has been read by everybody
         const unsigned total = (unsigned)(ntiles > 64 ? 64 : ntiles);
-        const unsigned stride = (unsigned)(ntiles > 64 ? ntiles / 64 : 1);
+        const unsigned wstride = (unsigned)(ntiles > 64 ? ntiles / 64 : 1);
         const unsigned mine_first = (unsigned)wib * (64u / PW);
         um = INFINITY;
-        if (mine_first < total)
-            score_run(mine_first * stride, min(64u / PW, total - mine_first), stride);
+        if (mine_first < total) {
+            unsigned long long fa[NS], na[NS];
+            unsigned cnt[NS], stride[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                fa[c] = na[c] = 0ull;
+                cnt[c] = 0u;
+                stride[c] = 1u;
+            }
+            fa[0] = (unsigned long long)(rf + (size_t)mine_first * wstride * 64);
+            na[0] = (unsigned long long)(rn2 + (size_t)mine_first * wstride * 32);
+            cnt[0] = min(64u / PW, total - mine_first);
+            stride[0] = wstride;
+            score_runs(fa, na, cnt, stride);
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
@@ -912,14 +1068,44 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
 // (<= 80 VGPRs: registers are handed out in eights and 6 waves x 88 do not fit a SIMD's 512)
 // (HIP's second launch bound is waves per SIMD: 6 = at most 80 registers.  Left at 2 the allocator settled at 96-98 once the
 // dense-cell and overflow paths were in — 4 waves per SIMD, and the kernel alone went from 0.035 to 0.042 ms at 2^21 rows)
-template <bool DYN>
+// What ends a batch (the last block of the scan on a clean batch, else of the tail kernel): local row -> global id of the
+// keys' index half when the shard's rows carry their own global numbers (cell-range shards, knn_index_create_sharded),
+// and the int32 indices when the caller asked for them (knn_index_query: no separate unpack launch).
+struct CellFinal {
+    const unsigned *gids;   // nullable: keys hold base + row already
+    int *out_idx;           // nullable
+    int defer;              // != 0: more launches fold into the keys behind the scan (rows outside the robust box): the tail finalises
+};
+
+__device__ __forceinline__ void cells_finalize(u64 *__restrict__ keys, int m, const CellFinal &fin, unsigned tid, unsigned nthreads)
+{
+    if (!fin.gids && !fin.out_idx)
+        return;
+    for (unsigned i = tid; i < (unsigned)m; i += nthreads) {
+        // (agent scope: the keys were folded by atomics of blocks on other XCDs; a plain load may see this XCD's stale L2 line)
+        u64 key = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin.gids && (unsigned)(key >> 32) != 0x7F800000u) {   // (+INF, 0) = nothing found: v0's index 0 stays
+            key = (key & 0xFFFFFFFF00000000ull) | (u64)fin.gids[(unsigned)key];
+            keys[i] = key;
+        }
+        if (fin.out_idx)
+            fin.out_idx[i] = (int)(unsigned)key;
+    }
+}
+
+// K: 16 = compile-time dimension of the inline re-rank, 0 = run-time k <= 16
+template <bool DYN, int K>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
     u64 *__restrict__ rec, unsigned *__restrict__ counts, unsigned *__restrict__ ctl, unsigned slice,
-    unsigned ovf_base, unsigned ovf_cap)
+    unsigned ovf_base, unsigned ovf_cap,
+    // the exact re-rank of this wave's own records (v0 arithmetic on the fp32 rows, through perm) and the end of the batch
+    const float *__restrict__ Q, const float *__restrict__ R, int krt, const unsigned *__restrict__ perm, long long npos,
+    long long base, u64 *__restrict__ keys, CellFinal fin)
 {
+#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
@@ -1098,11 +1284,277 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             mine_dyn = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
         }
     }
-    if (lane == 0) {
-        counts[wave] = ovf_cap != 0u ? min(cnt, slice) : cnt;   // what is IN the slice; the rest went to the shared area
-        if (ovf_cap == 0u && cnt > slice)
-            ctl[KNN_CTL_FALLBACK] = 1u;
+    const unsigned nrec = min(cnt, slice);   // what is IN the slice; the rest went to the shared area (wave-uniform)
+    if (lane == 0)
+        counts[wave] = nrec;                  // (statistics: knn_index_last_stats sums them)
+    // ---- this wave's records, re-ranked on the spot (round 4; rounds 1-3 launched knn_rerank_kernel behind the scan: one
+    // wave per list, 8-9 us for ~3000 records spread over 6144 lists).  16 lanes per record: its 16 rows with v0's
+    // arithmetic on the fp32 rows, min-folded, ONE guarded atomic per record.  The loop above is over: its registers are free.
+    if (nrec != 0u && !dead) {
+        // the records were stored by other lanes of this wave: wait for the stores, no more — workgroup scope is this CU's own
+        // cache.  (An agent-scope fence here, __threadfence(), is a write-back AND an invalidate of the XCD's whole L2 — one per
+        // wave with records: the scan took 261 us instead of 110 at C3 with it.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int k = K > 0 ? K : krt;
+        for (unsigned c0 = 0u; c0 < nrec * 16u; c0 += 64u) {
+            const unsigned c = c0 + (unsigned)lane;
+            const bool live = c < nrec * 16u;
+            // one dependent chain per pair — record -> position -> row number -> row — with everything that does not hang on
+            // it (the query's row, its current key) requested up front
+            const u64 e = live ? __hip_atomic_load(&my_rec[c >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+            const unsigned qi = (unsigned)(e >> 32), lo = (unsigned)e, reg = c & 15u;
+            const long long pos = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
+            const unsigned row = live && pos < npos ? perm[pos] : 0xFFFFFFFFu;   // ~0u: padding position
+            const float *__restrict__ qp = Q + (size_t)qi * k;
+            constexpr int KD = K > 0 ? K : 16;
+            float qv[KD], rv[KD];
+#pragma unroll
+            for (int d = 0; d < KD; ++d)
+                qv[d] = d < k ? qp[d] : 0.0f;
+            const u64 cur = keys[qi];   // (may be stale: keys[] only ever decreases, a stale read costs a spare atomic)
+            const float *__restrict__ rp = R + (size_t)(row != 0xFFFFFFFFu ? row : 0u) * k;
+#pragma unroll
+            for (int d = 0; d < KD; ++d)
+                rv[d] = d < k ? rp[d] : 0.0f;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < KD; ++d)
+                if (d < k) {   // v0's order and operations: diff, square, add (no contraction)
+                    const float diff = qv[d] - rv[d];
+                    const float sq = diff * diff;
+                    acc = acc + sq;
+                }
+            u64 key = row != 0xFFFFFFFFu && acc < INFINITY ? pack_key(acc, (unsigned)(base + (long long)row)) : ~0ull;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const u64 o = __shfl_xor(key, off, KNN_WAVE);
+                key = o < key ? o : key;
+            }
+            if ((lane & 15) == 0 && key < cur)   // (key == ~0: never below a key)
+                key_atomic_min(&keys[qi], key);
+        }
     }
+    // ---- end of the batch: the block that finishes last finalises it, unless something is still to fold into the keys
+    // (records in the shared area, an over-full area, rows outside the box) — then the tail kernel does, which sees the
+    // same two words and returns at once in the case handled here.
+    // (What the finaliser reads from other blocks are words they changed with agent-scope ATOMICS — the keys, the record
+    // counter: those are performed at the memory side, no cache to write back.  Every wave waits for its own atomics to have
+    // been performed before the block counts itself done; the finaliser reads with agent-scope loads.)
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&ctl[KNN_CTL_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last != 0u && !fin.defer) {   // block-uniform
+        const unsigned have = __hip_atomic_load(&ctl[KNN_CTL_RECORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (have == 0u)
+            cells_finalize(keys, m, fin, threadIdx.x, 64u * CELL_SCAN_WAVES);
+    }
+}
+
+// What is left of a batch behind the scan, in ONE gated launch (rounds 2-3: a re-rank launch and two gated ones):
+//   nothing (the usual case: the scan's last block has finalised the batch)     -> every block returns at once
+//   records in the shared overflow area                                        -> re-ranked here, all blocks striding
+//   the area over-full (a cluster tighter than the fp16 step: the fp16 scores do not separate the batch's rows)
+//                                                                              -> the batch's listed (item, query) pairs
+//                                                                                 with the exact arithmetic (cells_exact_items)
+//   FALLBACK (a query nothing bounds: the gated exact scan in front of this launch has answered the batch), fin.defer
+//                                                                              -> only the finalisation
+template <int K>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
+    const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long npos, long long base,
+    const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
+    const unsigned short *__restrict__ lists, unsigned cap, const unsigned *__restrict__ perm,
+    const u64 *__restrict__ rec, unsigned ovf_base, unsigned ovf_cap, unsigned *__restrict__ ctl, u64 *__restrict__ keys,
+    CellFinal fin)
+{
+#pragma clang fp contract(off)
+    const unsigned fb = ctl[KNN_CTL_FALLBACK], have = ctl[KNN_CTL_RECORDS];   // final: prep and the scan are complete
+    if (!fin.defer && fb == 0u && have == 0u)
+        return;
+    if (fb == 0u) {
+        if (have > ovf_cap) {
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+                ctl[KNN_CTL_EXACT_CELLS] = 1u;   // (statistics: knn_index_last_stats[2] = 2)
+            cells_exact_items<K>(Q, R, krt, m, base, items, nitems, cell_counts, lists, cap, perm, keys,
+                                 blockIdx.x * (unsigned)KNN_WAVES + (threadIdx.x >> 6), gridDim.x * (unsigned)KNN_WAVES);
+        } else if (have != 0u) {
+            const int k = K > 0 ? K : krt;
+            const u64 *__restrict__ ovf = rec + ovf_base;
+            const unsigned pairs = have * 16u;
+            const unsigned padded = (pairs + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
+            for (unsigned c = blockIdx.x * KNN_BLOCK + threadIdx.x; c < padded; c += gridDim.x * KNN_BLOCK) {
+                u64 key = ~0ull;
+                unsigned qi = 0u;
+                if (c < pairs)
+                    key = rerank_pair<K>(Q, R, k, npos, base, ovf[c >> 4], c & 15u, 0xFFFFu, 0u, perm, qi);
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    const u64 o = __shfl_xor(key, off, KNN_WAVE);
+                    key = o < key ? o : key;
+                }
+                if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+                    key_atomic_min(&keys[qi], key);
+            }
+        }
+    }
+    if (!fin.gids && !fin.out_idx)
+        return;
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (as in the scan: this wave's atomics have been performed)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&ctl[KNN_CTL_TAIL_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last != 0u)
+        cells_finalize(keys, m, fin, threadIdx.x, KNN_BLOCK);
+}
+
+// ------------------------------------------------------------------------------------------
+// Cell-range shards (round 4): the caller's partition pass, the replicated seed layer, the check of the rows' global numbers.
+// ------------------------------------------------------------------------------------------
+// owner[i] = the rank whose range of the global grid holds row i's cell
+__global__ __launch_bounds__(256) void knn_geom_assign_kernel(const float *__restrict__ R, long long n, CellGeom g,
+                                                              const float *__restrict__ bounds_arg, unsigned nranks,
+                                                              int *__restrict__ owner)
+{
+    __shared__ float s_bnd[16 * (CELL_MAX_BINS - 1)];
+    if (threadIdx.x < 16 * (CELL_MAX_BINS - 1))
+        s_bnd[threadIdx.x] = bounds_arg[threadIdx.x];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    unsigned c = 0u;
+    for (int d = 0; d < g.k; ++d)
+        if (g.nb[d])
+            c |= cell_bin(s_bnd + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], R[(size_t)i * g.k + d]) << g.shift[d];
+    owner[i] = (int)knn_shard_owner(c, g.ncells, nranks, 1u << g.sa);
+}
+
+// This rank's part of the seed layer: for every cell of its range the first T tiles of the cell-sorted layout (fragments
+// and split norms; a cell of fewer tiles is padded with zero fragments and +INF norms, which never give a score).
+// One block per cell.
+__global__ __launch_bounds__(256) void knn_cells_seed_export_kernel(const unsigned *__restrict__ tile_start, unsigned ncells,
+                                                                    unsigned cpr, unsigned T, const h8 *__restrict__ rf,
+                                                                    const unsigned *__restrict__ rn2,
+                                                                    unsigned char *__restrict__ part, float bmax, float nmax)
+{
+    const unsigned cell = blockIdx.x;   // < cpr
+    h8 *__restrict__ of = (h8 *)(part + KNN_SEED_HEADER_BYTES + (size_t)cell * T * 1024u);
+    unsigned *__restrict__ on = (unsigned *)(part + KNN_SEED_HEADER_BYTES + (size_t)cpr * T * 1024u + (size_t)cell * T * 128u);
+    unsigned tb = 0u, nt = 0u;
+    if (cell < ncells) {
+        tb = tile_start[cell];
+        nt = min(T, tile_start[cell + 1u] - tb);
+    }
+    for (unsigned i = threadIdx.x; i < T * 64u; i += 256u)
+        of[i] = i < nt * 64u ? rf[(size_t)tb * 64 + i] : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (unsigned i = threadIdx.x; i < T * 32u; i += 256u)
+        on[i] = i < nt * 32u ? rn2[(size_t)tb * 32 + i] : 0x00007C00u;
+    if (cell == 0u && threadIdx.x == 0) {   // header: what the bound constants of every rank must cover
+        ((float *)part)[0] = bmax;
+        ((float *)part)[1] = nmax;
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_gids_check_kernel(const unsigned *__restrict__ gids, long long n, unsigned *__restrict__ bad)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride)
+        if (!(gids[i] < gids[i + 1]))
+            atomicAdd(bad, 1u);
+}
+
+hipError_t knn_geom_assign_launch(const ShardGeom &sg, const float *rows_dev, long long n, int *owner_dev, hipStream_t s)
+{
+    if (n <= 0)
+        return hipSuccess;
+    CellGeom g;
+    memset(&g, 0, sizeof g);
+    g.k = sg.k;
+    g.bits = sg.bits;
+    g.sa = sg.sa;
+    memcpy(g.nb, sg.nb, 16);
+    memcpy(g.shift, sg.shift, 16);
+    g.ncells = sg.ncells;
+    float *bnd = nullptr;
+    FTRY(KNN_DEV_ALLOC((void **)&bnd, sizeof sg.bounds));
+    hipError_t e = hipMemcpyAsync(bnd, sg.bounds, sizeof sg.bounds, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(knn_geom_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows_dev, n, g, bnd,
+                           (unsigned)sg.nranks, owner_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);   // (the cuts' staging buffer goes back to the pool)
+    (void)KNN_DEV_FREE(bnd);
+    return e;
+}
+
+hipError_t knn_cells_seed_export(const FilterState &st, int rank, unsigned char *layer_dev, hipStream_t s)
+{
+    if (!st.cells || !st.cells->geom || !layer_dev)
+        return hipErrorInvalidValue;
+    const ShardGeom &sg = *st.cells->geom;
+    hipLaunchKernelGGL(knn_cells_seed_export_kernel, dim3(sg.cells_per_rank), dim3(256), 0, s, st.cells->tile_start, st.cells->ncells,
+                       sg.cells_per_rank, (unsigned)sg.seed_tiles, (const h8 *)st.ref_frags, st.ref_norms2,
+                       layer_dev + (size_t)rank * sg.part_bytes(), st.bmax, st.nmax);
+    return hipGetLastError();
+}
+
+hipError_t knn_gids_check(const unsigned *gids_dev, long long n, unsigned *bad_out, hipStream_t s)
+{
+    *bad_out = 0u;
+    if (n < 2)
+        return hipSuccess;
+    unsigned *bad = nullptr;
+    FTRY(KNN_DEV_ALLOC((void **)&bad, sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(knn_gids_check_kernel, dim3(1024), dim3(256), 0, s, gids_dev, n, bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(bad_out, bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)KNN_DEV_FREE(bad);
+    return e;
+}
+
+// The global grid of a cell-range sharded set.  bits: as many as the rows allow (>= 144 rows per cell on average, the
+// rule of a single index), at most 4 per dimension, and no more than lets every rank hold <= 2^16 cells; every rank's range
+// starts at a multiple of 2^sa codes (whole entries of the high pruning table; 2^sa >= 64: whole blocks of the match pass).
+bool knn_geom_cells(ShardGeom &g, int k, long long n_global, int nranks, const float *sample, long long samples, int seed_tiles)
+{
+    if (k < 1 || k > 16 || nranks < 1 || nranks > 64 || samples < 64 || seed_tiles < 1 || seed_tiles > 8 || n_global < 1)
+        return false;
+    int bits = std::min(cell_bits_for_rows(n_global), 4 * k);
+    while (bits > 0 && ((1ull << bits) + (unsigned long long)nranks - 1ull) / (unsigned long long)nranks > 65536ull)
+        --bits;
+    if (bits < 9)
+        return false;
+    g.k = k;
+    g.bits = bits;
+    g.nranks = nranks;
+    g.seed_tiles = seed_tiles;
+    g.n_global = n_global;
+    g.ncells = 1u << bits;
+    cell_grid_shape(k, bits, g.nb, g.shift, &g.sa);
+    if (g.sa < 6)
+        return false;
+    g.cells_per_rank = 0u;
+    for (int r = 0; r < nranks; ++r) {   // every rank needs a layout of its own, of at most 2^16 cells
+        const unsigned cr = g.cells_of(r);
+        if (cr < 512u || cr > 65536u || cr % 64u != 0u)
+            return false;
+        g.cells_per_rank = std::max(g.cells_per_rank, cr);
+    }
+    cell_quantile_cuts(k, g.nb, sample, samples, g.bounds);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1128,67 +1580,62 @@ void knn_cells_free(CellIndex *&c)
 // of the build (samples x k).  Synchronous.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                           unsigned **fill_out, bool one_pass)
+                           unsigned **fill_out, bool one_pass, const ShardGeom *geom, int rank, unsigned *bad_rows_out)
 {
     *out = nullptr;
     *code_out = nullptr;
     *fill_out = nullptr;
-    if (k > 16 || n < (1ll << 17) || n > 0x7FFFFFFFll || samples < 64)
-        return hipSuccess;
-    int bits = 0;
-    long long rows_min = 144;            // cells of 144 .. 288 rows on average: 5-9 tiles each
-    if (const char *e = getenv("KNN_MI355X_CELL_ROWS"))   // experiment: other cell sizes
-        rows_min = std::max(32, atoi(e));
-    while ((rows_min << (bits + 1)) <= n)
-        ++bits;
-    bits = std::min(bits, std::min(16, 4 * k));
-    if (bits < 9)
+    if (bad_rows_out)
+        *bad_rows_out = 0u;
+    if (k > 16 || n > 0x7FFFFFFFll || (!geom && (n < (1ll << 17) || samples < 64)))
         return hipSuccess;
     CellIndex *c = new CellIndex();
-    c->bits = bits;
-    c->ncells = 1u << bits;
+    std::vector<float> bounds((size_t)16 * (CELL_MAX_BINS - 1), INFINITY);
+    if (geom) {
+        // cell-range shard: the global grid's shape and cuts, this rank's range of its codes
+        c->bits = geom->bits;
+        c->sa = geom->sa;
+        memcpy(c->nb, geom->nb, 16);
+        memcpy(c->shift, geom->shift, 16);
+        c->cell_base = geom->first_cell(rank);
+        c->ncells = geom->cells_of(rank);
+        c->geom = geom;
+        memcpy(bounds.data(), geom->bounds, sizeof geom->bounds);
+        if (c->ncells < 512u || c->ncells % 64u != 0u || c->ncells > 65536u) {   // (knn_geom_from_sample sizes the ranges so)
+            delete c;
+            return hipSuccess;
+        }
+    } else {
+        const int bits = std::min(cell_bits_for_rows(n), std::min(16, 4 * k));
+        if (bits < 9) {
+            delete c;
+            return hipSuccess;
+        }
+        c->bits = bits;
+        c->ncells = 1u << bits;
+        cell_grid_shape(k, bits, c->nb, c->shift, &c->sa);
+        if (c->sa < 6) {   // a wave of the match pass covers 64 consecutive low-table entries
+            delete c;
+            return hipSuccess;
+        }
+        cell_quantile_cuts(k, c->nb, samp.data(), samples, bounds.data());
+    }
     // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
     // in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
     c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
-    int pos = 0, sa = 0;
-    for (int d = 0; d < k; ++d) {
-        c->nb[d] = (unsigned char)(bits / k + (d < bits % k ? 1 : 0));
-        c->shift[d] = (unsigned char)pos;
-        if (pos <= 8)
-            sa = pos;
-        pos += c->nb[d];
-    }
-    if (pos <= 8)
-        sa = pos;
-    c->sa = sa;
-    if (sa < 6) {   // a wave of the match pass covers 64 consecutive low-table entries
-        delete c;
-        return hipSuccess;
-    }
-    // cuts at the sample quantiles
-    std::vector<float> bounds((size_t)16 * (CELL_MAX_BINS - 1), INFINITY), col((size_t)samples);
-    for (int d = 0; d < k; ++d) {
-        if (!c->nb[d])
-            continue;
-        for (long long i = 0; i < samples; ++i)
-            col[(size_t)i] = samp[(size_t)i * k + d];
-        std::sort(col.begin(), col.end());
-        const int nbins = 1 << c->nb[d];
-        for (int j = 1; j < nbins; ++j)
-            bounds[(size_t)d * (CELL_MAX_BINS - 1) + (j - 1)] = col[(size_t)(j * samples / nbins)];
-    }
-    CellGeom g;
-    memset(&g, 0, sizeof g);
-    g.k = k;
-    g.bits = bits;
-    g.sa = sa;
-    memcpy(g.nb, c->nb, 16);
-    memcpy(g.shift, c->shift, 16);
+    const CellGeom g = cell_geom_of(*c, k);
+    int lbits = 0;   // bits of a LOCAL cell number (= bits without a shard geometry)
+    while ((1u << lbits) < c->ncells)
+        ++lbits;
 
     unsigned *code = nullptr, *counts = nullptr;
     std::vector<unsigned> hcounts((size_t)c->ncells), hstart((size_t)c->ncells + 1);
     std::vector<u64> hitems;
-    hipError_t e = KNN_DEV_ALLOC((void **)&c->bounds, bounds.size() * sizeof(float));
+    // (one word behind the cuts counts rows outside the index's cell range)
+    hipError_t e = KNN_DEV_ALLOC((void **)&c->bounds, (bounds.size() + 1) * sizeof(float));
+    unsigned *bad_dev = (unsigned *)(c->bounds + bounds.size());
+    if (e == hipSuccess)
+        e = hipMemsetAsync(bad_dev, 0, sizeof(unsigned), s);
     if (e == hipSuccess)
         e = KNN_DEV_ALLOC((void **)&c->tile_start, hstart.size() * sizeof(unsigned));
     if (e == hipSuccess)
@@ -1203,7 +1650,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     // Two-pass build (see the kernels): needs n x 72 bytes of scratch; without it (or with option `cells_build` = 1, for A/B
     // timing and tests) the one-pass placement serves.
     const bool one_pass_env = one_pass;
-    const int bshift = bits - 8;   // bits >= 9: a bucket = 2^bshift consecutive cells
+    const int bshift = lbits - 8;   // >= 512 cells: a bucket = 2^bshift consecutive (local) cells
     const unsigned bblocks = (unsigned)((n + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS);
     unsigned *bucket_counts = nullptr, *bucket_fill = nullptr;
     // (shards of up to 2^25 rows: beyond, the scratch is gigabytes that the buffer pool does not keep between builds, and one
@@ -1237,7 +1684,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         e = hipMemsetAsync(bucket_counts, 0, 2 * CELL_BUCKETS * sizeof(unsigned), s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(knn_cells_bucket_count_kernel, dim3(bblocks), dim3(256), 0, s, r, n, g, c->bounds, bshift, code,
-                               bucket_counts);
+                               bucket_counts, bad_dev);
             e = hipGetLastError();
         }
         if (e == hipSuccess)
@@ -1267,7 +1714,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         (void)KNN_DEV_FREE(bucket_counts);
     } else {
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(knn_cells_code_kernel, dim3(blocks), dim3(256), 0, s, r, n, g, c->bounds, code, counts);
+            hipLaunchKernelGGL(knn_cells_code_kernel, dim3(blocks), dim3(256), 0, s, r, n, g, c->bounds, code, counts, bad_dev);
             e = hipGetLastError();
         }
         if (e == hipSuccess)
@@ -1276,6 +1723,17 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
             e = hipStreamSynchronize(s);   // (also keeps `bounds` alive until its copy is done)
     }
     bool keep = e == hipSuccess;
+    if (keep && geom) {   // rows outside this rank's cell range: the caller partitioned with another geometry
+        unsigned hbad = 0u;
+        e = hipMemcpy(&hbad, bad_dev, sizeof hbad, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && hbad != 0u) {
+            if (bad_rows_out)
+                *bad_rows_out = hbad;
+            keep = false;
+        }
+        keep = keep && e == hipSuccess;
+    }
+    c->lbits = lbits;
     long long tiles = 0;
     if (keep) {
         unsigned biggest = 0u;
@@ -1341,7 +1799,7 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
     FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms2, 0x00007C00, (size_t)rows_padded, s));
     if (st.cells->tmp_rows)
         hipLaunchKernelGGL(knn_cells_place_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, st.cells->tmp_rows,
-                           st.cells->tmp_meta, st.cells->bucket_start, st.k, st.cells->bits - 8, st.cells->tile_start, fill, st.center, st.sigma,
+                           st.cells->tmp_meta, st.cells->bucket_start, st.k, st.cells->lbits - 8, st.cells->tile_start, fill, st.center, st.sigma,
                            (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, out, st.outliers, ocap);
     else
         hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
@@ -1381,7 +1839,7 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
         w.cell_m_cap = 0;
         FTRY(KNN_DEV_ALLOC((void **)&w.dup, (size_t)m_padded * sizeof(float)));
         FTRY(KNN_DEV_ALLOC((void **)&w.lo_tab, (size_t)m_padded * ((size_t)1 << c.sa) * sizeof(float)));
-        FTRY(KNN_DEV_ALLOC((void **)&w.hi_tab, (size_t)m_padded * ((size_t)1 << (c.bits - c.sa)) * sizeof(float)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.hi_tab, (size_t)m_padded * (size_t)((c.ncells + (1u << c.sa) - 1u) >> c.sa) * sizeof(float)));
         w.cell_m_cap = m_padded;
     }
     return hipSuccess;
@@ -1412,21 +1870,18 @@ CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems,
     return p;
 }
 
-// One batch of <= KNN_CELL_BATCH queries: prep + match + scan.  Records in w, as the full scan leaves them.
+// One batch of <= KNN_CELL_BATCH queries, the whole chain: prep -> match -> scan (its waves re-rank their own records) ->
+// [rows outside the robust box, exactly] -> the exact scan of the shard, gated on FALLBACK -> the tail kernel (gated: records
+// in the shared area, the listed pairs exactly when that area is over-full, the finalisation when the scan could not do it).
+// Five launches on clean data.  out_idx (nullable): int32 indices of the batch, written by whichever block ends it.
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, const float *r, long long base,
-                           u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys)
+                           u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys, int *out_idx)
 {
     u64 *keys_init = init_keys ? keys : nullptr;
     FTRY(ensure_cells_workspace(st, w, m));
     const CellIndex &c = *st.cells;
     const int m_padded = (m + 31) / 32 * 32;
-    CellGeom g;
-    memset(&g, 0, sizeof g);
-    g.k = st.k;
-    g.bits = c.bits;
-    g.sa = c.sa;
-    memcpy(g.nb, c.nb, 16);
-    memcpy(g.shift, c.shift, 16);
+    const CellGeom g = cell_geom_of(c, st.k);
     w.has_rows = false;
     w.pieces = RerankPieces();
     const double sigma2 = (double)st.sigma * (double)st.sigma;
@@ -1450,16 +1905,29 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     unsigned *ctl_next = w.ctl + KNN_CTL_WORDS * (2u - parity);
     // batches in flight side by side: two waves per query (two seed cells each) — half the registers the launch holds,
     // 0.0421 -> 0.0408 ms per step at n_local 2^21 for 2 us more when a batch runs alone; else four waves per query
-    if (st.several_slots)
-        hipLaunchKernelGGL(knn_cells_prep_kernel<2>, dim3((unsigned)m_padded), dim3(64 * 2), 0, s, q, m,
-                           m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
-                           st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
-                           w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+    SeedLayer layer;
+    memset(&layer, 0, sizeof layer);
+    if (c.geom && c.seed_layer) {
+        layer.base = c.seed_layer;
+        layer.cpr = c.geom->cells_per_rank;
+        layer.tiles = (unsigned)c.geom->seed_tiles;
+        layer.ncells = c.geom->ncells;
+        layer.nranks = (unsigned)c.geom->nranks;
+        layer.gran = 1u << c.geom->sa;
+        layer.part_bytes = c.geom->part_bytes();
+    }
+#define KNN_PREP_LAUNCH(PWV, SDV)                                                                                          \
+    hipLaunchKernelGGL((knn_cells_prep_kernel<PWV, SDV>), dim3((unsigned)m_padded), dim3(64 * PWV), 0, s, q, m, m_padded, g, \
+                       c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,            \
+                       st.ref_norms2, layer, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr,    \
+                       w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init)
+    if (c.geom)   // cell-range shard: 16 seed cells (4 per wave, the other ranks' through the seed layer)
+        KNN_PREP_LAUNCH(4, 4);
+    else if (st.several_slots)
+        KNN_PREP_LAUNCH(2, 2);
     else
-        hipLaunchKernelGGL(knn_cells_prep_kernel<4>, dim3((unsigned)m_padded), dim3(64 * 4), 0, s, q, m,
-                           m_padded, g, c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,
-                           st.ref_norms2, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr, w.dup,
-                           w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init);
+        KNN_PREP_LAUNCH(4, 2);
+#undef KNN_PREP_LAUNCH
     FTRY(hipGetLastError());
     if (c.ncells <= 16384u)
         hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
@@ -1501,16 +1969,49 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // 0.0831 / 0.1249) — so that is what pipelined callers get.
     // (below two items per wave the counter has nothing to even out: 2^21 rows, one batch at a time, 0.0786 ms fixed / 0.0800 counter)
     const bool dyn = st.scan_deal == 2 || (st.scan_deal == 0 && !st.several_slots && c.nitems >= 2u * w.nlists);
-    if (dyn)
-        hipLaunchKernelGGL(knn_cells_scan_kernel<true>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
-                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
-    else
-        hipLaunchKernelGGL(knn_cells_scan_kernel<false>, dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags,
-                           st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded,
-                           w.cell_counts, w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap);
+    CellFinal fin;
+    fin.gids = c.gids;
+    fin.out_idx = out_idx;
+    fin.defer = st.n_outliers != 0u ? 1 : 0;
+    const long long npos = st.ntiles * 32;
+#define KNN_SCAN_LAUNCH(DYNV, KV)                                                                                          \
+    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, \
+                       st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded, w.cell_counts,        \
+                       w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap, q, r, st.k,    \
+                       c.perm, npos, base, keys, fin)
+    if (dyn) {
+        if (st.k == 16)
+            KNN_SCAN_LAUNCH(true, 16);
+        else
+            KNN_SCAN_LAUNCH(true, 0);
+    } else {
+        if (st.k == 16)
+            KNN_SCAN_LAUNCH(false, 16);
+        else
+            KNN_SCAN_LAUNCH(false, 0);
+    }
+#undef KNN_SCAN_LAUNCH
     FTRY(hipGetLastError());
     if (timed && w.ev_end)
         FTRY(hipEventRecord(w.ev_end, s));
-    return hipSuccess;
+    // rows outside the robust box never entered the layouts: exact scan of that (short) list
+    FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
+    // gated on the device: the whole shard exactly when the batch has a query nothing bounds
+    FTRY(knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
+    {
+        unsigned blocks = (unsigned)num_cu * 8u;
+        if (blocks * KNN_WAVES > c.nitems)
+            blocks = (c.nitems + KNN_WAVES - 1u) / KNN_WAVES;
+#define KNN_TAIL_LAUNCH(KV)                                                                                                \
+    hipLaunchKernelGGL(knn_cells_tail_kernel<KV>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, npos, base, c.items,  \
+                       c.nitems, w.cell_counts, w.cell_lists, c.cap, c.perm, w.records, w.ovf_base, w.ovf_cap, w.ctl_cur,   \
+                       keys, fin)
+        switch (st.k) {
+        case 16: KNN_TAIL_LAUNCH(16); break;
+        case 8: KNN_TAIL_LAUNCH(8); break;
+        default: KNN_TAIL_LAUNCH(0); break;
+        }
+#undef KNN_TAIL_LAUNCH
+    }
+    return hipGetLastError();
 }

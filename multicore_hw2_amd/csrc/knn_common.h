@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #define KNN_WAVE 64
 
@@ -38,11 +39,6 @@ struct RerankPieces {
 // perm (nullable): records name positions of a permuted layout; perm[position] = row (~0u = padding), and n
 // is then the number of positions.
 // ovf_cap != 0: records[ovf_base ..) hold ctl[KNN_CTL_RECORDS] more records (capped at ovf_cap) that belong to no list.
-// Cell-pruned path, gated on ctl[KNN_CTL_EXACT_CELLS]: exact v0 arithmetic over the batch's listed (item, query) pairs.
-hipError_t knn_cells_exact_launch(int k, int m, long long base, const float *q_dev, const float *r_dev,
-                                  const unsigned long long *items, unsigned nitems, const unsigned *cell_counts,
-                                  const unsigned short *lists, unsigned cap, const unsigned *perm, const unsigned *ctl,
-                                  unsigned long long *keys, int num_cu, hipStream_t s);
 hipError_t knn_rerank_launch(int k, long long n, const float *q_dev, const float *r_dev, long long base,
                              const u64 *records, const unsigned short *record_rows, const unsigned *counts,
                              unsigned nlists, unsigned slice, unsigned *ctl, u64 *keys, RerankPieces pieces,
@@ -68,6 +64,8 @@ enum {
     KNN_CTL_DENSE_CELLS = 7, // cell-pruned path: cells whose query list outgrew its LDS room (scored against the whole batch)
     KNN_CTL_EXACT_CELLS = 8, // cell-pruned path, != 0: more candidates than the record buffers hold (the fp16 scores cannot tell
                              // the rows of a tight cluster apart): the listed (cell, query) pairs are evaluated exactly instead
+    KNN_CTL_SCAN_DONE = 9,   // cell-pruned path: blocks of the scan that have finished (the last one finalises a clean batch)
+    KNN_CTL_TAIL_DONE = 10,  // cell-pruned path: blocks of the tail kernel that have finished
     KNN_CTL_WORDS = 12
 };
 
@@ -120,9 +118,51 @@ static inline int knn_kt_of(int k)
          : k <= KNN_FILTER_MAX_K ? 8 * ((k + 127) / 128) : 0;
 }
 
+// Global geometry of a CELL-RANGE sharded set (round 4; include/knn_mi355x.h, knn_geom_*): ONE grid for the whole reference
+// set — cuts, centre and scale from a sample of the global set, identical on every rank — whose cell codes are split into
+// contiguous ranges, one per rank.  A rank's index sorts ITS rows into ITS cells of that grid, so the ranks' scans add up to
+// the scan of one GPU holding everything (index-range shards re-grid n / N rows at 1 / N of the resolution and do 3.5x the
+// work at N = 8: profiles/r04_shard_sim.txt).
+#define KNN_SEED_HEADER_BYTES 256u
+// Rank r of nranks owns the codes [first(r), first(r + 1)) of a grid of ncells cells, first(r) = r ncells / nranks rounded
+// down to a multiple of gran (whole entries of the high pruning table; first(nranks) = ncells).
+__host__ __device__ static inline unsigned knn_shard_first_cell(unsigned r, unsigned ncells, unsigned nranks, unsigned gran)
+{
+    if (r >= nranks)
+        return ncells;
+    return (unsigned)((unsigned long long)r * ncells / nranks) / gran * gran;
+}
+__host__ __device__ static inline unsigned knn_shard_owner(unsigned code, unsigned ncells, unsigned nranks, unsigned gran)
+{
+    unsigned r = (unsigned)((unsigned long long)code * nranks / ncells);
+    if (r >= nranks)
+        r = nranks - 1u;
+    while (r > 0u && code < knn_shard_first_cell(r, ncells, nranks, gran))
+        --r;
+    while (r + 1u < nranks && code >= knn_shard_first_cell(r + 1u, ncells, nranks, gran))
+        ++r;
+    return r;
+}
+struct ShardGeom {
+    int k = 0, bits = 0, sa = 0, nranks = 1;
+    int seed_tiles = 2;              // tiles of every cell each rank replicates (the seed layer)
+    unsigned char nb[16] = {0}, shift[16] = {0};
+    unsigned ncells = 0;             // 2^bits, all ranks together
+    unsigned cells_per_rank = 0;     // the LARGEST rank's cells (a part of the seed layer has room for that many)
+    long long n_global = 0;
+    float bounds[16 * 15];           // ascending cuts of every dimension (+INF beyond a dimension's bins)
+    float center[16];
+    float sigma = 1.0f;
+    unsigned first_cell(int rank) const { return knn_shard_first_cell((unsigned)rank, ncells, (unsigned)nranks, 1u << sa); }
+    unsigned cells_of(int rank) const { return first_cell(rank + 1) - first_cell(rank); }
+    // bytes of ONE rank's part of the seed layer: header (bmax, nmax) | [cpr][T][64] fragments | [cpr][T][32] split norms
+    size_t part_bytes() const { return KNN_SEED_HEADER_BYTES + (size_t)cells_per_rank * (size_t)seed_tiles * (1024u + 128u); }
+};
+
 // Cell-sorted layout of the references (k <= 16): see the head of knn_cells.hip.
 struct CellIndex {
     int bits = 0, sa = 0;            // cells = 2^bits; low pruning table = 2^sa entries
+    int lbits = 0;                   // bits of a local cell number (= bits unless the index is a cell-range shard)
     unsigned char nb[16] = {0}, shift[16] = {0};
     unsigned ncells = 0, cap = 0;    // cap: queries a cell's list can hold per batch
     float *bounds = nullptr;         // device [16][15]: ascending cuts of every dimension
@@ -139,6 +179,13 @@ struct CellIndex {
     float *tmp_rows = nullptr;
     unsigned long long *tmp_meta = nullptr;
     unsigned *bucket_start = nullptr;   // device [257]: first record of each bucket
+    // cell-range shards (knn_index_create_sharded): global number of every local row, ascending (borrowed); null: base + row
+    const unsigned *gids = nullptr;
+    // cell-range shards: `bits`, `nb`, `shift`, `sa`, `bounds` are the GLOBAL grid's; this index holds cells
+    // [cell_base, cell_base + ncells) of it under local numbers 0 .. ncells - 1 (cell_base is a multiple of 2^sa)
+    unsigned cell_base = 0;
+    const ShardGeom *geom = nullptr;      // (borrowed: outlives the index)
+    const unsigned char *seed_layer = nullptr;   // device: every rank's part, nranks x geom->part_bytes() (borrowed)
 };
 
 struct FilterState {
@@ -178,9 +225,12 @@ struct FilterState {
 #include <vector>
 // Cell codes + counts of the shard (cuts from the strided host sample of the build).  *out stays null when the
 // shard does not suit; else *code_out / *fill_out (device; the caller frees them) feed knn_cells_place_rows.
+// geom != null: the cell-range shard `rank` of that global grid (no cuts of its own; *out stays null — with *bad_rows_out
+// set — when rows fall outside the rank's cell range).
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r_dev, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                           unsigned **fill_out, bool one_pass = false);
+                           unsigned **fill_out, bool one_pass = false, const ShardGeom *geom = nullptr, int rank = 0,
+                           unsigned *bad_rows_out = nullptr);
 #endif
 // Sizes of one scan launch of the cell-pruned path (knn_cells.hip; host arithmetic only).
 struct CellScanPlan {
@@ -196,7 +246,7 @@ void knn_cells_workspace_free(FilterWorkspace &w);
 // match, scan (records in w, as the full scan leaves them).  Asynchronous.
 // init_keys: the batch's keys are set to (+INF, 0) by the first kernel of the chain.
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q_dev, const float *r_dev, long long base,
-                           u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys);
+                           u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys, int *out_idx = nullptr);
 
 // Builds the filter layouts for refs[0..n) (device, AoS).  Synchronous.  Leaves st.usable false
 // (and returns hipSuccess) when the data rules the filter out.
@@ -229,17 +279,30 @@ int knn_rccl_allreduce_min(int ndev, const int *devices, u64 *const *keys, int m
 #endif
 
 // want_cells != 0: also sort the layout into cells (k <= 16, large shards; see CellIndex).
+// geom != null (cell-range shard `rank`): centre, scale and cuts are the global grid's; the layout is always cell-sorted.
 hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r_dev, hipStream_t stream,
-                            int want_cells = 0);
+                            int want_cells = 0, const ShardGeom *geom = nullptr, int rank = 0, unsigned *bad_rows_out = nullptr);
+// The global grid of a cell-range sharded set from a sample of it (host rows, samples x k): false when the set does not suit
+// (k > 16, too few rows per rank for a cell-sorted layout, a degenerate or non-finite sample).
+bool knn_geom_cells(ShardGeom &g, int k, long long n_global, int nranks, const float *sample, long long samples, int seed_tiles);   // (the grid part of it)
+bool knn_geom_from_sample(ShardGeom &g, int k, long long n_global, int nranks, const float *sample, long long samples,
+                          int seed_tiles);
+// owner[i] = rank whose cell range holds rows[i] (device arrays).
+hipError_t knn_geom_assign_launch(const ShardGeom &g, const float *rows_dev, long long n, int *owner_dev, hipStream_t s);
+// This rank's part of the seed layer, written into the whole-layer buffer `layer_dev` (device; the caller all-gathers the parts).
+hipError_t knn_cells_seed_export(const FilterState &st, int rank, unsigned char *layer_dev, hipStream_t s);
+// != 0 when gids[0 .. n) is not strictly ascending (device array).  Synchronous.
+hipError_t knn_gids_check(const unsigned *gids_dev, long long n, unsigned *bad_out, hipStream_t s);
 // Host rows -> device rows (r_dev, n x k floats) + filter layouts, chunk by chunk under the copy.  Synchronous.
 hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
                                       hipStream_t copy, hipStream_t compute);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.
 // init_keys: the keys are written from scratch ((+INF, 0) first) instead of min-folded into what they hold.
+// out_idx (nullable): the int32 indices of the batch as well (no separate unpack launch on the cell-pruned path).
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q_dev, const float *r_dev,
                             long long base, u64 *keys_dev, int num_cu, hipStream_t stream,
-                            hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys = false);
+                            hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys = false, int *out_idx = nullptr);
 // Test hook: raw filter scores S[m][n] (row-major) and the per-query thresholds for a query
 // batch, plus {sigma, eta, rho, amax, bmax}.  Synchronous.
 hipError_t knn_filter_debug(FilterState &st, int m, const float *q_dev, const float *r_dev,

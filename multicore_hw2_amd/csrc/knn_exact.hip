@@ -20,26 +20,13 @@
 //
 // This is not a translation of the reference's one-block-per-query kernels (core.cu:808-855):
 // no SoA transpose pass, no per-block result array, no host second-level reduce.
-#include "knn_common.h"
+#include "knn_exact_dev.h"
 
 #include <math.h>
 #include <stdlib.h>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-#define KNN_BLOCK 256
-#define KNN_WAVES (KNN_BLOCK / KNN_WAVE)
-
-__device__ __forceinline__ u64 pack_key(float d2, unsigned idx)
-{
-    return ((u64)__float_as_uint(d2) << 32) | (u64)idx;
-}
-
-__device__ __forceinline__ void key_atomic_min(u64 *p, u64 key)
-{
-    // gfx950: global_atomic_umin_x2, device scope (all XCDs).
-    __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ------------------------------------------------------------------------------------------
 // qreg: queries in VGPRs (pairs packed as float2), references streamed as wave-uniform rows.
@@ -299,15 +286,6 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg1(const float *__rest
 //   K > 0: compile-time dimension (rows read with the widest aligned loads the compiler
 //   finds); K == 0: run-time k.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 wave_min_u64(u64 v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const u64 o = __shfl_xor(v, off, KNN_WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
-}
 
 template <int K, int QT>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane(const float *__restrict__ Q,
@@ -502,71 +480,6 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_rlane16(const float *__re
 // references one lane of a 32x32 MFMA tile covers: (query << 32) | (ref_tile << 1) | half, rows
 // 8g + 4*half + i (g, i in 0..3) of that tile.  One (record, row) pair per thread, v0 arithmetic.
 // ------------------------------------------------------------------------------------------
-// One (record, row) pair: the packed key of row `reg` of record e for its query, ~0 when there is nothing to evaluate.
-template <int K>
-__device__ __forceinline__ u64 rerank_pair(const float *__restrict__ Q, const float *__restrict__ R, int k, long long n,
-                                           long long base, u64 e, unsigned reg, unsigned rmask, unsigned qrow_base,
-                                           const unsigned *__restrict__ perm, unsigned &qi)
-{
-#pragma clang fp contract(off)
-    qi = (unsigned)(e >> 32) + qrow_base;
-    const unsigned lo = (unsigned)(e & 0xFFFFFFFFull);
-    long long ri = (long long)(lo >> 1) * 32 + 8 * (reg >> 2) + 4 * (lo & 1u) + (reg & 3u);
-    // rows the filter already proved to be above the threshold are not the answer: skip them
-    bool live = ri < n && ((rmask >> reg) & 1u);
-    if (perm && live) {  // cell-sorted layout: position -> row, padding positions hold ~0u
-        const unsigned row = perm[ri];
-        live = row != 0xFFFFFFFFu;
-        ri = (long long)row;
-    }
-    if (!live)
-        return ~0ull;
-    const float *__restrict__ q = Q + (size_t)qi * k;
-    const float *__restrict__ r = R + (size_t)ri * k;
-    float acc = 0.0f;
-    if (K > 0) {
-        float qv[K > 0 ? K : 1], rv[K > 0 ? K : 1];
-#pragma unroll
-        for (int d = 0; d < K; ++d) {
-            qv[d] = q[d];
-            rv[d] = r[d];
-        }
-#pragma unroll
-        for (int d = 0; d < K; ++d) {
-            const float diff = qv[d] - rv[d];
-            const float sq = diff * diff;
-            acc = acc + sq;
-        }
-    } else {
-        // run-time k: chunks of 16 with all 32 loads of a chunk in flight together
-        // (a plain scalar loop is one dependent round trip per dimension); the
-        // accumulation order stays d = 0..k-1
-        int d = 0;
-        for (; d + 16 <= k; d += 16) {
-            float qv[16], rv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                qv[j] = q[d + j];
-                rv[j] = r[d + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float diff = qv[j] - rv[j];
-                const float sq = diff * diff;
-                acc = acc + sq;
-            }
-        }
-        for (; d < k; ++d) {
-            const float diff = q[d] - r[d];
-            const float sq = diff * diff;
-            acc = acc + sq;
-        }
-    }
-    if (acc < INFINITY)  // false for NaN too: v0 never selects those
-        return pack_key(acc, (unsigned)(base + ri));
-    return ~0ull;
-}
-
 template <int K, bool LPW = false>  // K > 0: compile-time dimension (all row loads issue before the first use)
 __global__ __launch_bounds__(KNN_BLOCK) void knn_rerank_kernel(const float *__restrict__ Q,
                                                                const float *__restrict__ R, int krt,
@@ -996,127 +909,6 @@ hipError_t knn_rerank_launch(int k, long long n, const float *q, const float *r,
     }
 #undef KNN_RERANK
 #undef KNN_RERANK_LPW
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Exact evaluation of the cell-pruned path's listed (cell, query) pairs — what a batch falls back to when the fp16 scores
-// cannot tell its candidates apart (rows of a cluster tighter than the fp16 step: every row of the query's cells passes the
-// threshold and the record buffers overflow).  The geometry still rules out every cell it ruled out before (the lower
-// bounds are exact arithmetic on the fp32 coordinates), so the exact v0 arithmetic runs over the same (item, listed query)
-// pairs the MFMA scan visited instead of over the whole shard: for 64 clusters of 2^16 rows that is 1/64 of the pairs.
-// A wave takes items w, w + W, ...; per pass its lanes hold CX_ROWS rows each (fetched through perm: layout position ->
-// row) and walk the list — the query's coordinates are wave-uniform loads.  Gated on the device: ctl[EXACT_CELLS] raised
-// by the re-rank when it finds the shared overflow area over-full, and FALLBACK not raised (then the whole shard is
-// scanned anyway).  K > 0: compile-time dimension; 0: run-time k <= 16.
-// ------------------------------------------------------------------------------------------
-#define CX_ROWS 4
-template <int K>
-__global__ __launch_bounds__(KNN_BLOCK) void knn_cells_exact_kernel(
-    const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long base,
-    const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
-    const unsigned short *__restrict__ lists, unsigned cap, const unsigned *__restrict__ perm,
-    const unsigned *__restrict__ ctl, u64 *__restrict__ keys)
-{
-#pragma clang fp contract(off)
-    if (ctl[KNN_CTL_EXACT_CELLS] == 0u || ctl[KNN_CTL_FALLBACK] != 0u)
-        return;
-    constexpr int KD = K > 0 ? K : 16;
-    const int k = K > 0 ? K : krt;
-    const int lane = threadIdx.x & (KNN_WAVE - 1);
-    const unsigned wave = blockIdx.x * (unsigned)KNN_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * (unsigned)KNN_WAVES;
-    for (unsigned it = wave; it < nitems; it += nwaves) {
-        const u64 item = items[it];
-        const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item >> 48));
-        const unsigned tb = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item & 0xFFFFFFFFull));
-        const unsigned nt = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(item >> 40) & 0xFFu));
-        unsigned nq = (unsigned)__builtin_amdgcn_readfirstlane((int)cell_counts[cell]);
-        if (nq == 0u)
-            continue;
-        const bool dense = nq > cap;   // the list was cut short: every query of the batch (as in the MFMA scan)
-        if (dense)
-            nq = (unsigned)m;
-        const unsigned short *__restrict__ list = lists + (size_t)cell * cap;
-        const unsigned p_end = (tb + nt) * 32u;
-        for (unsigned p0 = tb * 32u; p0 < p_end; p0 += 64u * CX_ROWS) {
-            float rv[CX_ROWS][KD];
-            unsigned row[CX_ROWS];
-#pragma unroll
-            for (int j = 0; j < CX_ROWS; ++j) {
-                const unsigned pos = p0 + (unsigned)j * 64u + (unsigned)lane;
-                row[j] = pos < p_end ? perm[pos] : 0xFFFFFFFFu;   // ~0u: padding position
-                const float *__restrict__ x = R + (size_t)(row[j] != 0xFFFFFFFFu ? row[j] : 0u) * k;
-#pragma unroll
-                for (int d = 0; d < KD; ++d)
-                    rv[j][d] = d < k ? x[d] : 0.0f;
-            }
-            // the list 64 entries at a time on the lanes; the NEXT query's row and current key are requested before this
-            // one's distances are computed (three dependent round trips per query — list entry, row, key — were 0.24 ms
-            // for 64 clusters of 2^16 rows; the key may be stale: keys[] only ever decreases, a stale read costs a spare
-            // reduction)
-            for (unsigned e0 = 0u; e0 < nq; e0 += 64u) {
-                const unsigned idx = min(e0 + (unsigned)lane, nq - 1u);
-                const unsigned lq = dense ? idx : (unsigned)list[idx];
-                const int cq = (int)min(64u, nq - e0);
-                unsigned qid = (unsigned)__builtin_amdgcn_readlane((int)lq, 0);
-                float qv[KD];
-#pragma unroll
-                for (int d = 0; d < KD; ++d)
-                    qv[d] = d < k ? Q[(size_t)qid * k + d] : 0.0f;
-                u64 cur = keys[qid];
-                for (int j = 0; j < cq; ++j) {
-                    const unsigned qid_n = (unsigned)__builtin_amdgcn_readlane((int)lq, min(j + 1, cq - 1));
-                    float qn[KD];
-#pragma unroll
-                    for (int d = 0; d < KD; ++d)
-                        qn[d] = d < k ? Q[(size_t)qid_n * k + d] : 0.0f;
-                    const u64 cur_n = keys[qid_n];
-                    u64 best = ~0ull;
-#pragma unroll
-                    for (int jr = 0; jr < CX_ROWS; ++jr) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int d = 0; d < KD; ++d)
-                            if (d < k) {   // v0's order and operations: diff, square, add (no contraction)
-                                const float diff = qv[d] - rv[jr][d];
-                                const float sq = diff * diff;
-                                acc = acc + sq;
-                            }
-                        if (row[jr] != 0xFFFFFFFFu && acc < INFINITY) {
-                            const u64 key = pack_key(acc, (unsigned)(base + (long long)row[jr]));
-                            best = key < best ? key : best;
-                        }
-                    }
-                    if (__ballot(best < cur) != 0ull) {   // wave-uniform
-                        const u64 wmin = wave_min_u64(best);
-                        if (lane == 0)
-                            key_atomic_min(&keys[qid], wmin);
-                    }
-#pragma unroll
-                    for (int d = 0; d < KD; ++d)
-                        qv[d] = qn[d];
-                    cur = cur_n;
-                    qid = qid_n;
-                }
-            }
-        }
-    }
-}
-
-hipError_t knn_cells_exact_launch(int k, int m, long long base, const float *q, const float *r, const u64 *items,
-                                  unsigned nitems, const unsigned *cell_counts, const unsigned short *lists, unsigned cap,
-                                  const unsigned *perm, const unsigned *ctl, u64 *keys, int num_cu, hipStream_t s)
-{
-    if (nitems == 0u || m <= 0)
-        return hipSuccess;
-    unsigned blocks = (unsigned)num_cu * 8u;
-    if (blocks * KNN_WAVES > nitems)
-        blocks = (nitems + KNN_WAVES - 1u) / KNN_WAVES;
-    switch (k) {
-    case 16: hipLaunchKernelGGL(knn_cells_exact_kernel<16>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, k, m, base, items, nitems, cell_counts, lists, cap, perm, ctl, keys); break;
-    case 8: hipLaunchKernelGGL(knn_cells_exact_kernel<8>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, k, m, base, items, nitems, cell_counts, lists, cap, perm, ctl, keys); break;
-    default: hipLaunchKernelGGL(knn_cells_exact_kernel<0>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, k, m, base, items, nitems, cell_counts, lists, cap, perm, ctl, keys); break;
-    }
     return hipGetLastError();
 }
 

@@ -1284,12 +1284,125 @@ static double robust_box(const std::vector<float> &samp, long long samples, int 
     return h;
 }
 
-hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s, int want_cells)
+// Centre and power-of-two scale of a sample's robust box (what knn_filter_build_from_host derives from its host sample):
+// false when the sample holds non-finite values or its box is degenerate.
+static bool box_from_sample(const float *sample, long long samples, int k, int kp, std::vector<float> &center, float *sigma_out)
+{
+    const long long sub = samples >= 4096 ? 4 : 1, nsub = samples / sub;
+    std::vector<float> samp((size_t)nsub * k), dlo((size_t)k, INFINITY), dhi((size_t)k, -INFINITY);
+    for (long long i = 0; i < samples; ++i) {
+        const float *x = sample + (size_t)i * k;
+        for (int d = 0; d < k; ++d) {
+            const float v = x[d];
+            if (!(fabsf(v) < INFINITY))
+                return false;
+            if (i % sub == 0 && i / sub < nsub)
+                samp[(size_t)(i / sub) * k + d] = v;
+            dlo[(size_t)d] = fminf(dlo[(size_t)d], v);
+            dhi[(size_t)d] = fmaxf(dhi[(size_t)d], v);
+        }
+    }
+    for (int d = 0; d < k; ++d) {   // the sample's range, widened by 1 / 32 of its width
+        const float pad = (dhi[(size_t)d] - dlo[(size_t)d]) * (1.0f / 32.0f);
+        dlo[(size_t)d] -= pad;
+        dhi[(size_t)d] += pad;
+    }
+    const double h = robust_box(samp, nsub, k, kp, dlo, dhi, center);
+    if (!(h <= 1e15) || (h != 0.0 && h < 1e-15))
+        return false;
+    float sigma = 1.0f;
+    if (h > 0.0) {
+        int ex;
+        (void)frexp(h, &ex);
+        sigma = (float)ldexp(1.0, -ex);
+    }
+    *sigma_out = sigma;
+    return true;
+}
+
+bool knn_geom_from_sample(ShardGeom &g, int k, long long n_global, int nranks, const float *sample, long long samples,
+                          int seed_tiles)
+{
+    if (!sample || k < 1 || k > 16)
+        return false;
+    std::vector<float> center;
+    float sigma = 1.0f;
+    if (!box_from_sample(sample, samples, k, 16, center, &sigma))
+        return false;
+    if (!knn_geom_cells(g, k, n_global, nranks, sample, samples, seed_tiles))
+        return false;
+    for (int d = 0; d < 16; ++d)
+        g.center[d] = d < k ? center[(size_t)d] : 0.0f;
+    g.sigma = sigma;
+    return true;
+}
+
+hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r, hipStream_t s, int want_cells,
+                            const ShardGeom *geom, int rank, unsigned *bad_rows_out)
 {
     st = FilterState();
     const int kt = knn_kt_of(k);
     if (n <= 0 || kt == 0)
         return hipSuccess;
+    if (geom) {
+        // Cell-range shard of a global grid: centre, scale and cuts are the grid's (identical on every rank: the ranks' fp16
+        // fragments — the seed layer — must live in one frame), the layout is this rank's cells of it.
+        if (kt != 1 || geom->k != k)
+            return hipSuccess;
+        long long ntiles = 0;
+        unsigned *cell_code = nullptr, *cell_fill = nullptr;
+        std::vector<float> none;
+        FTRY(knn_cells_build(&st.cells, k, n, r, none, 0, s, &ntiles, &cell_code, &cell_fill, want_cells == 2, geom, rank, bad_rows_out));
+        if (!st.cells)
+            return hipSuccess;
+        st.k = k;
+        st.kt = 1;
+        st.n = n;
+        st.ntiles = ntiles;
+        st.sigma = geom->sigma;
+        unsigned *dout = nullptr;
+        hipError_t e = KNN_DEV_ALLOC((void **)&st.center, 16 * sizeof(float));
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * 64 * 16);
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&st.ref_norms2, (size_t)ntiles * 32 * sizeof(unsigned));
+        const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
+        if (e == hipSuccess)
+            e = KNN_DEV_ALLOC((void **)&dout, 4 * sizeof(unsigned));
+        if (e == hipSuccess)
+            e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(st.center, geom->center, 16 * sizeof(float), hipMemcpyHostToDevice, s);
+        unsigned hout[4] = {0, 0, 0, 0};
+        if (e == hipSuccess)
+            e = knn_cells_place_rows(st, r, cell_code, cell_fill, dout, ocap, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        (void)KNN_DEV_FREE(cell_code);
+        (void)KNN_DEV_FREE(cell_fill);
+        (void)KNN_DEV_FREE(st.cells->tmp_rows);
+        (void)KNN_DEV_FREE(st.cells->tmp_meta);
+        (void)KNN_DEV_FREE(st.cells->bucket_start);
+        st.cells->tmp_rows = nullptr;
+        st.cells->tmp_meta = nullptr;
+        st.cells->bucket_start = nullptr;
+        (void)KNN_DEV_FREE(dout);
+        if (e != hipSuccess || hout[2] != 0u || hout[3] > ocap) {   // (too many rows outside the global box: no layouts)
+            knn_filter_free(st);
+            return e;
+        }
+        st.n_outliers = hout[3];
+        memcpy(&st.bmax, &hout[0], 4);
+        memcpy(&st.nmax, &hout[1], 4);
+        st.usable = true;
+        return hipSuccess;
+    }
     const int kp = 16 * kt;
     long long ntiles = (n + 31) / 32;
     const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
@@ -2066,7 +2179,8 @@ static hipError_t launch_filter_chunked(FilterState &st, FilterWorkspace &w, int
 }
 
 hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, const float *r, long long base,
-                            u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys)
+                            u64 *keys, int num_cu, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool init_keys,
+                            int *out_idx)
 {
     FilterWorkspace &w = st.ws[slot];
     const unsigned *perm = st.cells ? st.cells->perm : nullptr;
@@ -2085,15 +2199,7 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
             const int mb = std::min(KNN_CELL_BATCH, m - q0);
             const float *qb = q + (size_t)q0 * st.k;
             u64 *kb = keys + q0;
-            FTRY(knn_cells_query(st, w, mb, qb, r, base, kb, num_cu, q0 == 0, s, init_keys));   // (the prep kernel starts the keys)
-            FTRY(knn_rerank_launch(st.k, positions, qb, r, base, w.records, nullptr, w.counts, w.nlists, w.slice, w.ctl_cur,
-                                   kb, w.pieces, s, perm, w.ovf_base, w.ovf_cap));
-            FTRY(knn_exact_gather_launch(st.k, mb, st.n_outliers, base, qb, r, st.outliers, kb, num_cu, nullptr, s));
-            // gated on the device, both: the listed pairs exactly when the records overflowed, the whole shard when the
-            // batch has a query nothing bounds
-            FTRY(knn_cells_exact_launch(st.k, mb, base, qb, r, st.cells->items, st.cells->nitems, w.cell_counts, w.cell_lists,
-                                        st.cells->cap, perm, w.ctl_cur, kb, num_cu, s));
-            FTRY(knn_exact_launch(st.k, mb, st.n, base, qb, r, kb, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
+            FTRY(knn_cells_query(st, w, mb, qb, r, base, kb, num_cu, q0 == 0, s, init_keys, out_idx ? out_idx + q0 : nullptr));
         }
         return hipSuccess;
     }
@@ -2136,7 +2242,10 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     // rows outside the robust box never entered the filter: exact scan of that (short) list
     FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
     // gated: runs only if the filter was ruled out on the device (bad queries, overflow)
-    return knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl + KNN_CTL_FALLBACK, s);
+    FTRY(knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl + KNN_CTL_FALLBACK, s));
+    if (out_idx)
+        FTRY(knn_keys_unpack_launch(keys, m, out_idx, s));
+    return hipSuccess;
 }
 
 hipError_t knn_filter_debug(FilterState &st, int m, const float *q, const float *r, float *scores,

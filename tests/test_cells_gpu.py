@@ -24,8 +24,22 @@ def _need_gpu():
 
 
 def _query(ix, Q):
-    got = ix.query(Q)
-    return got, ix.last_stats()
+    """One batch through the device API the way a resident caller drives it (knn_index_query: keys started inside the call,
+    int32 indices written by whichever block ends the batch), cross-checked against the keys' own index halves and against
+    the host-in / host-out convenience entry."""
+    dev = torch.device("cuda:0")
+    Qf = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1)
+    m = Qf.size // ix.k
+    q_d = torch.from_numpy(Qf).to(dev)
+    keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out = torch.full((m,), -7, dtype=torch.int32, device=dev)
+    ix.query_keys(m, q_d.data_ptr(), keys.data_ptr(), init_keys=True, indices_dev=out.data_ptr())
+    torch.cuda.synchronize()
+    st = ix.last_stats()
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal((keys.cpu().numpy() & 0xFFFFFFFF).astype(np.int32), got)
+    np.testing.assert_array_equal(ix.query(Q), got)
+    return got, st
 
 
 def _cases(rng, name, k, m, n):

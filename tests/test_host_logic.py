@@ -111,7 +111,8 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
     hold v_sub/v_mul/v_add (or their packed forms), never an FMA."""
     found = 0
     # (a kernel's body runs to its .Lfunc_end label: kernels with early returns hold several s_endpgm)
-    for fname, pattern, least in (("knn_exact.hip", r"knn_exact|knn_rerank|knn_cells_exact", 13),):
+    # (the cell-pruned scan re-ranks its own records and the tail kernel evaluates listed pairs: v0 arithmetic in knn_cells.hip too)
+    for fname, pattern, least in (("knn_exact.hip", r"knn_exact|knn_rerank", 10), ("knn_cells.hip", r"knn_cells_scan|knn_cells_tail", 7)):
         src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", fname)
         asm = tmp_path / (fname + ".s")
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
@@ -124,7 +125,7 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
             assert not bad, (name, bad[:3])
             assert re.search(r"v_(pk_)?mul_f32", body), name
             found += 1
-    assert found >= 13, found
+    assert found >= 17, found
 
 
 
