@@ -58,6 +58,16 @@ def parse_args():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: any other library option (knn_set_option), e.g. --opt scan_deal=2 --opt scan_blocks=1")
     ap.add_argument("--serial", action="store_true", help="one batch in flight (no overlap of consecutive steps)")
+    ap.add_argument("--shard", choices=["auto", "cells", "index"], default="auto",
+                    help="N > 1: how the reference set is split over the ranks.  index = contiguous index ranges (reference "
+                         "core.cu:875-883: every rank grids its own n / N rows); cells = contiguous ranges of the cell codes of ONE "
+                         "global grid (knn_geom_*: the rows move to their ranks by an all-to-all at index build, the ranks' scans "
+                         "add up to one GPU's); auto = cells where the pruned path serves the shape (k <= 16, enough rows per rank)")
+    ap.add_argument("--seed-tiles", type=int, default=0, help="cell-range shards: tiles of every cell in the replicated seed layer (0 = library default)")
+    ap.add_argument("--emulate", default="", metavar="N[:r]",
+                    help="one GPU plays rank r (default 0) of an N-rank cell-range sharded run: the whole set is generated here, "
+                         "all N shards are built (their seed layer is needed), rank r's step is timed — no collective.  For the "
+                         "per-rank projections under profiles/ when no multi-GPU node is at hand")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -188,6 +198,12 @@ def main():
         pkg.set_option("cells", args.cells)
 
     stream = torch.cuda.current_stream().cuda_stream
+    emu_n, emu_r = 0, 0
+    if args.emulate:
+        parts = args.emulate.split(":")
+        emu_n, emu_r = int(parts[0]), int(parts[1]) if len(parts) > 1 else 0
+        assert world == 1 and 1 <= emu_n <= 64 and 0 <= emu_r < emu_n, "--emulate N[:r] runs on ONE GPU"
+    nshards = emu_n if emu_n else world
     lo, hi = pkg.shard_bounds(n, world)[rank] if rank < len(pkg.shard_bounds(n, world)) else (n, n)
     n_local = hi - lo
     # synthetic uniform [0,1) inputs generated on the device (counter-based: each rank fills its
@@ -196,6 +212,96 @@ def main():
     q_d = torch.empty(m * k, dtype=torch.float32, device=dev)
     pkg.synth_fill_device(r_d.data_ptr(), n_local * k, 1001, first=lo * k, device=local_rank, stream=stream)
     pkg.synth_fill_device(q_d.data_ptr(), m * k, 1000, device=local_rank, stream=stream)
+    # ---- N > 1 (or --emulate): cell-range shards.  Every rank holds rows [lo, hi) of the global set as generated; they move
+    # to the rank whose range of the global grid's cell codes they fall into (index build: untimed, like the layouts).
+    shard_mode = "index"
+    cells_ok = k <= 16 and pkg.get_option("path") in (0, 2) and pkg.get_option("cells") != 2
+    if nshards > 1 and args.shard != "index" and cells_ok:
+        shard_mode = "cells"
+    geom, gids_d, layer_d, shard_note = None, None, None, None
+    if shard_mode == "cells":
+        torch.cuda.synchronize()
+        t_part = time.perf_counter()
+        rows2d = r_d[: n_local * k].reshape(n_local, k)
+        # 1. ONE grid from a sample of the global set: every rank's strided sample, gathered (identical input on every rank)
+        per_rank = 8192 if emu_n == 0 else 8192 * emu_n
+        samp = rows2d[:: max(1, n_local // per_rank)][:per_rank].contiguous()
+        if dist is not None:
+            gathered = [torch.empty_like(samp) for _ in range(world)]
+            if rehearse:
+                gl = [torch.empty(samp.shape, dtype=samp.dtype) for _ in range(world)]
+                dist.all_gather(gl, samp.cpu())
+                gathered = gl
+            else:
+                dist.all_gather(gathered, samp)
+            samp = torch.cat([g_.to("cpu") for g_ in gathered])
+        try:
+            geom = pkg.KnnGeom(k, n, nshards, samp.cpu().numpy(), args.seed_tiles)
+        except pkg.KnnError as exc:
+            if args.shard == "cells":
+                raise
+            sys.stderr.write("bench.py: %s\nbench.py: falling back to index-range shards\n" % exc)
+            shard_mode = "index"
+    if shard_mode == "cells":
+        # 2. where every row belongs; rows and their global numbers sorted by destination (stable: ascending per destination)
+        owner = torch.empty(n_local, dtype=torch.int32, device=dev)
+        geom.assign(rows2d.data_ptr(), n_local, owner.data_ptr(), device=local_rank, stream=stream)
+        torch.cuda.synchronize()
+        my = emu_r if emu_n else rank
+        counts = torch.bincount(owner, minlength=nshards).to(torch.int64)
+
+        def all_to_all(send, in_split, out_split):
+            """rows of `send` (sorted by destination) -> the rows every rank sends here, in source order"""
+            out = torch.empty((int(sum(out_split)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            if rehearse:      # gloo moves CPU tensors
+                o_cpu, s_cpu = out.cpu(), send.cpu()
+                dist.all_to_all_single(o_cpu, s_cpu, output_split_sizes=out_split, input_split_sizes=in_split)
+                return o_cpu.to(send.device)
+            dist.all_to_all_single(out, send, output_split_sizes=out_split, input_split_sizes=in_split)
+            return out
+
+        if emu_n:
+            # one GPU plays every rank in turn: the others' shards exist only long enough to export their seed tiles
+            layer_d = torch.zeros(geom.layer_bytes, dtype=torch.uint8, device=dev)
+            mine_rows = mine_gids = None
+            for r_ in range(emu_n):
+                g_ = torch.nonzero(owner == r_).reshape(-1)
+                rows_r = rows2d[g_].contiguous()
+                gids_r = (g_ + lo).to(torch.int32)
+                ix_ = pkg.KnnIndex.sharded(geom, r_, rows_r.data_ptr(), gids_r.data_ptr(), rows_r.shape[0], device=local_rank, stream=stream)
+                ix_.seed_export(layer_d.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                ix_.close()
+                if r_ == emu_r:
+                    mine_rows, mine_gids = rows_r, gids_r
+                del rows_r, gids_r, g_
+            rows_d, gids_d = mine_rows, mine_gids
+        else:
+            order = torch.argsort(owner, stable=True)
+            send_rows = rows2d[order].contiguous()
+            send_gids = (order + lo).to(torch.int32)
+            cnt_out = torch.empty(world, dtype=torch.int64, device=dev)
+            if rehearse:
+                c_cpu = torch.empty(world, dtype=torch.int64)
+                dist.all_to_all_single(c_cpu, counts.cpu())
+                cnt_out = c_cpu.to(dev)
+            else:
+                dist.all_to_all_single(cnt_out, counts)
+            in_split, out_split = [int(c_) for c_ in counts.tolist()], [int(c_) for c_ in cnt_out.tolist()]
+            rows_d = all_to_all(send_rows, in_split, out_split)
+            gids_d = all_to_all(send_gids, in_split, out_split)
+            del send_rows, send_gids, order
+        del owner
+        r_d = rows_d.reshape(-1)            # this rank's rows from here on
+        n_local = rows_d.shape[0]
+        torch.cuda.synchronize()
+        shard_note = {"partition": "cell ranges of one global grid of 2^%d cells (%d per rank at most), seed layer %d tile(s) per cell = "
+                                   "%.0f MB replicated" % (geom.bits, geom.cells_per_rank, geom.seed_tiles, geom.layer_bytes / 1e6),
+                      "partition_ms": (time.perf_counter() - t_part) * 1e3, "rows_this_rank": int(n_local)}
+        if emu_n:
+            shard_note["emulated"] = "one GPU as rank %d of %d (no collective in the step)" % (emu_r, emu_n)
+            args.cpu_queries = 0     # (one rank's answers are not the set's: parity of the shards is tests/test_shards_gpu.py's job)
+        assert not args.separate_init, "a cell-range shard starts its keys itself (KNN_QUERY_INIT_KEYS)"
     # Two batches in flight: step i runs on stream i&1 with the index's query workspace i&1 and its
     # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
     # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
@@ -203,7 +309,7 @@ def main():
     # (the library chains the scans of different slots for shards of >= 16M rows: two in flight are enough then)
     long_scan = n_local >= (1 << 24)
     cells_from = {0: (1 << 19) if k <= 12 else (1 << 20), 1: 1 << 17}.get(pkg.get_option("cells"))   # the library's policy
-    cells_expected = k <= 16 and cells_from is not None and n_local >= cells_from and pkg.get_option("path") in (0, 2)
+    cells_expected = (k <= 16 and cells_from is not None and n_local >= cells_from and pkg.get_option("path") in (0, 2)) or shard_mode == "cells"
     inflight = args.inflight if args.inflight > 0 else (2 if long_scan and not cells_expected else 4 if cells_expected and k > 4 else 3)
     nbuf = 1 if args.serial else max(1, min(8, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.
@@ -213,17 +319,38 @@ def main():
     outs = [outs_all[0, b] for b in range(nbuf)]
     # index build: the first one of a process also loads the code objects and fills the library's buffer pool (13 ms at C3
     # against 4.7 for every later one): built twice, both reported
+    def make_index():
+        if shard_mode == "cells":
+            return pkg.KnnIndex.sharded(geom, emu_r if emu_n else rank, r_d.data_ptr(), gids_d.data_ptr(), n_local,
+                                        device=local_rank, stream=stream)
+        return pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo, refs_on_device=True, stream=stream)
+
     t0 = time.perf_counter()
-    index = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo,
-                         refs_on_device=True, stream=stream)
+    index = make_index()
     torch.cuda.synchronize()
     prep_first_ms = (time.perf_counter() - t0) * 1e3
     index.close()
     t0 = time.perf_counter()
-    index = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo,
-                         refs_on_device=True, stream=stream)
+    index = make_index()
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) * 1e3
+    if shard_mode == "cells":
+        # the seed layer: every rank's part (the first tiles of each of its cells), gathered; replicated on every rank
+        t0 = time.perf_counter()
+        if not emu_n:
+            layer_d = torch.zeros(geom.layer_bytes, dtype=torch.uint8, device=dev)
+            index.seed_export(layer_d.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            part = layer_d[rank * geom.part_bytes:(rank + 1) * geom.part_bytes].clone()
+            if rehearse:
+                gl = [torch.empty(geom.part_bytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(gl, part.cpu())
+                layer_d.copy_(torch.cat(gl).to(dev))
+            else:
+                dist.all_gather_into_tensor(layer_d, part)
+        index.seed_attach(layer_d.data_ptr())
+        torch.cuda.synchronize()
+        shard_note["seed_layer_ms"] = (time.perf_counter() - t0) * 1e3
     nstreams = nbuf
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     # N > 1: the exchange step.  The nbuf batches in flight form a group whose packed keys are
@@ -522,7 +649,8 @@ def main():
             "dtype": "f32 results (f16 MFMA filter + f32 exact re-rank)" if path_taken in (2, 4) else "f32", "data": "synthetic",
             "config": {"workload": "%s: k=%d m=%d n=%d uniform[0,1) fp32, refs resident in HBM, sharded over n" %
                                    (wname, k, m, n),
-                       "n_per_gpu": n_local, "path": {1: "exact", 2: "mfma_filter+exact_rerank", 3: "grid_index",
+                       "n_per_gpu": n_local, "shards": shard_note if shard_note else ("index ranges (reference core.cu:875-883)" if world > 1 else None),
+                       "path": {1: "exact", 2: "mfma_filter+exact_rerank", 3: "grid_index",
                                                      4: "cell_pruned_mfma_filter+exact_rerank"}.get(path_taken),
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "index_prep_first_in_process_ms": prep_first_ms,

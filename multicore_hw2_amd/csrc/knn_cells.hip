@@ -729,21 +729,24 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 &a, const f4v *__restrict
 #define CELL_PREP_WAVES 4
 #define CELL_PREP_TILES 9     // seed tiles a wave requests at once (a cell of 144 .. 288 rows: one round trip)
 #define CELL_SEED_MAX_TILES 36u   // tiles of one seed cell a query looks at (a larger cell: every stride-th tile)
+#define CELL_OUTER_SEED_TILES 2   // cell-range shards: tiles an outer seed cell of this rank contributes (the layer's depth by default)
 
 // Where the seed tiles of cells OUTSIDE this index's range come from (cell-range shards; all zero otherwise): every rank's
 // part of the replicated seed layer, `tiles` tiles per cell (ShardGeom::part_bytes).
+#define KNN_MAX_RANKS 64
 struct SeedLayer {
     const unsigned char *base;
     unsigned cpr, tiles;             // cells a part has room for (the largest rank's), tiles per cell
-    unsigned ncells, nranks, gran;   // the global grid's cells, the ranks, the granule of their ranges (knn_shard_owner)
+    unsigned nranks;
     unsigned long long part_bytes;
+    unsigned first[KNN_MAX_RANKS + 1];   // first cell code of every rank's range (first[nranks] = the grid's cells)
 };
 
 // PW: waves per query, 4 or 2 (half the registers held while batches are in flight side by side, see knn_cells_query).
 // SD: seed dimensions — the seeds are the query's own cell and every combination of moves across its SD nearest cuts:
-//     2 (4 cells, each WHOLE) when the index holds the whole grid; 4 for a cell-range shard (16 cells: those of this rank
-//     whole, the others through the seed layer's few tiles — profiles/r04_shard_sim.txt: 236 cells per query and rank
-//     survive at N = 8 against 199 with the bound one GPU would have, 399 with 4 seed cells).
+//     2 = 4 cells (what ships; a cell of this index WHOLE, a cell of another rank through the seed layer's few tiles).  The
+//     kernel is generic in SD: 4 = 16 cells leaves fewer survivors (profiles/r04_shard_sim.txt: 236 cells per query and
+//     rank at N = 8 against 399, 199 with the bound one GPU would have) but measured slower end to end (knn_cells_query).
 template <int PW, int SD>
 __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
     const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
@@ -895,11 +898,18 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         if (code >= g.cell_base && l < g.ncells) {
             const unsigned tb = tile_start[l];
             v_nt = tile_start[l + 1u] - tb;
+            // (a shard's OUTER seeds — beyond the own cell and the cells across the two nearest cuts — give what the layer
+            // would: their first tiles.  Whole, the 16 local seed cells of a query that lives on this rank were 136 tiles
+            // against the 32 of everybody else's, and the launch lasted as long as those blocks: 36 us against 15)
+            if (SD > 2 && lane >= 4)
+                v_nt = min(v_nt, (unsigned)CELL_OUTER_SEED_TILES);
             v_fa = (unsigned long long)(rf + (size_t)tb * 64);
             v_na = (unsigned long long)(rn2 + (size_t)tb * 32);
         } else if (layer.base) {
-            const unsigned part = knn_shard_owner(code, layer.ncells, layer.nranks, layer.gran);
-            const unsigned cl = code - knn_shard_first_cell(part, layer.ncells, layer.nranks, layer.gran);
+            unsigned part = 0u;   // the rank whose range holds the cell (a table walk: no 64-bit divisions in here)
+            for (unsigned r = 1u; r < layer.nranks; ++r)
+                part += code >= layer.first[r] ? 1u : 0u;
+            const unsigned cl = code - layer.first[part];
             const unsigned char *pb = layer.base + (size_t)part * layer.part_bytes + KNN_SEED_HEADER_BYTES;
             v_nt = layer.tiles;
             v_fa = (unsigned long long)(pb + (size_t)cl * layer.tiles * 1024u);
@@ -940,30 +950,31 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
     // (all wave-uniform) run c: `cnt[c]` tiles fa[c] + v stride[c] KiB, norm words na[c] + v stride[c] 128 B
     auto score_runs = [&](const unsigned long long (&fa)[NS], const unsigned long long (&na)[NS], const unsigned (&cnt)[NS],
                           const unsigned (&stride)[NS]) __attribute__((always_inline)) {
-        unsigned total = 0u;
+        unsigned start[NS + 1];   // run c holds positions [start[c], start[c + 1]) of the list (constant indices only: these
+        start[0] = 0u;            // arrays must stay in registers — indexed by a run-time c they went to scratch memory)
 #pragma unroll
         for (int c = 0; c < NS; ++c)
-            total += cnt[c];
+            start[c + 1] = start[c] + cnt[c];
+        const unsigned total = start[NS];
         for (unsigned v0 = 0u; v0 < total; v0 += CELL_PREP_TILES) {
             h8 ar[CELL_PREP_TILES];
             unsigned nw[CELL_PREP_TILES];
 #pragma unroll
             for (int p = 0; p < CELL_PREP_TILES; ++p) {
-                unsigned v = v0 + (unsigned)p;   // position in the list -> (run, tile of the run)
+                const unsigned v = v0 + (unsigned)p;   // position in the list -> (run, tile of the run)
                 nw[p] = 0u;
                 if (v < total) {
                     unsigned long long f = fa[0], nn = na[0];
-                    unsigned st = stride[0];
+                    unsigned st = stride[0], vv = v;
 #pragma unroll
                     for (int c = 1; c < NS; ++c)
-                        if (v >= cnt[c - 1]) {   // (runs in order: past run c - 1)
-                            v -= cnt[c - 1];
+                        if (v >= start[c]) {   // (start[] ascends: the last run that matches is the one)
                             f = fa[c];
                             nn = na[c];
                             st = stride[c];
-                        } else
-                            break;
-                    const size_t t = (size_t)v * st;
+                            vv = v - start[c];
+                        }
+                    const size_t t = (size_t)vv * st;
                     ar[p] = ((const h8 *)f)[t * 64 + lane];
                     if (lane < 32)
                         nw[p] = ((const unsigned *)nn)[t * 32 + lane];
@@ -1360,11 +1371,13 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
 //   the area over-full (a cluster tighter than the fp16 step: the fp16 scores do not separate the batch's rows)
 //                                                                              -> the batch's listed (item, query) pairs
 //                                                                                 with the exact arithmetic (cells_exact_items)
-//   FALLBACK (a query nothing bounds: the gated exact scan in front of this launch has answered the batch), fin.defer
-//                                                                              -> only the finalisation
+//   FALLBACK (a query nothing bounds)                                          -> K = 16: the exact scan of the whole shard,
+//                                                                                 here (exact_qreg_body); other k: the gated
+//                                                                                 exact launch in front of this one has run
+//   fin.defer                                                                  -> only the finalisation
 template <int K>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
-    const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long npos, long long base,
+    const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long nrows, long long npos, long long base,
     const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
     const unsigned short *__restrict__ lists, unsigned cap, const unsigned *__restrict__ perm,
     const u64 *__restrict__ rec, unsigned ovf_base, unsigned ovf_cap, unsigned *__restrict__ ctl, u64 *__restrict__ keys,
@@ -1374,7 +1387,15 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
     const unsigned fb = ctl[KNN_CTL_FALLBACK], have = ctl[KNN_CTL_RECORDS];   // final: prep and the scan are complete
     if (!fin.defer && fb == 0u && have == 0u)
         return;
-    if (fb == 0u) {
+    if (fb != 0u) {
+        if constexpr (K == 16) {
+            // a query nothing bounds (not finite, far outside the box): v0's arithmetic over the whole shard, 512 queries per
+            // block (two per lane), slices of 1024 rows strided over the blocks
+            const unsigned qgroups = ((unsigned)m + 511u) / 512u, gx = gridDim.x / qgroups;
+            if (gx != 0u && blockIdx.x < gx * qgroups)
+                exact_qreg_body<16, 1>(Q, R, m, nrows, base, keys, 1024ll, blockIdx.x / qgroups, gx, blockIdx.x % qgroups);
+        }
+    } else {
         if (have > ovf_cap) {
             if (blockIdx.x == 0 && threadIdx.x == 0)
                 ctl[KNN_CTL_EXACT_CELLS] = 1u;   // (statistics: knn_index_last_stats[2] = 2)
@@ -1431,7 +1452,7 @@ __global__ __launch_bounds__(256) void knn_geom_assign_kernel(const float *__res
     for (int d = 0; d < g.k; ++d)
         if (g.nb[d])
             c |= cell_bin(s_bnd + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], R[(size_t)i * g.k + d]) << g.shift[d];
-    owner[i] = (int)knn_shard_owner(c, g.ncells, nranks, 1u << g.sa);
+    owner[i] = (int)knn_shard_owner(c, g.ncells, nranks, 1u << g.sa);   // (one 64-bit division per row: a build-time pass)
 }
 
 // This rank's part of the seed layer: for every cell of its range the first T tiles of the cell-sorted layout (fragments
@@ -1873,7 +1894,7 @@ CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems,
 // One batch of <= KNN_CELL_BATCH queries, the whole chain: prep -> match -> scan (its waves re-rank their own records) ->
 // [rows outside the robust box, exactly] -> the exact scan of the shard, gated on FALLBACK -> the tail kernel (gated: records
 // in the shared area, the listed pairs exactly when that area is over-full, the finalisation when the scan could not do it).
-// Five launches on clean data.  out_idx (nullable): int32 indices of the batch, written by whichever block ends it.
+// Four launches on clean data at k = 16 (the exact scan of the shard is a branch of the tail kernel there), five otherwise.  out_idx (nullable): int32 indices of the batch, written by whichever block ends it.
 hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const float *q, const float *r, long long base,
                            u64 *keys, int num_cu, bool timed, hipStream_t s, bool init_keys, int *out_idx)
 {
@@ -1911,9 +1932,9 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         layer.base = c.seed_layer;
         layer.cpr = c.geom->cells_per_rank;
         layer.tiles = (unsigned)c.geom->seed_tiles;
-        layer.ncells = c.geom->ncells;
         layer.nranks = (unsigned)c.geom->nranks;
-        layer.gran = 1u << c.geom->sa;
+        for (int r_ = 0; r_ <= c.geom->nranks && r_ <= KNN_MAX_RANKS; ++r_)
+            layer.first[r_] = c.geom->first_cell(r_);
         layer.part_bytes = c.geom->part_bytes();
     }
 #define KNN_PREP_LAUNCH(PWV, SDV)                                                                                          \
@@ -1921,9 +1942,12 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
                        c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,            \
                        st.ref_norms2, layer, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr,    \
                        w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init)
-    if (c.geom)   // cell-range shard: 16 seed cells (4 per wave, the other ranks' through the seed layer)
-        KNN_PREP_LAUNCH(4, 4);
-    else if (st.several_slots)
+    // (cell-range shards take the same four seed cells — those of another rank through the seed layer.  Sixteen seed cells
+    // (SD = 4) leave 20 % fewer candidates, as the simulation said, and cost more than they save: the prep kernel is a chain
+    // of dependent round trips, and at a rank's size the step is made of those — emulated rank of N = 8, ms per step / one
+    // batch at a time: 16 cells x 2 tiles 0.0302 / 0.0526, 8 x 2 0.0279 / 0.0493, 4 x 2 0.0275 / 0.0471, 4 x 4 0.0271 / 0.0473;
+    // N = 4: 0.0432 / 0.0423 / 0.0414 / 0.0408.  profiles/r04_seed_sweep.txt)
+    if (st.several_slots)
         KNN_PREP_LAUNCH(2, 2);
     else
         KNN_PREP_LAUNCH(4, 2);
@@ -1996,14 +2020,15 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         FTRY(hipEventRecord(w.ev_end, s));
     // rows outside the robust box never entered the layouts: exact scan of that (short) list
     FTRY(knn_exact_gather_launch(st.k, m, st.n_outliers, base, q, r, st.outliers, keys, num_cu, nullptr, s));
-    // gated on the device: the whole shard exactly when the batch has a query nothing bounds
-    FTRY(knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
+    // gated on the device: the whole shard exactly when the batch has a query nothing bounds (k = 16: inside the tail kernel)
+    if (st.k != 16)
+        FTRY(knn_exact_launch(st.k, m, st.n, base, q, r, keys, num_cu, w.ctl_cur + KNN_CTL_FALLBACK, s));
     {
         unsigned blocks = (unsigned)num_cu * 8u;
         if (blocks * KNN_WAVES > c.nitems)
-            blocks = (c.nitems + KNN_WAVES - 1u) / KNN_WAVES;
+            blocks = std::max(2u, (c.nitems + KNN_WAVES - 1u) / KNN_WAVES);
 #define KNN_TAIL_LAUNCH(KV)                                                                                                \
-    hipLaunchKernelGGL(knn_cells_tail_kernel<KV>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, npos, base, c.items,  \
+    hipLaunchKernelGGL(knn_cells_tail_kernel<KV>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, st.n, npos, base, c.items,  \
                        c.nitems, w.cell_counts, w.cell_lists, c.cap, c.perm, w.records, w.ovf_base, w.ovf_cap, w.ctl_cur,   \
                        keys, fin)
         switch (st.k) {

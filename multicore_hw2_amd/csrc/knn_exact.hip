@@ -25,7 +25,6 @@
 #include <math.h>
 #include <stdlib.h>
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 
 // ------------------------------------------------------------------------------------------
@@ -40,86 +39,9 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_qreg(const float *__restr
                                                             long long refs_per_block,
                                                             const unsigned *__restrict__ gate)
 {
-#pragma clang fp contract(off)
     if (gate && *gate == 0u)
         return;
-    const int lane = threadIdx.x & (KNN_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int q0 = (blockIdx.y * KNN_WAVES + wave) * (2 * QP * KNN_WAVE);
-    if (q0 >= m)
-        return;
-
-    f2 q[QP][K];
-    f2 best[QP];
-    unsigned bidx[2 * QP];
-#pragma unroll
-    for (int p = 0; p < QP; ++p) {
-        const int qa = min(q0 + (2 * p) * KNN_WAVE + lane, m - 1);
-        const int qb = min(q0 + (2 * p + 1) * KNN_WAVE + lane, m - 1);
-#pragma unroll
-        for (int d = 0; d < K; ++d) {
-            q[p][d].x = Q[(size_t)qa * K + d];
-            q[p][d].y = Q[(size_t)qb * K + d];
-        }
-        best[p].x = INFINITY;
-        best[p].y = INFINITY;
-        bidx[2 * p] = 0u;
-        bidx[2 * p + 1] = 0u;
-    }
-
-    // Slices are strided over: an ordinary launch has one block per slice; the GATED launch (the filter's
-    // device-side fallback, almost always a no-op) has at most ~5 resident blocks per CU, so looking at
-    // the flag costs a few hundred blocks instead of a full grid queued on every query.
-    for (long long i0 = (long long)blockIdx.x * refs_per_block; i0 < n; i0 += (long long)gridDim.x * refs_per_block) {
-    const long long i1 = min(n, i0 + refs_per_block);
-    unsigned gidx = (unsigned)(base + i0);  // global index of the current reference (low 32 bits)
-    const float *__restrict__ r = R + (size_t)i0 * K;
-
-#pragma unroll 2
-    for (long long i = i0; i < i1; ++i, ++gidx, r += K) {
-        float rv[K];
-#pragma unroll
-        for (int d = 0; d < K; ++d)
-            rv[d] = r[d];  // wave-uniform address -> scalar load
-#pragma unroll
-        for (int p = 0; p < QP; ++p) {
-            f2 acc = {0.0f, 0.0f};
-#pragma unroll
-            for (int d = 0; d < K; ++d) {
-                const f2 rr = {rv[d], rv[d]};
-                const f2 diff = q[p][d] - rr;
-                const f2 sq = diff * diff;
-                acc = acc + sq;
-            }
-            if (best[p].x > acc.x) {
-                best[p].x = acc.x;
-                bidx[2 * p] = gidx;
-            }
-            if (best[p].y > acc.y) {
-                best[p].y = acc.y;
-                bidx[2 * p + 1] = gidx;
-            }
-        }
-    }
-    }  // slices
-
-#pragma unroll
-    for (int p = 0; p < QP; ++p) {
-        const int qa = q0 + (2 * p) * KNN_WAVE + lane;
-        const int qb = q0 + (2 * p + 1) * KNN_WAVE + lane;
-        // best == +INF means no reference beat +INF: leave the key alone (v0 keeps index 0).
-        // (keys[] only decreases: a stale plain read can only cause a spare atomic, never skip one)
-        if (qa < m && best[p].x < INFINITY) {
-            const u64 key = pack_key(best[p].x, bidx[2 * p]);
-            if (key < keys[qa])
-                key_atomic_min(&keys[qa], key);
-        }
-        if (qb < m && best[p].y < INFINITY) {
-            const u64 key = pack_key(best[p].y, bidx[2 * p + 1]);
-            if (key < keys[qb])
-                key_atomic_min(&keys[qb], key);
-        }
-    }
+    exact_qreg_body<K, QP>(Q, R, m, n, base, keys, refs_per_block, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // Any k up to 16*KC without a compile-time K: the same scheme (queries in VGPRs, rows through

@@ -135,21 +135,29 @@ def test_bench_exchange_step_rehearsed_with_a_one_rank_rccl_group():
     assert doc["parity_spot_check"].startswith("8/8 sampled queries identical")
 
 
-def test_two_rank_bench_flow_rehearsed_on_one_gpu():
-    """The N = 2 flow of bench.py end to end — self-launch, one rank per shard of the SAME global set (rank 1's
-    index carries base_index = n/2), three batches in flight per rank, grouped MIN all-reduce of the packed keys,
-    unpack, oracle spot check of the reduced indices — with both ranks on GPU 0 and gloo as the transport (RCCL
-    refuses two ranks on one device).  What the 1-rank rehearsal cannot see: shard offsets and a real reduction."""
+@pytest.mark.parametrize("shard", ["index", "cells"])
+def test_two_rank_bench_flow_rehearsed_on_one_gpu(shard):
+    """The N = 2 flow of bench.py end to end — self-launch, one rank per shard of the SAME global set, four batches in flight
+    per rank, grouped MIN all-reduce of the packed keys, unpack, oracle spot check of the reduced indices — with both ranks
+    on GPU 0 and gloo as the transport (RCCL refuses two ranks on one device).  What the 1-rank rehearsal cannot see:
+    index: shard offsets (rank 1's index carries base_index = n/2) and a real reduction;
+    cells: the gathered sample -> one grid on both ranks, the all-to-all that moves every row (and its global number) to the
+           rank whose cell range holds it, the gathered seed layer, keys that carry global numbers when the batch ends."""
     env = dict(os.environ, KNN_BENCH_REHEARSE_ON_ONE_GPU="1")
     for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KNN_BENCH_FORCE_DIST"):
         env.pop(name, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "16,1024,2097152",
-                        "--steps", "20", "--warmup", "2", "--cpu-queries", "8"], capture_output=True, text=True, env=env,
-                       timeout=900)
+                        "--steps", "20", "--warmup", "2", "--cpu-queries", "8", "--shard", shard], capture_output=True, text=True,
+                       env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     doc = json.loads(lines[0])
-    assert doc["n_gpus"] == 2 and doc["config"]["n_per_gpu"] == 1 << 20 and doc["scaling"] == "strong"
+    assert doc["n_gpus"] == 2 and doc["scaling"] == "strong"
+    if shard == "index":
+        assert doc["config"]["n_per_gpu"] == 1 << 20 and "index ranges" in doc["config"]["shards"]
+    else:
+        assert abs(doc["config"]["n_per_gpu"] - (1 << 20)) < (1 << 20) * 0.05         # the grid's two halves: equal shares, nearly
+        assert "cell ranges of one global grid of 2^13 cells" in doc["config"]["shards"]["partition"]
     assert "all_reduce(min)" in doc["config"]["collective"]
     assert doc["parity_spot_check"].startswith("8/8 sampled queries identical")
