@@ -1126,6 +1126,28 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
         s_flag = ctl[KNN_CTL_FALLBACK];   // read once per block: see knn_cells_match_kernel
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
+    __shared__ unsigned s_next, s_imeta[DYN ? CELL_SCAN_CHUNK : 1], s_itb[DYN ? CELL_SCAN_CHUNK : 1], s_inq[DYN ? CELL_SCAN_CHUNK : 1];
+    const unsigned per_wave = (nitems + nwaves - 1u) / nwaves;
+    const unsigned per_block = (nitems + gridDim.x - 1u) / gridDim.x;
+    const unsigned i0 = min(blockIdx.x * per_block, nitems), i1 = min(i0 + per_block, nitems);
+    // DYN: the first chunk's descriptors — two dependent round trips (item -> its cell's list length) — are requested BEFORE
+    // the block fills its LDS (36 KiB of B operands and thresholds, one more round trip and a barrier): they overlap instead
+    // of queueing up in front of the first tile load, and one barrier pair goes (round 4: 114.4 -> 112.5 us at C3, rocprofv3).
+    // (The same for the fixed deal kept two more values alive across the fill: 16 bytes of scratch under the 80-register
+    // cap, and a kernel that uses scratch at all ran 7 % slower — 0.1197 -> 0.1283 ms on one box.  Left as it was.)
+    if constexpr (DYN) {
+        const unsigned nc0 = min((unsigned)CELL_SCAN_CHUNK, i1 - i0);
+        for (unsigned i = threadIdx.x; i < nc0; i += 64 * CELL_SCAN_WAVES) {
+            const u64 item = items[i0 + i];
+            s_imeta[i] = (unsigned)(item >> 40);
+            s_itb[i] = (unsigned)item;
+            s_inq[i] = cell_counts[(unsigned)(item >> 48)];
+        }
+        if (threadIdx.x == 0)
+            s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
+    }
+    // (LDS-DMA for this fill — no staging registers — measured: C3 -0.5 %, a rank of 8 +5 % per pipelined step.  Not taken.)
     for (int i = threadIdx.x; i < m_padded * 2; i += 64 * CELL_SCAN_WAVES)
         s_qf[i] = qfg[i];
     for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
@@ -1135,7 +1157,6 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
         return;
     f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
 
-    const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
     unsigned cnt = 0u;
     bool dead = false;                  // the shared area is over-full: stop scanning (wave-uniform)
@@ -1145,17 +1166,15 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     // DYN = true (small shards: an item or three per wave): the block owns a contiguous run of items and its waves take them
     // one by one from a counter in LDS — with the fixed deal the busiest wave of a 2^21-row shard had 115 tile steps against
     // 48.5 on average (lists of 76..160 queries, cells of 5..9 tiles) and the launch lasted as long as that wave.
-    __shared__ unsigned s_next, s_imeta[DYN ? CELL_SCAN_CHUNK : 1], s_itb[DYN ? CELL_SCAN_CHUNK : 1], s_inq[DYN ? CELL_SCAN_CHUNK : 1];
-    const unsigned per_wave = (nitems + nwaves - 1u) / nwaves;
-    const unsigned per_block = (nitems + gridDim.x - 1u) / gridDim.x;
-    const unsigned i0 = min(blockIdx.x * per_block, nitems), i1 = min(i0 + per_block, nitems);
-    unsigned c0 = i0, nc = 0u, mine_dyn = 0u;   // DYN: the chunk of the block's run whose tables are in LDS, this wave's item in it
+    // DYN: the chunk of the block's run whose tables are in LDS (the first one was filled above), this wave's item in it
+    unsigned c0 = i0, nc = min((unsigned)CELL_SCAN_CHUNK, i1 - i0), mine_dyn = (unsigned)wib;
     for (unsigned g0 = 0u;; g0 += 64u) {
         unsigned v_meta = 0u, v_tb = 0u, v_nq = 0u;
         if constexpr (DYN) {
-            if (g0 == 0u || mine_dyn >= nc) {   // block-uniform in effect: every wave runs dry before the barrier lets anyone on
-                if (g0 != 0u)
-                    c0 += CELL_SCAN_CHUNK;
+            if (g0 == 0u && c0 >= i1)
+                break;
+            if (g0 != 0u && mine_dyn >= nc) {   // block-uniform in effect: every wave runs dry before the barrier lets anyone on
+                c0 += CELL_SCAN_CHUNK;
                 if (c0 >= i1)
                     break;
                 nc = min((unsigned)CELL_SCAN_CHUNK, i1 - c0);

@@ -130,6 +130,29 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
+def test_hot_kernels_of_the_pruned_path_use_no_scratch_memory(tmp_path):
+    """Round 4 measured it twice: a kernel that spills even two dwords to scratch runs slower out of proportion (the scan with
+    16 bytes of scratch under its 80-register cap: 0.1197 -> 0.1283 ms at C3 on one box; the prep kernel with its seed runs
+    indexed at run time: 15 -> 36 us).  The code object's metadata says what the compiler did."""
+    src = os.path.join(ROOT, "multicore_hw2_amd", "csrc", "knn_cells.hip")
+    asm = tmp_path / "knn_cells.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           "-o", str(asm), src])
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm.read_text(), flags=re.S):
+        name, body = m.group(1), m.group(2)
+        if not re.search(r"knn_cells_(scan|prep|match|tail)_kernel", name):
+            continue
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert scratch == 0, (name, scratch)
+        if "scan" in name:
+            assert vgprs <= 80, (name, vgprs)       # six waves per SIMD: 512 / 6 rounded down to the allocation granule
+        seen += 1
+    assert seen >= 10, seen
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
 def test_filter_kernels_keep_mfma_results_12_wait_states_from_their_readers(tmp_path):
     """tools/mfma_hazard_audit.py: every v_mfma result in the filter kernels is first touched by a
     VALU/memory instruction >= 12 wait states later in fall-through order (a per-step branch
