@@ -104,8 +104,11 @@ static void cell_quantile_cuts(int k, const unsigned char nb[16], const float *s
             continue;
         for (long long i = 0; i < samples; ++i)
             col[(size_t)i] = samp[(size_t)i * k + d];
-        std::sort(col.begin(), col.end());
         const int nbins = 1 << nb[d];
+        if (nbins == 2)   // one cut: the median, without sorting the column
+            std::nth_element(col.begin(), col.begin() + samples / 2, col.end());
+        else
+            std::sort(col.begin(), col.end());
         for (int j = 1; j < nbins; ++j)
             bounds[(size_t)d * (CELL_MAX_BINS - 1) + (j - 1)] = col[(size_t)(j * samples / nbins)];
     }
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__rest
 // Scatter + layout in one pass (k <= 16): row i, read in row order, goes to the next free position of its
 // cell as an fp16 fragment + norm — what knn_frag_kernel would write there (same arithmetic, same outlier
 // rule), without a second pass that gathers 64-byte rows in cell order (8.8 ms for 2^24 rows, against 1.1).
-// frag / norms / norms2 / perm arrive pre-filled with the padding values (0, +INF, (+INF, 0), ~0u); out[] as in
+// (the padding positions of every cell are written afterwards by knn_cells_pad_kernel); out[] as in
 // knn_frag_kernel.
 __global__ __launch_bounds__(256) void knn_cells_scatter_frag_kernel(
     const float *__restrict__ R, long long n, int k, const unsigned *__restrict__ code,
@@ -541,6 +544,26 @@ __global__ __launch_bounds__(256) void knn_cells_place_kernel(
     }
 }
 
+// The padding of every cell's last tile: positions [rows of the cell, its tiles x 32) get what the scan must see there — zero
+// fragment, +INF norm (never a score under a threshold), no row.  32 threads per cell, after the placement (fill[c] = rows
+// placed).  Rounds 2-3 memset the whole layout first: 0.76 GB of writes for 46 MB of padding at C3.
+__global__ __launch_bounds__(256) void knn_cells_pad_kernel(const unsigned *__restrict__ tile_start, const unsigned *__restrict__ fill,
+                                                            unsigned ncells, h8 *__restrict__ frag, float *__restrict__ norms,
+                                                            unsigned *__restrict__ norms2, unsigned *__restrict__ perm)
+{
+    const unsigned c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, j = threadIdx.x & 31u;   // 32 threads per cell: at most 31 pads
+    if (c >= ncells)
+        return;
+    const size_t pos = (size_t)tile_start[c] * 32 + fill[c] + j, end = (size_t)tile_start[c + 1u] * 32;
+    if (pos < end) {
+        frag[(pos >> 5) * 64 + (pos & 31)] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        frag[(pos >> 5) * 64 + 32 + (pos & 31)] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        norms[pos] = INFINITY;
+        norms2[pos] = 0x00007C00u;
+        perm[pos] = 0xFFFFFFFFu;
+    }
+}
+
 __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
 {
     const float m0 = min3f(x[0], x[1], x[2]);
@@ -627,6 +650,10 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     // rule entry j out" as bit j of a mask, the waves' counts are prefix-summed through LDS, and the second sweep
     // writes every survivor to its final place — no LDS atomics (16 waves adding to the same 64 counters cost
     // more than the table loads at 2^13 cells, where a list holds ~125 of 1024 queries), lists in query order.
+    // (64 loads outstanding — a wave's whole run of the queue in one round trip instead of three — measured in round 4: 76-80
+    // registers instead of 55-58, C3 one batch at a time 0.150 -> 0.155 ms, pipelined 0.1195 -> 0.1235.  16 stays.)
+    // (64 loads outstanding — a wave's whole run of the queue in one round trip instead of three — measured in round 4: 76-80
+    // registers instead of 55-58, C3 one batch at a time 0.150 -> 0.155 ms, pipelined 0.1195 -> 0.1235.  16 stays.)
     constexpr int EPW = 1024 / CELL_MATCH_WAVES, INFLIGHT = 16;   // entries per wave; low-table loads outstanding
     const unsigned per = (npass + CELL_MATCH_WAVES - 1u) / CELL_MATCH_WAVES;
     const unsigned e_begin = min((unsigned)wib * per, npass), e_end = min(e_begin + per, npass);
@@ -1804,9 +1831,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         if (e == hipSuccess)
             e = hipMemcpyAsync(c->items, hitems.data(), hitems.size() * sizeof(u64), hipMemcpyHostToDevice, s);
         if (e == hipSuccess)
-            e = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles * 32 * sizeof(unsigned));
-        if (e == hipSuccess)
-            e = hipMemsetAsync(c->perm, 0xFF, (size_t)tiles * 32 * sizeof(unsigned), s);
+            e = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles * 32 * sizeof(unsigned));   // (filled by the placement + padding kernels)
         if (e == hipSuccess)
             e = hipStreamSynchronize(s);   // hstart / hitems are about to go out of scope
     }
@@ -1828,15 +1853,11 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     return hipSuccess;
 }
 
-// Padding first (zero fragments, +INF norms), then every row to its cell (knn_cells_scatter_frag_kernel).
+// Every row to its cell (knn_cells_place_kernel / knn_cells_scatter_frag_kernel), then the padding of the cells' last tiles.
 // code / fill: what knn_cells_build handed back; out: the 4 words of knn_frag_kernel's statistics.
 hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned *code, unsigned *fill, unsigned *out,
                                 unsigned ocap, hipStream_t s)
 {
-    const long long rows_padded = st.ntiles * 32;
-    FTRY(hipMemsetAsync(st.ref_frags, 0, (size_t)st.ntiles * 64 * 16, s));
-    FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms, 0x7F800000, (size_t)rows_padded, s));
-    FTRY(hipMemsetD32Async((hipDeviceptr_t)st.ref_norms2, 0x00007C00, (size_t)rows_padded, s));
     if (st.cells->tmp_rows)
         hipLaunchKernelGGL(knn_cells_place_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, st.cells->tmp_rows,
                            st.cells->tmp_meta, st.cells->bucket_start, st.k, st.cells->lbits - 8, st.cells->tile_start, fill, st.center, st.sigma,
@@ -1845,6 +1866,9 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
         hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
                            st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,
                            st.cells->perm, out, st.outliers, ocap);
+    FTRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_cells_pad_kernel, dim3((st.cells->ncells + 7u) / 8u), dim3(256), 0, s, st.cells->tile_start, fill,
+                       st.cells->ncells, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm);
     return hipGetLastError();
 }
 

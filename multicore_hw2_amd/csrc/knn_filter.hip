@@ -36,6 +36,9 @@
 // shards: the cell-pruned form, knn_cells.hip.
 #include "knn_filter_dev.h"
 
+#include <functional>
+#include <thread>
+
 // ------------------------------------------------------------------------------------------
 // Per-dimension min / max of the reference coordinates (+ count of non-finite values).
 //   stats[0..k) = ordered min, stats[k..2k) = ordered max, stats[2k] = #non-finite
@@ -1344,22 +1347,37 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     const int kt = knn_kt_of(k);
     if (n <= 0 || kt == 0)
         return hipSuccess;
-    if (geom) {
-        // Cell-range shard of a global grid: centre, scale and cuts are the grid's (identical on every rank: the ranks' fp16
-        // fragments — the seed layer — must live in one frame), the layout is this rank's cells of it.
-        if (kt != 1 || geom->k != k)
-            return hipSuccess;
+    const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[knn build] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    // The cell-sorted layout from a GIVEN frame (centre, scale) and either a shard geometry's cuts or cuts taken from `samp`.
+    // Returns with st.usable set when the layout stands; st.cells null (and st reset) when the shard does not suit the cells.
+    // late_frame (nullable): called once the cells are counted; fills centre and scale then (false: no frame — give up)
+    auto sorted_layout = [&](float *center16, float sigma, const std::vector<float> &samp, long long samples,
+                             const std::function<bool(float *, float *)> &late_frame) -> hipError_t {
         long long ntiles = 0;
         unsigned *cell_code = nullptr, *cell_fill = nullptr;
-        std::vector<float> none;
-        FTRY(knn_cells_build(&st.cells, k, n, r, none, 0, s, &ntiles, &cell_code, &cell_fill, want_cells == 2, geom, rank, bad_rows_out));
+        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles, &cell_code, &cell_fill, want_cells == 2, geom, rank, bad_rows_out));
+        lap(st.cells ? "cell codes + counts" : "cell codes (not kept)");
         if (!st.cells)
             return hipSuccess;
+        if (late_frame && !late_frame(center16, &sigma)) {
+            (void)KNN_DEV_FREE(cell_code);
+            (void)KNN_DEV_FREE(cell_fill);
+            knn_filter_free(st);
+            return hipSuccess;
+        }
         st.k = k;
         st.kt = 1;
         st.n = n;
         st.ntiles = ntiles;
-        st.sigma = geom->sigma;
+        st.sigma = sigma;
         unsigned *dout = nullptr;
         hipError_t e = KNN_DEV_ALLOC((void **)&st.center, 16 * sizeof(float));
         if (e == hipSuccess)
@@ -1376,14 +1394,16 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         if (e == hipSuccess)
             e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), s);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(st.center, geom->center, 16 * sizeof(float), hipMemcpyHostToDevice, s);
+            e = hipMemcpyAsync(st.center, center16, 16 * sizeof(float), hipMemcpyHostToDevice, s);
+        lap("allocations");
         unsigned hout[4] = {0, 0, 0, 0};
         if (e == hipSuccess)
             e = knn_cells_place_rows(st, r, cell_code, cell_fill, dout, ocap, s);
         if (e == hipSuccess)
             e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess)
-            e = hipStreamSynchronize(s);
+            e = hipStreamSynchronize(s);   // (also keeps `center16` alive until the copy is done)
+        lap("placement + sync");
         (void)KNN_DEV_FREE(cell_code);
         (void)KNN_DEV_FREE(cell_fill);
         (void)KNN_DEV_FREE(st.cells->tmp_rows);
@@ -1393,7 +1413,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         st.cells->tmp_meta = nullptr;
         st.cells->bucket_start = nullptr;
         (void)KNN_DEV_FREE(dout);
-        if (e != hipSuccess || hout[2] != 0u || hout[3] > ocap) {   // (too many rows outside the global box: no layouts)
+        if (e != hipSuccess || hout[2] != 0u || hout[3] > ocap) {   // (too many rows outside the box: no layouts from this frame)
             knn_filter_free(st);
             return e;
         }
@@ -1402,18 +1422,75 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         memcpy(&st.nmax, &hout[1], 4);
         st.usable = true;
         return hipSuccess;
+    };
+    if (geom) {
+        // Cell-range shard of a global grid: centre, scale and cuts are the grid's (identical on every rank: the ranks' fp16
+        // fragments — the seed layer — must live in one frame), the layout is this rank's cells of it.
+        if (kt != 1 || geom->k != k)
+            return hipSuccess;
+        std::vector<float> none;
+        float center16[16];
+        memcpy(center16, geom->center, sizeof center16);
+        return sorted_layout(center16, geom->sigma, none, 0, nullptr);
+    }
+    if (want_cells && kt == 1 && n >= (1ll << 17)) {
+        // Round 4: the frame of a cell-sorted layout from a strided SAMPLE of the rows (4096 of them: range widened by 1 / 32,
+        // median / MAD box inside it — what knn_filter_build_from_host does for host rows), not from a pass over the whole
+        // shard: the full-range statistics kernel read 1 GiB for a box that any representative sample gives, and its round
+        // trip to the host stood in front of everything else (0.25 of the build's 3.4 ms at C3).  ANY box is correct: rows
+        // outside it go to the exact list; if the sample was not representative (more than n / 32 rows outside, or values that
+        // are not finite in the sample) the classic build below starts over with full-range statistics.
+        const long long samples = 4096, row_stride = n / samples;
+        std::vector<float> samp((size_t)samples * k);
+        float *dsamp = nullptr;
+        FTRY(KNN_DEV_ALLOC((void **)&dsamp, samp.size() * sizeof(float)));
+        hipLaunchKernelGGL(knn_sample_rows_kernel, dim3((unsigned)((samples * k + 255) / 256)), dim3(256), 0, s, r, k, row_stride,
+                           samples, dsamp);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(samp.data(), dsamp, samp.size() * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        (void)KNN_DEV_FREE(dsamp);
+        FTRY(e);
+        lap("sample rows + copy");
+        // (the frame is host arithmetic on the sample — 0.25 ms — and only the placement needs it: it is worked out on a thread
+        // of its own while the cell codes and buckets are made on the GPU)
+        std::vector<float> center;
+        float sigma = 1.0f;
+        bool box_ok = false;
+        std::thread boxer([&] { box_ok = box_from_sample(samp.data(), samples, k, 16, center, &sigma); });
+        std::vector<float> cut_samp((size_t)(samples / 4) * k);   // (the cuts from every fourth sample row, 1024 as before)
+        for (long long i = 0; i < samples / 4; ++i)
+            memcpy(&cut_samp[(size_t)i * k], &samp[(size_t)(4 * i) * k], (size_t)k * sizeof(float));
+        float center16[16] = {0};
+        struct Joiner {   // (every way out of this block waits for the thread)
+            std::thread &t;
+            ~Joiner()
+            {
+                if (t.joinable())
+                    t.join();
+            }
+        } joiner{boxer};
+        auto frame = [&](float *c16, float *sg) -> bool {
+            if (boxer.joinable())
+                boxer.join();
+            if (!box_ok)
+                return false;
+            for (int d = 0; d < 16; ++d)
+                c16[d] = d < k ? center[(size_t)d] : 0.0f;
+            *sg = sigma;
+            return true;
+        };
+        {
+            FTRY(sorted_layout(center16, sigma, cut_samp, samples / 4, frame));
+            if (st.usable)
+                return hipSuccess;
+            st = FilterState();   // (declined, or the sampled frame left too many rows out: the classic build decides)
+        }
     }
     const int kp = 16 * kt;
     long long ntiles = (n + 31) / 32;
-    const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!trace)
-            return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[knn build] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
 
     // 1. per-dimension range
     std::vector<unsigned> hstats((size_t)2 * k + 1);
