@@ -230,15 +230,16 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             record buffers (rows of a cluster tighter than the fp16 step) by the exact arithmetic over its
  *             listed (cell, query) pairs only; the next batch is back on the pruned path.  Results are
  *             bit-exact either way
- *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^15 cells once a query has
- *             used a workspace slot other than 0 — batches in flight side by side: the scan alone gets 10-20 % longer and
- *             the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
+ *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^15 cells while the index's last
+ *             eight calls named more than one workspace slot — batches in flight side by side: the scan alone gets 10-20 %
+ *             longer and the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
  *   "scan_deal" how the pruned scan's waves get their work items (runs of tiles of one cell): 1 = fixed (wave w takes items
  *             w, w + W, ...), 2 = a block owns a contiguous run and its waves take items from a counter in LDS (the launch
  *             is 6-8 % shorter: no wave is left with twice the average), 0 = auto: 2 for callers that query one batch at a
- *             time on shards with at least two items per wave, 1 below that and once a workspace slot other than 0 has
- *             been used (batches in flight fill each other's gaps; the fixed deal's cheaper prologue then gives the
- *             shorter step)
+ *             time on shards with at least two items per wave, 1 below that and while the last eight calls on the index
+ *             named more than one workspace slot (batches in flight fill each other's gaps; the fixed deal's cheaper
+ *             prologue then gives the shorter step).  The automatic choices follow the caller's recent behaviour: a
+ *             caller that goes back to one batch at a time gets the one-batch shapes again after eight calls
  *   "cells_build" how the cell-sorted layout is built: 0 = two passes (rows grouped into 256 buckets of consecutive cells, then
  *             placed bucket by bucket out of one XCD's L2: 3.4 ms for 2^24 rows of 16 floats; needs n x 72 bytes of scratch: used for
  *             shards of up to 2^25 rows, and falls back when the scratch does not fit), 1 = the one-pass placement (4.7 ms).  Read when an index is created

@@ -259,6 +259,8 @@ struct knn_index {
     size_t events_used = 0;
     int last_slot = 0;
     bool filter_wanted = false;  // the creator asked for the filter layouts explicitly (one-shot cost model)
+    unsigned long long recent_slots = 0;   // the workspace slots of the last eight calls, one byte each (newest lowest)
+    int recent_calls = 0;
     bool sharded = false;        // a cell-range shard (knn_index_create_sharded): always served by the cell-pruned path
     ShardGeom geom;              // its copy of the global grid (filter.cells->geom points here)
     int rank = 0;
@@ -848,9 +850,18 @@ int knn_index_query(knn_index *idx, int slot, int m, const float *queries_dev, u
         idx->filter.chain_policy = (int)g_opt_filter_chain;
         idx->filter.cells_policy = idx->sharded ? 0 : (int)g_opt_cells;   // (a cell-range shard has no other layout)
         // batches in flight on several workspace slots = a caller after throughput: the pruned scan of a small shard then
-        // takes ONE block per CU, so that the next batch's preparation kernels find registers beside it (knn_cells_query)
-        if (slot != 0)
-            idx->filter.several_slots = true;
+        // takes ONE block per CU, so that the next batch's preparation kernels find registers beside it (knn_cells_query).
+        // Derived from the last eight calls (the flag used to stick for the life of the index once any call
+        // had named a slot other than 0 — a caller that went back to one batch at a time kept the throughput shapes).
+        idx->recent_slots = (idx->recent_slots << 8) | (unsigned long long)(unsigned)slot;
+        if (idx->recent_calls < 8)
+            ++idx->recent_calls;
+        {
+            bool several = false;
+            for (int i = 1; i < idx->recent_calls; ++i)
+                several = several || ((idx->recent_slots >> (8 * i)) & 0xFFull) != (unsigned long long)(unsigned)slot;
+            idx->filter.several_slots = several;
+        }
         idx->filter.scan_blocks = (int)g_opt_scan_blocks;
         idx->filter.scan_deal = (int)g_opt_scan_deal;
         idx->last_slot = slot;

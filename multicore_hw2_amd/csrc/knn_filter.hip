@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void knn_ref_stats_kernel(const float *__restr
     }
     // fold the block in LDS first: one guarded global atomic per dimension per block —
     // per-thread atomics on the same 2k words ran at the single-word rate (1.4 ms for a 20 MB shard)
-    __shared__ unsigned s_lo[KNN_FILTER_MAX_K], s_hi[KNN_FILTER_MAX_K], s_bad;
+    // (dynamic LDS, 2 k words: a static [KNN_FILTER_MAX_K] pair was 32 KiB per block at every k — ADVICE r03)
+    extern __shared__ unsigned s_dyn_stats[];
+    unsigned *s_lo = s_dyn_stats, *s_hi = s_dyn_stats + k;
+    __shared__ unsigned s_bad;
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         s_lo[i] = 0xFFFFFFFFu;
         s_hi[i] = 0u;
@@ -116,7 +119,9 @@ __global__ __launch_bounds__(256) void knn_ref_stats4_kernel(const f4v *__restri
     }
     // fold the block in LDS first: one guarded global atomic per dimension per block
     // instead of eight per thread on the same two cache lines
-    __shared__ unsigned s_lo[KNN_FILTER_MAX_K], s_hi[KNN_FILTER_MAX_K], s_bad;
+    extern __shared__ unsigned s_dyn_stats[];   // 2 k words (see knn_ref_stats_kernel)
+    unsigned *s_lo = s_dyn_stats, *s_hi = s_dyn_stats + k;
+    __shared__ unsigned s_bad;
     for (int d = threadIdx.x; d < k; d += blockDim.x) {
         s_lo[d] = 0xFFFFFFFFu;
         s_hi[d] = 0u;
@@ -1505,10 +1510,10 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
                                   hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         if (k % 4 == 0 && ((uintptr_t)r & 15u) == 0)
-            hipLaunchKernelGGL(knn_ref_stats4_kernel, dim3(2048), dim3(256), 0, s, (const f4v *)r,
+            hipLaunchKernelGGL(knn_ref_stats4_kernel, dim3(2048), dim3(256), 2 * (size_t)k * sizeof(unsigned), s, (const f4v *)r,
                                n * (long long)k / 4, k, dstats);
         else
-            hipLaunchKernelGGL(knn_ref_stats_kernel, dim3(2048), dim3(256), 0, s, r, n * (long long)k, k, dstats);
+            hipLaunchKernelGGL(knn_ref_stats_kernel, dim3(2048), dim3(256), 2 * (size_t)k * sizeof(unsigned), s, r, n * (long long)k, k, dstats);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
