@@ -236,9 +236,9 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "scan_deal" how the pruned scan's waves get their work items (runs of tiles of one cell): 1 = fixed (wave w takes items
  *             w, w + W, ...), 2 = a block owns a contiguous run and its waves take items from a counter in LDS (the launch
  *             is 6-8 % shorter: no wave is left with twice the average), 0 = auto: 2 for callers that query one batch at a
- *             time on shards with at least two items per wave, 1 below that and while the last eight calls on the index
- *             named more than one workspace slot (batches in flight fill each other's gaps; the fixed deal's cheaper
- *             prologue then gives the shorter step).  The automatic choices follow the caller's recent behaviour: a
+ *             time on shards with at least two items per wave, and for shards of more than 2^15 cells always; 1 below two items
+ *             per wave, and on the smaller shards while the last eight calls on the index named more than one workspace slot
+ *             (batches in flight fill each other's gaps; the fixed deal's cheaper prologue then gives the shorter step).  The automatic choices follow the caller's recent behaviour: a
  *             caller that goes back to one batch at a time gets the one-batch shapes again after eight calls
  *   "cells_build" how the cell-sorted layout is built: 0 = two passes (rows grouped into 256 buckets of consecutive cells, then
  *             placed bucket by bucket out of one XCD's L2: 3.4 ms for 2^24 rows of 16 floats; needs n x 72 bytes of scratch: used for

@@ -2035,7 +2035,12 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // and moving window win: the step is 1-4 % SHORTER with it (0.0415 / 0.0549 / 0.0794 / 0.1233 against 0.0425 / 0.0568 /
     // 0.0831 / 0.1249) — so that is what pipelined callers get.
     // (below two items per wave the counter has nothing to even out: 2^21 rows, one batch at a time, 0.0786 ms fixed / 0.0800 counter)
-    const bool dyn = st.scan_deal == 2 || (st.scan_deal == 0 && !st.several_slots && c.nitems >= 2u * w.nlists);
+    // (round 4: the counter form lost its 8 bytes of scratch and requests its first descriptors in front of the LDS fill — 3.6 %
+    // shorter alone at C3, 0.1127 against 0.1169 ms between events — and with that it also gives the shorter PIPELINED step on
+    // the large shards that keep two blocks per CU, 0.1188-0.1202 against 0.1197-0.1214; a rank of eight stays with the fixed
+    // deal, 0.0258-0.0265 against 0.0266-0.0293)
+    const bool dyn = st.scan_deal == 2 ||
+                     (st.scan_deal == 0 && c.nitems >= 2u * w.nlists && (!st.several_slots || c.ncells > 32768u));
     CellFinal fin;
     fin.gids = c.gids;
     fin.out_idx = out_idx;
