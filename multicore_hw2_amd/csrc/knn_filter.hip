@@ -649,7 +649,12 @@ __global__ __launch_bounds__(FILTER_BLOCK, (KT == 1 && QT <= 16 ? 3 : 2)) void k
 //   SAMPLE = false: all tiles, threshold test -> per-wave record slices (as knn_filter_kernel)
 //   grid.x blocks split the (sampled) reference tiles, grid.y = groups of 4*QT query tiles.
 // ------------------------------------------------------------------------------------------
-template <int KT, int QT, bool SAMPLE, int BLOCK = FILTER_BLOCK, int TPB = 1>
+//   X16 (round 4): the same tiles out of v_mfma_f32_16x16x32_f16 — four 16 x 16 sub-tiles per (32 references x 32 queries),
+//   two K-steps per instruction — instead of v_mfma_f32_32x32x16_f16.  Same flops per cycle, same layouts (the LDS and
+//   register operands are fetched with per-lane addresses: any lane order is free), same records; what differs is the clock
+//   the chip holds: register-only chains on random f16 data run 1.72-1.75 PFLOP/s at 1.70 GHz with the 32 x 32 shape and
+//   1.98 at 1.96 GHz with the 16 x 16 one (tools/mfma_shape_probe.hip, profiles/r04_mfma_shape_probe.txt).
+template <int KT, int QT, bool SAMPLE, int BLOCK = FILTER_BLOCK, int TPB = 1, bool X16 = false>
 __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, long long stride,
@@ -677,16 +682,37 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     const long long i0 = ns * blockIdx.x / gridDim.x;
     const long long i1 = ns * (blockIdx.x + 1) / gridDim.x;
 
+    // X16: entry [t][2 j + ch] = B operand of K-step pair j for the 16 queries 16 ch .. of query tile t (lane l: query
+    // 16 ch + (l & 15), dimensions 32 j + 8 (l >> 4) ..: the stored fragment of K-step 2 j + (l >> 5), half (l >> 4) & 1);
+    // th / um [t][ch] in th[2 t + ch]
+    static_assert(!X16 || KT % 2 == 0, "two K-steps per 16x16x32 instruction");
     h8 qf[QT][KT];
-    float th[QT], um[QT];
+    float th[QT], um[X16 ? 2 * QT : QT];
+    __shared__ float s_th16[X16 ? WAVES : 1][X16 ? QT * 32 : 1];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int tt = min(qt0 + min(t, max(nq - 1, 0)), qtiles - 1);
+        if constexpr (X16) {
 #pragma unroll
-        for (int kk = 0; kk < KT; ++kk)
-            qf[t][kk] = qfg[((size_t)tt * KT + kk) * 64 + lane];
-        th[t] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + (lane & 31)] : -INFINITY;
-        um[t] = INFINITY;
+            for (int j = 0; j < KT / 2; ++j)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    qf[t][2 * j + ch] = qfg[((size_t)tt * KT + 2 * j + (lane >> 5)) * 64 + ((lane >> 4) & 1) * 32 + 16 * ch + (lane & 15)];
+            // (the 8 thresholds of a lane live in LDS, not in registers: with them the kernel needed 13 registers more than
+            // the 256 two waves per SIMD leave each other, and the spill code sat inside the tile loop)
+            if (lane < 32)
+                s_th16[wib][t * 32 + lane] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + lane] : -INFINITY;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+                um[2 * t + ch] = INFINITY;
+            th[t] = 0.0f;   // (unused in this form)
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                qf[t][kk] = qfg[((size_t)tt * KT + kk) * 64 + lane];
+            th[t] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + (lane & 31)] : -INFINITY;
+            um[t] = INFINITY;
+        }
     }
     const size_t list = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wib;
     u64 *__restrict__ my_rec = SAMPLE ? nullptr : rec + list * slice;
@@ -697,6 +723,79 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
 
     // one reference tile (fragments at a_lds, norm tile at n_lds) against this wave's QT query tiles
     auto score_tile = [&](const h8 *a_lds, const f4v *n_lds, long long i) __attribute__((always_inline)) {
+        if constexpr (X16) {
+            // lane l of a 16 x 16 sub-tile holds rows 4 (l >> 4) .. + 3 of its 16 references for query l & 15: the norms of
+            // rows 16 rh + 4 (l >> 4) .. start the accumulators
+            const int g = lane >> 4;
+            f4v cn[2];
+            cn[0] = n_lds[g];
+            cn[1] = n_lds[4 + g];
+            f4v d[QT][2][2];   // [t][ch][rh]
+#pragma unroll
+            for (int j = 0; j < KT / 2; ++j)
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    // A operand: reference 16 rh + (l & 15), dimensions 32 j + 8 (l >> 4) ..
+                    const h8 a = a_lds[(2 * j + (lane >> 5)) * 64 + ((lane >> 4) & 1) * 32 + 16 * rh + (lane & 15)];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch)
+                            d[t][ch][rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[t][2 * j + ch], j == 0 ? cn[rh] : d[t][ch][rh], 0, 0, 0);
+                }
+            // the lane's 8 thresholds, requested together now that the operand registers are free (one LDS round trip for
+            // the eight trees, not one each)
+            float thv[2 * QT];
+            if (!SAMPLE) {
+#pragma unroll
+                for (int e = 0; e < 2 * QT; ++e)
+                    thv[e] = s_th16[wib][(e >> 1) * 32 + 16 * (e & 1) + (lane & 15)];
+#pragma unroll
+                for (int e = 0; e < 2 * QT; ++e)
+                    asm volatile("" : "+v"(thv[e]));   // (keeps the reads here: left alone they sank in front of each tree)
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const f4v &x0 = d[t][ch][0], &x1 = d[t][ch][1];
+                    const float m0 = min3f(x0[0], x0[1], x0[2]);
+                    const float m1 = min3f(x0[3], x1[0], x1[1]);
+                    const float m2 = min3f(x1[2], x1[3], m0);
+                    if (SAMPLE) {
+                        um[2 * t + ch] = min3f(m1, m2, um[2 * t + ch]);
+                    } else {
+                        const float thq = thv[2 * t + ch];
+                        const float mn = min3f(m1, m2, thq);
+                        const bool hit = mn < thq;
+                        const u64 mask = __ballot(hit);
+                        if (__builtin_expect(mask != 0ull, 0)) {
+                            if (hit) {
+                                const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                if (pos < slice) {
+                                    // the record format of the 32 x 32 scan: (query, tile, half) + a mask over rows
+                                    // 8 (reg >> 2) + 4 half + (reg & 3): this lane's rows 16 rh + 4 g + r are half = g & 1,
+                                    // reg = 8 rh + 4 (g >> 1) + r
+                                    unsigned qv = (unsigned)((qt0 + t) * 32 + 16 * ch) + ((unsigned)lane & 15u);
+                                    asm volatile("" : "+v"(qv));   // (worked out HERE, in the rare branch: hoisted out of the
+                                                                   // tile loop the eight of them were spilled to scratch)
+                                    my_rec[pos] = ((u64)qv << 32) | ((u64)(i * stride) << 1) | (u64)(g & 1);
+                                    unsigned rm = 0u;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        rm |= x0[r] < thq ? (1u << (4 * (g >> 1) + r)) : 0u;
+                                        rm |= x1[r] < thq ? (1u << (8 + 4 * (g >> 1) + r)) : 0u;
+                                    }
+                                    my_rows[pos] = (unsigned short)rm;
+                                }
+                            }
+                            cnt += (unsigned)__popcll(mask);
+                        }
+                    }
+                }
+            return;
+        }
         f16v c;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -749,6 +848,7 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
             }
         }
     };
+    static_assert(!X16 || TPB > 1, "the 16 x 16 shape is built into the LDS-DMA form only");
     if constexpr (TPB > 1) {
         static_assert(CHUNKS % 64 == 0 && (CHUNKS / 64) % WAVES == 0, "a tile's 1 KiB pieces are dealt out evenly to the waves");
         constexpr int PPW = CHUNKS / 64 / WAVES;   // 1 KiB pieces of a tile each wave requests
@@ -873,11 +973,24 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
         }
     }
     if (SAMPLE) {
+        if constexpr (X16) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const float v = fminf(um[t], __shfl_xor(um[t], 32, KNN_WAVE));
-            if (lane < 32 && t < nq)
-                umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + lane] = v;
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {   // a query's column sits on the four lanes l & 15, one per group of rows
+                    float v = um[2 * t + ch];
+                    v = fminf(v, __shfl_xor(v, 16, KNN_WAVE));
+                    v = fminf(v, __shfl_xor(v, 32, KNN_WAVE));
+                    if (lane < 16 && t < nq)
+                        umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + 16 * ch + lane] = v;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float v = fminf(um[t], __shfl_xor(um[t], 32, KNN_WAVE));
+                if (lane < 32 && t < nq)
+                    umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + lane] = v;
+            }
         }
     } else if (lane == 0) {
         counts[list] = cnt;
@@ -2181,12 +2294,19 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     // k > 64 (KT = 8): four reference tiles per barrier staged by LDS-DMA (-2.4 % at C5 against one tile per barrier through
     // registers); k > 128: one tile per barrier — a tile is 16 or 32 KiB there, four of them twice over do not fit the LDS.
     // (8 waves per block and two tiles per barrier were measured too: profiles/r02_c5_variants.txt, r03_deepk.txt.)
-    if constexpr (KT == 8)
-        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                           (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                           1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                           (unsigned short *)(w.records + w.rec_cap));
-    else
+    if constexpr (KT == 8) {
+        static const bool x16_off = getenv("KNN_MI355X_X16") && atoi(getenv("KNN_MI355X_X16")) == 0;   // (A/B while it is new)
+        if (x16_off)
+            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                               (unsigned short *)(w.records + w.rec_cap));
+        else
+            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4, true>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                               (unsigned short *)(w.records + w.rec_cap));
+    } else
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,

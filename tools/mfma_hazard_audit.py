@@ -18,6 +18,13 @@ import sys
 NEED = 12
 
 
+def need_of(mnemonic, need32=NEED):
+    """Wait states between an MFMA and the first VALU / memory instruction that touches its result: 12 for the 8-pass
+    v_mfma_f32_32x32x16_f16 (what hipcc inserts inside a basic block), 8 for the 4-pass 16x16x32 forms (round 4: the deep-K
+    scan's 16 x 16 shape; hipcc pads those with s_nop 7 = 8 states in a block of their own)."""
+    return 8 if "_16x16x" in mnemonic else need32
+
+
 def _regs(tok):
     out = set()
     for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
@@ -57,12 +64,13 @@ def audit(text, need=NEED):
             continue
         n_mfma += 1
         dst = _regs(s.split(None, 1)[1].split(", ")[0])
+        need_here = need_of(s.split()[0], need)
         work = [(i + 1, 0)]
         seen = {}
         while work:
             j, states = work.pop()
-            while j < len(ins) and states < need:
-                if seen.get(j, need + 1) <= states:
+            while j < len(ins) and states < need_here:
+                if seen.get(j, need_here + 1) <= states:
                     break  # reached before with no more wait states behind it
                 seen[j] = states
                 ln2, k2, s2 = ins[j]
@@ -101,7 +109,7 @@ def audit(text, need=NEED):
                 if s2.startswith(("v_", "global_", "ds_", "buffer_", "flat_", "scratch_")):
                     touched = _regs(s2.split(None, 1)[1]) if " " in s2 else set()
                     if touched & dst:
-                        if states < need:
+                        if states < need_here:
                             found.append((cur, states, ln, ln2))
                         break
                 states += 1
