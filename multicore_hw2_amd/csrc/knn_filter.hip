@@ -743,6 +743,10 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
                         for (int ch = 0; ch < 2; ++ch)
                             d[t][ch][rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[t][2 * j + ch], j == 0 ? cn[rh] : d[t][ch][rh], 0, 0, 0);
                 }
+            // (no MFMA may be scheduled down among the trees: with a tree's branch between an MFMA and the next block's reader
+            // of its result the compiler left 6 wait states where the 4-pass shape needs 8 — tools/mfma_hazard_audit.py, the
+            // cross-block miscount of DESIGN 4.2 again)
+            __builtin_amdgcn_sched_barrier(0);
             // the lane's 8 thresholds, requested together now that the operand registers are free (one LDS round trip for
             // the eight trees, not one each)
             float thv[2 * QT];
@@ -768,25 +772,32 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
                         const float thq = thv[2 * t + ch];
                         const float mn = min3f(m1, m2, thq);
                         const bool hit = mn < thq;
-                        const u64 mask = __ballot(hit);
-                        if (__builtin_expect(mask != 0ull, 0)) {
+                        if (__builtin_expect(__ballot(hit) != 0ull, 0)) {
+                            // the record format of the 32 x 32 scan: (query, tile, half) + a mask over rows
+                            // 8 (reg >> 2) + 4 half + (reg & 3).  This lane's rows 16 rh + 4 g + r are half = g & 1,
+                            // reg = 8 rh + 4 (g >> 1) + r; lanes l and l ^ 32 (groups g and g ^ 2) hold the other eight rows of
+                            // the SAME (query, half): their masks are merged and the lower lane writes ONE record — as many
+                            // records as the 32 x 32 form leaves (two per hit filled the slices twice as fast: a far-away
+                            // query, whose threshold lets most rows through, tipped a batch into the exact scan)
+                            unsigned rm = 0u;
                             if (hit) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    rm |= x0[r] < thq ? (1u << (4 * (g >> 1) + r)) : 0u;
+                                    rm |= x1[r] < thq ? (1u << (8 + 4 * (g >> 1) + r)) : 0u;
+                                }
+                            }
+                            rm |= (unsigned)__shfl_xor((int)rm, 32, KNN_WAVE);
+                            const bool emit = lane < 32 && rm != 0u;
+                            const u64 mask = __ballot(emit);
+                            if (emit) {
                                 const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                 if (pos < slice) {
-                                    // the record format of the 32 x 32 scan: (query, tile, half) + a mask over rows
-                                    // 8 (reg >> 2) + 4 half + (reg & 3): this lane's rows 16 rh + 4 g + r are half = g & 1,
-                                    // reg = 8 rh + 4 (g >> 1) + r
                                     unsigned qv = (unsigned)((qt0 + t) * 32 + 16 * ch) + ((unsigned)lane & 15u);
                                     asm volatile("" : "+v"(qv));   // (worked out HERE, in the rare branch: hoisted out of the
                                                                    // tile loop the eight of them were spilled to scratch)
                                     my_rec[pos] = ((u64)qv << 32) | ((u64)(i * stride) << 1) | (u64)(g & 1);
-                                    unsigned rm = 0u;
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        rm |= x0[r] < thq ? (1u << (4 * (g >> 1) + r)) : 0u;
-                                        rm |= x1[r] < thq ? (1u << (8 + 4 * (g >> 1) + r)) : 0u;
-                                    }
                                     my_rows[pos] = (unsigned short)rm;
                                 }
                             }
@@ -848,7 +859,6 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
             }
         }
     };
-    static_assert(!X16 || TPB > 1, "the 16 x 16 shape is built into the LDS-DMA form only");
     if constexpr (TPB > 1) {
         static_assert(CHUNKS % 64 == 0 && (CHUNKS / 64) % WAVES == 0, "a tile's 1 KiB pieces are dealt out evenly to the waves");
         constexpr int PPW = CHUNKS / 64 / WAVES;   // 1 KiB pieces of a tile each wave requests
@@ -916,57 +926,7 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
             const int buf = (int)((i - i0) & 1);
             if (i + 1 < i1)
                 fetch(i + 1);  // global loads in flight while this tile is consumed
-            f16v c;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4v v = s_n[buf][2 * g + (lane >> 5)];
-                c[4 * g + 0] = v[0];
-                c[4 * g + 1] = v[1];
-                c[4 * g + 2] = v[2];
-                c[4 * g + 3] = v[3];
-            }
-            f16v d[QT];
-#pragma unroll
-            for (int kk = 0; kk < KT; ++kk) {
-                const h8 a = s_a[buf][kk * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < QT; ++t)
-                    d[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[t][kk], kk == 0 ? c : d[t], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                const f16v &x = d[t];
-                const float m0 = min3f(x[0], x[1], x[2]);
-                const float m1 = min3f(x[3], x[4], x[5]);
-                const float m2 = min3f(x[6], x[7], x[8]);
-                const float m3 = min3f(x[9], x[10], x[11]);
-                const float m4 = min3f(x[12], x[13], x[14]);
-                const float m5 = min3f(m0, m1, m2);
-                const float m6 = min3f(m3, m4, x[15]);
-                if (SAMPLE) {
-                    um[t] = min3f(m5, m6, um[t]);
-                } else {
-                    const float mn = min3f(m5, m6, th[t]);
-                    const bool hit = mn < th[t];
-                    const u64 mask = __ballot(hit);
-                    if (__builtin_expect(mask != 0ull, 0)) {
-                        if (hit) {
-                            const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            if (pos < slice) {
-                                my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) |
-                                              ((u64)(i * stride) << 1) | (u64)(lane >> 5);
-                                unsigned rm = 0u;
-#pragma unroll
-                                for (int r16 = 0; r16 < 16; ++r16)
-                                    rm |= x[r16] < th[t] ? (1u << r16) : 0u;
-                                my_rows[pos] = (unsigned short)rm;
-                            }
-                        }
-                        cnt += (unsigned)__popcll(mask);
-                    }
-                }
-            }
+            score_tile(&s_a[buf][0], &s_n[buf][0], i);
             if (i + 1 < i1)
                 park(buf ^ 1);  // the other buffer was last read one iteration ago
             __syncthreads();
@@ -2270,6 +2230,8 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
             w.umin_cap = need;
         }
     }
+    // (the sample pass — 1 / 16 of the tiles, running minima only — keeps the 32 x 32 shape: with eight running minima the
+    // 16 x 16 form of it spilled)
     hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, true>), dim3(sb, gy), dim3(FILTER_BLOCK), 0, s,
                        (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                        stride, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
@@ -2294,20 +2256,13 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     // k > 64 (KT = 8): four reference tiles per barrier staged by LDS-DMA (-2.4 % at C5 against one tile per barrier through
     // registers); k > 128: one tile per barrier — a tile is 16 or 32 KiB there, four of them twice over do not fit the LDS.
     // (8 waves per block and two tiles per barrier were measured too: profiles/r02_c5_variants.txt, r03_deepk.txt.)
-    if constexpr (KT == 8) {
-        static const bool x16_off = getenv("KNN_MI355X_X16") && atoi(getenv("KNN_MI355X_X16")) == 0;   // (A/B while it is new)
-        if (x16_off)
-            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                               (unsigned short *)(w.records + w.rec_cap));
-        else
-            hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4, true>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
-                               (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
-                               1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                               (unsigned short *)(w.records + w.rec_cap));
-    } else
-        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+    if constexpr (KT == 8)
+        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4, true>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
+                           (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
+                           1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
+                           (unsigned short *)(w.records + w.rec_cap));
+    else   // (16 x 16 shape from k = 65 up: measured -8 % at k 128, -6 % at k 256 and 512, +7 % at k 64 where a tile is only 16 MFMAs)
+        hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 1, (KT > 4)>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
                            (unsigned short *)(w.records + w.rec_cap));
