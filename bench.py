@@ -242,8 +242,10 @@ def main():
                 raise
             sys.stderr.write("bench.py: %s\nbench.py: falling back to index-range shards\n" % exc)
             shard_mode = "index"
-    if shard_mode == "cells":
-        # 2. where every row belongs; rows and their global numbers sorted by destination (stable: ascending per destination)
+    def partition_by_cells():
+        """2. where every row belongs; rows and their global numbers sorted by destination (stable: ascending per destination),
+        moved there by one all-to-all.  -> (this rank's rows, their global numbers, note)"""
+        nonlocal layer_d
         owner = torch.empty(n_local, dtype=torch.int32, device=dev)
         geom.assign(rows2d.data_ptr(), n_local, owner.data_ptr(), device=local_rank, stream=stream)
         torch.cuda.synchronize()
@@ -292,16 +294,39 @@ def main():
             gids_d = all_to_all(send_gids, in_split, out_split)
             del send_rows, send_gids, order
         del owner
-        r_d = rows_d.reshape(-1)            # this rank's rows from here on
-        n_local = rows_d.shape[0]
         torch.cuda.synchronize()
-        shard_note = {"partition": "cell ranges of one global grid of 2^%d cells (%d per rank at most), seed layer %d tile(s) per cell = "
-                                   "%.0f MB replicated" % (geom.bits, geom.cells_per_rank, geom.seed_tiles, geom.layer_bytes / 1e6),
-                      "partition_ms": (time.perf_counter() - t_part) * 1e3, "rows_this_rank": int(n_local)}
+        note = {"partition": "cell ranges of one global grid of 2^%d cells (%d per rank at most), seed layer %d tile(s) per cell = "
+                             "%.0f MB replicated" % (geom.bits, geom.cells_per_rank, geom.seed_tiles, geom.layer_bytes / 1e6),
+                "partition_ms": (time.perf_counter() - t_part) * 1e3, "rows_this_rank": int(rows_d.shape[0])}
         if emu_n:
-            shard_note["emulated"] = "one GPU as rank %d of %d (no collective in the step)" % (emu_r, emu_n)
-            args.cpu_queries = 0     # (one rank's answers are not the set's: parity of the shards is tests/test_shards_gpu.py's job)
+            note["emulated"] = "one GPU as rank %d of %d (no collective in the step)" % (emu_r, emu_n)
+        return rows_d, gids_d, note
+
+    if shard_mode == "cells":
         assert not args.separate_init, "a cell-range shard starts its keys itself (KNN_QUERY_INIT_KEYS)"
+        # (a failure here — an all-to-all the transport does not support, a geometry a rank refuses — must not take the whole
+        # run down: every rank reports, and if any failed all of them keep the index-range shards they already hold)
+        parted, why = None, ""
+        try:
+            parted = partition_by_cells()
+        except Exception as exc:     # noqa: BLE001
+            why = "%s: %s" % (type(exc).__name__, exc)
+        ok = 1 if parted is not None else 0
+        if dist is not None:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearse else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            rows_d, gids_d, shard_note = parted
+            r_d = rows_d.reshape(-1)            # this rank's rows from here on
+            n_local = rows_d.shape[0]
+            if emu_n:
+                args.cpu_queries = 0     # (one rank's answers are not the set's: parity of the shards is tests/test_shards_gpu.py's job)
+        else:
+            if args.shard == "cells" or emu_n:
+                raise SystemExit("bench.py: cell-range shards failed on some rank (%s)" % (why or "another rank"))
+            sys.stderr.write("bench.py: cell-range shards failed on some rank (%s): index-range shards instead\n" % (why or "another rank"))
+            shard_mode, geom = "index", None
     # Two batches in flight: step i runs on stream i&1 with the index's query workspace i&1 and its
     # own key/result buffers.  The small latency-bound kernels of step i+1 (query fragments, sample
     # pass, thresholds) and — with N > 1 — the all-reduce of step i overlap the other step's scan.
