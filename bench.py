@@ -68,6 +68,9 @@ def parse_args():
                     help="one GPU plays rank r (default 0) of an N-rank cell-range sharded run: the whole set is generated here, "
                          "all N shards are built (their seed layer is needed), rank r's step is timed — no collective.  For the "
                          "per-rank projections under profiles/ when no multi-GPU node is at hand")
+    ap.add_argument("--scan-stamps", default="", metavar="FILE.npz",
+                    help="development: with a library built by tools/build_timeline_lib.sh (KNN_MI355X_LIB), save the "
+                         "per-wave wall-clock stamps of the last pruned-scan launch, pipelined and one batch at a time")
     ap.add_argument("--cpu-queries", type=int, default=-1,
                     help="queries in the cpu_baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -702,6 +705,23 @@ def main():
         os.dup2(saved_stdout_fd, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
+    if args.scan_stamps and dist is None:
+        import ctypes
+        import numpy as np
+        fn = pkg.lib().knn_debug_scan_stamps   # (AttributeError: not the stamped build)
+        fn.argtypes = [ctypes.c_void_p]
+        grabbed = {}
+        for tag in ("pipe", "serial"):
+            for i in range(48):
+                if tag == "pipe":
+                    step(i)
+                else:
+                    index.query_keys(m, q_ptr, key_ptrs[0], stream=raw_streams[0], slot=0, init_keys=True, indices_dev=out_ptrs[0])
+            torch.cuda.synchronize()
+            buf = np.zeros(8192 * 5, dtype=np.uint64)
+            assert fn(buf.ctypes.data) == 0
+            grabbed[tag] = buf.reshape(8192, 5)
+        np.savez(args.scan_stamps, **grabbed)
     index.close()
     if dist is not None:
         dist.barrier()

@@ -725,7 +725,8 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 // broadcast ds_read_b128 per tile and block of queries.  (Round 3 measured the C tile out of one extra MFMA on split norms
 // instead: 115-138 VGPRs, slower at every size — tools/arms/README.md.)
 #define CELL_SCAN_WAVES 12
-#define CELL_SCAN_CHUNK 256   // items of a block's run whose tile ranges and list lengths sit in LDS at a time (DYN)
+#define CELL_SCAN_CHUNK 256   // slots of a block's share whose tile ranges and list lengths sit in LDS at a time (DYN)
+#define CELL_SCAN_RUN 16      // DYN: consecutive items a block takes at a time; its next run lies gridDim.x runs further on
 
 // One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
 __device__ __forceinline__ u64 cell_tile_step(const h8 &a, const f4v *__restrict__ my_nrm, int p, int half, const h8 &b, float th)
@@ -1131,6 +1132,23 @@ __device__ __forceinline__ void cells_finalize(u64 *__restrict__ keys, int m, co
     }
 }
 
+#ifdef KNN_SCAN_TIMELINE
+// development only (tools/build_timeline_lib.sh builds a private copy of the library with this macro, tools/scan_timeline.py
+// reads it): five stamps per wave of the last scan launch — entry, LDS filled, items done, own records re-ranked, exit — of
+// the 100 MHz wall clock.  The product build compiles none of it.
+__device__ unsigned long long g_scan_stamps[8192 * 5];
+#define SCAN_STAMP(i)                                                                                  \
+    do {                                                                                               \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * CELL_SCAN_WAVES + (threadIdx.x >> 6) < 8192u)      \
+            g_scan_stamps[(blockIdx.x * CELL_SCAN_WAVES + (threadIdx.x >> 6)) * 5 + (i)] = wall_clock64(); \
+    } while (0)
+extern "C" int knn_debug_scan_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_stamps), sizeof(unsigned long long) * 8192 * 5);
+}
+#else
+#define SCAN_STAMP(i) do { } while (0)
+#endif
 // K: 16 = compile-time dimension of the inline re-rank, 0 = run-time k <= 16
 template <bool DYN, int K>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel(
@@ -1149,6 +1167,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
     f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
     __shared__ unsigned s_flag;
+    SCAN_STAMP(0);
     if (threadIdx.x == 0)
         s_flag = ctl[KNN_CTL_FALLBACK];   // read once per block: see knn_cells_match_kernel
     const int lane = threadIdx.x & 63;
@@ -1156,8 +1175,36 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
     __shared__ unsigned s_next, s_imeta[DYN ? CELL_SCAN_CHUNK : 1], s_itb[DYN ? CELL_SCAN_CHUNK : 1], s_inq[DYN ? CELL_SCAN_CHUNK : 1];
     const unsigned per_wave = (nitems + nwaves - 1u) / nwaves;
-    const unsigned per_block = (nitems + gridDim.x - 1u) / gridDim.x;
-    const unsigned i0 = min(blockIdx.x * per_block, nitems), i1 = min(i0 + per_block, nitems);
+    // DYN: a block's share is one RUN of CELL_SCAN_RUN consecutive items out of every stripe of gridDim.x runs, not one
+    // contiguous stretch of the item order.  Round 4, from the per-wave stamps of tools/scan_timeline.py at C3
+    // (profiles/r04_scan_timeline.txt): with contiguous shares the blocks finished their items 71 to 109 us after the launch
+    // began, later the further along the cell order their stretch lay (+14 us from the first to the last block of either half
+    // of the grid: the work per cell drifts along the order — the side of a cut that got a percent more rows has more cells
+    // that spill into a ninth tile).  A share that samples the whole order carries the average: the launch alone 0.1133 ->
+    // 0.1085 ms, one batch at a time 0.1500 -> 0.1450 (three A/B pairs on one box); batches in flight fill the gaps either
+    // way (0.1186-0.1237 / 0.1179-0.1204 per step).  All blocks still move through the layout together.
+    // Which run of a stripe: rotated from stripe to stripe by a golden-ratio step — with the b-th run of every stripe a
+    // block's cells would all share the code bits that number the run inside a stripe, and the drift follows the code bits.
+    // Slot s of a share = item (stripe * gridDim.x + (blockIdx.x + stripe * rot) % gridDim.x) * RUN + s % RUN, stripe = s / RUN;
+    // slots past the last item are holes.
+    // (What is left after this: the 256 blocks placed second on their CUs finish 15 us behind the 256 placed first whatever
+    // they are given — 87 against 102 us — and the XCDs differ by +-6 %.  A pool of items behind the shares that waves drain
+    // through ONE counter in memory was tried for that: an agent-scope atomic on one address costs ~26 ns and they queue up —
+    // 10 % of the items in the pool doubled the launch, 0.107 -> 0.190 ms.  tools/arms/scan_item_pool.patch.)
+    // (everything derived from the arguments is recomputed where it is used — the fills, twice a launch: values kept across
+    // the item loop for them went to scratch under the 80-register cap)
+    const unsigned i0 = 0u;
+    const unsigned i1 = DYN ? (((nitems + (unsigned)CELL_SCAN_RUN - 1u) / (unsigned)CELL_SCAN_RUN + gridDim.x - 1u) / gridDim.x) *
+                                  (unsigned)CELL_SCAN_RUN
+                            : 0u;   // the share, in slots
+    auto slot_item = [&](unsigned s) {
+        const unsigned nruns = (nitems + (unsigned)CELL_SCAN_RUN - 1u) / (unsigned)CELL_SCAN_RUN;
+        const unsigned rot = __umulhi(gridDim.x, 2654435769u) | 1u;   // gridDim.x * 0.618...
+        const unsigned stripe = s / (unsigned)CELL_SCAN_RUN;
+        const unsigned run = stripe * gridDim.x + (blockIdx.x + stripe * rot) % gridDim.x;
+        const unsigned it = run * (unsigned)CELL_SCAN_RUN + s % (unsigned)CELL_SCAN_RUN;
+        return run < nruns && it < nitems ? it : 0xFFFFFFFFu;
+    };
     // DYN: the first chunk's descriptors — two dependent round trips (item -> its cell's list length) — are requested BEFORE
     // the block fills its LDS (36 KiB of B operands and thresholds, one more round trip and a barrier): they overlap instead
     // of queueing up in front of the first tile load, and one barrier pair goes (round 4: 114.4 -> 112.5 us at C3, rocprofv3).
@@ -1166,10 +1213,11 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     if constexpr (DYN) {
         const unsigned nc0 = min((unsigned)CELL_SCAN_CHUNK, i1 - i0);
         for (unsigned i = threadIdx.x; i < nc0; i += 64 * CELL_SCAN_WAVES) {
-            const u64 item = items[i0 + i];
+            const unsigned it = slot_item(i0 + i);
+            const u64 item = it != 0xFFFFFFFFu ? items[it] : 0ull;
             s_imeta[i] = (unsigned)(item >> 40);
             s_itb[i] = (unsigned)item;
-            s_inq[i] = cell_counts[(unsigned)(item >> 48)];
+            s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;   // (a hole: nobody lists it)
         }
         if (threadIdx.x == 0)
             s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
@@ -1182,6 +1230,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     __syncthreads();
     if (s_flag != 0u)
         return;
+    SCAN_STAMP(1);
     f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
 
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
@@ -1190,7 +1239,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     const int col = lane & 31, half = lane >> 5;
     // DYN = false: wave w takes items w, w + W, ... (an item = a run of tiles of one cell; uniform data: one item per cell):
     // all waves read one moving window of the layout (contiguous ranges per wave: +6 %).
-    // DYN = true (small shards: an item or three per wave): the block owns a contiguous run of items and its waves take them
+    // DYN = true: the block owns a share of the items (see above) and its waves take them
     // one by one from a counter in LDS — with the fixed deal the busiest wave of a 2^21-row shard had 115 tile steps against
     // 48.5 on average (lists of 76..160 queries, cells of 5..9 tiles) and the launch lasted as long as that wave.
     // DYN: the chunk of the block's run whose tables are in LDS (the first one was filled above), this wave's item in it
@@ -1207,10 +1256,11 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                 nc = min((unsigned)CELL_SCAN_CHUNK, i1 - c0);
                 __syncthreads();   // everybody is done with the previous chunk's tables
                 for (unsigned i = threadIdx.x; i < nc; i += 64 * CELL_SCAN_WAVES) {
-                    const u64 item = items[c0 + i];
+                    const unsigned it = slot_item(c0 + i);
+                    const u64 item = it != 0xFFFFFFFFu ? items[it] : 0ull;
                     s_imeta[i] = (unsigned)(item >> 40);
                     s_itb[i] = (unsigned)item;
-                    s_inq[i] = cell_counts[(unsigned)(item >> 48)];
+                    s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;
                 }
                 if (threadIdx.x == 0)
                     s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
@@ -1341,6 +1391,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             mine_dyn = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
         }
     }
+    SCAN_STAMP(2);
     const unsigned nrec = min(cnt, slice);   // what is IN the slice; the rest went to the shared area (wave-uniform)
     if (lane == 0)
         counts[wave] = nrec;                  // (statistics: knn_index_last_stats sums them)
@@ -1383,11 +1434,20 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                     acc = acc + sq;
                 }
             u64 key = row != 0xFFFFFFFFu && acc < INFINITY ? pack_key(acc, (unsigned)(base + (long long)row)) : ~0ull;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const u64 o = __shfl_xor(key, off, KNN_WAVE);
-                key = o < key ? o : key;
+            // (ds_swizzle's xor mode, not __shfl_xor: that one wants every lane's number in a register, computed at the top of
+            // the kernel and kept across the item loop — 4 bytes of scratch under the 80-register cap)
+#define KNN_SWZ_MIN(OFF)                                                                                   \
+            {                                                                                              \
+                const unsigned olo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)key, ((OFF) << 10) | 0x1F);         \
+                const unsigned ohi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(key >> 32), ((OFF) << 10) | 0x1F); \
+                const u64 o = ((u64)ohi << 32) | (u64)olo;                                                 \
+                key = o < key ? o : key;                                                                   \
             }
+            KNN_SWZ_MIN(8)
+            KNN_SWZ_MIN(4)
+            KNN_SWZ_MIN(2)
+            KNN_SWZ_MIN(1)
+#undef KNN_SWZ_MIN
             if ((lane & 15) == 0 && key < cur)   // (key == ~0: never below a key)
                 key_atomic_min(&keys[qi], key);
         }
@@ -1399,6 +1459,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     // counter: those are performed at the memory side, no cache to write back.  Every wave waits for its own atomics to have
     // been performed before the block counts itself done; the finaliser reads with agent-scope loads.)
     __shared__ unsigned s_last;
+    SCAN_STAMP(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1409,6 +1470,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
         if (have == 0u)
             cells_finalize(keys, m, fin, threadIdx.x, 64u * CELL_SCAN_WAVES);
     }
+    SCAN_STAMP(4);
 }
 
 // What is left of a batch behind the scan, in ONE gated launch (rounds 2-3: a re-rank launch and two gated ones):
