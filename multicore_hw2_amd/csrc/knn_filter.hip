@@ -668,8 +668,11 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     // per-tile barrier coupled the block's four waves, each of which shares its SIMD with a wave of another block, and
     // waves spent 38 % of their cycles parked at it (profiles/r02_c5_variants.txt); with TPB tiles between two barriers a
     // wave that is held up has TPB x 32 MFMAs of slack before the others wait for it
-    __shared__ h8 s_a[2][TPB * CHUNKS];
-    __shared__ f4v s_n[2][TPB * 8];
+    // (TWO arrays per operand, not one [2][..]: the compiler orders every LDS read behind every LDS-DMA in flight that
+    // may write what it reads, and with the buffer chosen by a run-time index that was every read — a vmcnt(0) right
+    // behind the request for the next group, the copy never overlapped the scoring of the wave that asked for it.  Two
+    // objects and a loop unrolled by two: reads of one array, requests into the other.)
+    // (declared where they are used: s_a0 / s_a1 / s_n0 / s_n1 in the TPB > 1 branch, s_a[2] / s_n[2] in the other)
     if (!SAMPLE && ctl[KNN_CTL_FALLBACK] != 0u)
         return;
     const int tid = threadIdx.x;
@@ -758,6 +761,9 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
                 for (int e = 0; e < 2 * QT; ++e)
                     asm volatile("" : "+v"(thv[e]));   // (keeps the reads here: left alone they sank in front of each tree)
             }
+            // (round 4, measured and not kept: ONE branch per tile over the eight trees' results, the records worked out again
+            // in a slow path — C5 0.745 -> 0.925 ms.  Hits are not rare at C5: a dozen candidates per query leave a hit in
+            // two of three (tile, 128 queries) pairs, and the slow path then paid for all eight trees' masks.)
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -860,10 +866,12 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
         }
     };
     if constexpr (TPB > 1) {
+        __shared__ h8 s_a0[TPB * CHUNKS], s_a1[TPB * CHUNKS];
+        __shared__ f4v s_n0[TPB * 8], s_n1[TPB * 8];
         static_assert(CHUNKS % 64 == 0 && (CHUNKS / 64) % WAVES == 0, "a tile's 1 KiB pieces are dealt out evenly to the waves");
         constexpr int PPW = CHUNKS / 64 / WAVES;   // 1 KiB pieces of a tile each wave requests
         // LDS-DMA: lane l of the wave copies 16 bytes from ITS global address to (wave-uniform LDS base) + 16 l
-        auto issue = [&](int buf, long long j0) __attribute__((always_inline)) {
+        auto issue = [&](h8 *sa, f4v *sn, long long j0) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < TPB; ++u) {
                 const long long i = j0 + u;
@@ -873,29 +881,36 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
                     for (int pp = 0; pp < PPW; ++pp) {
                         const int piece = wib * PPW + pp;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rf + (size_t)tile * CHUNKS + piece * 64 + lane),
-                                                         (__attribute__((address_space(3))) void *)&s_a[buf][u * CHUNKS + piece * 64], 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void *)&sa[u * CHUNKS + piece * 64], 16, 0, 0);
                     }
                     if (wib == 0 && lane < 8)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rn + (size_t)tile * 32 + 4 * lane),
-                                                         (__attribute__((address_space(3))) void *)&s_n[buf][u * 8], 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void *)&sn[u * 8], 16, 0, 0);
                 }
             }
         };
-        if (i0 < i1) {
-            issue(0, i0);
-            __syncthreads();   // (waits for the DMA: hipcc drains vmcnt in front of the barrier)
-            int buf = 0;
-            for (long long j0 = i0; j0 < i1; j0 += TPB, buf ^= 1) {
-                if (j0 + TPB < i1)
-                    issue(buf ^ 1, j0 + TPB);   // in flight while this group of tiles is scored
+        // one group of TPB tiles: scored out of (ra, rn_) while the next group is on its way into (wa, wn)
+        auto group = [&](const h8 *ra, const f4v *rn_, h8 *wa, f4v *wn, long long j0) __attribute__((always_inline)) {
+            if (j0 + TPB < i1)
+                issue(wa, wn, j0 + TPB);
 #pragma unroll
-                for (int u = 0; u < TPB; ++u)
-                    if (j0 + u < i1)   // block-uniform
-                        score_tile(&s_a[buf][u * CHUNKS], &s_n[buf][u * 8], j0 + u);
-                __syncthreads();   // the next group has landed; nobody reads this one any more
+            for (int u = 0; u < TPB; ++u)
+                if (j0 + u < i1)   // block-uniform
+                    score_tile(&ra[u * CHUNKS], &rn_[u * 8], j0 + u);
+            __syncthreads();   // the next group has landed (hipcc drains vmcnt in front of the barrier); nobody reads this one any more
+        };
+        if (i0 < i1) {
+            issue(s_a0, s_n0, i0);
+            __syncthreads();
+            for (long long j0 = i0; j0 < i1; j0 += 2 * TPB) {
+                group(s_a0, s_n0, s_a1, s_n1, j0);
+                if (j0 + TPB < i1)   // block-uniform
+                    group(s_a1, s_n1, s_a0, s_n0, j0 + TPB);
             }
         }
     } else if (i0 < i1) {
+        __shared__ h8 s_a[2][CHUNKS];
+        __shared__ f4v s_n[2][8];
         h8 stage_a[CPT];
         f4v stage_n = {0.f, 0.f, 0.f, 0.f};
         auto fetch = [&](long long i) {
@@ -982,8 +997,11 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     constexpr int WAVES = FILTER_BLOCK / 64;
     constexpr int PIECES = CHK_T * CHK_KC;          // 1 KiB pieces of A per stage
     static_assert(PIECES % WAVES == 0, "a stage's pieces are dealt out evenly to the waves");
-    __shared__ h8 s_a[2][PIECES * 64];
-    __shared__ f4v s_n[2][CHK_T * 8];
+    // (two arrays per operand and the stage loop unrolled by two, as in knn_filter_tiled_kernel: a read of the array a
+    // request in flight may write waits for that request)
+    __shared__ h8 s_a0[PIECES * 64], s_a1[PIECES * 64];
+    static_assert(CHK_T == WAVES, "wave w requests the norms of the stage's tile w");
+    __shared__ f4v s_n0[CHK_T * 64], s_n1[CHK_T * 64];   // [tile][64]: a whole wave's LDS-DMA (entries 8.. of a tile are copies)
     if (!SAMPLE && ctl[KNN_CTL_FALLBACK] != 0u)
         return;
     const int tid = threadIdx.x;
@@ -1012,45 +1030,41 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
 
     // stage = (group, chunk): the A fragments of the group's T tiles for K-steps [8 chunk, 8 chunk + 8), and with chunk 0
     // the tiles' norms.  Tiles past the end are clamped to the last one (their scores are dropped in the epilogue).
-    auto issue = [&](int buf, long long g, int chunk) __attribute__((always_inline)) {
+    auto issue = [&](h8 *wa, f4v *wn, long long g, int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int pp = 0; pp < PIECES / WAVES; ++pp) {
             const int piece = wib * (PIECES / WAVES) + pp;      // = tt * KC + kk
             const int tt = piece / CHK_KC, kk = piece % CHK_KC;
             const long long tile = min((g * CHK_T + tt) * stride, ntiles - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rf + ((size_t)tile * kt + (size_t)chunk * CHK_KC + kk) * 64 + lane),
-                                             (__attribute__((address_space(3))) void *)&s_a[buf][piece * 64], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)&wa[piece * 64], 16, 0, 0);
         }
-        if (chunk == 0 && wib == 0 && lane < CHK_T * 8) {
-            const long long tile = min((g * CHK_T + (lane >> 3)) * stride, ntiles - 1);
-            s_n[buf][lane] = *(const f4v *)(rn + (size_t)tile * 32 + 4 * (lane & 7));
+        // the tiles' norms with every stage, by every wave, all lanes (no branch around a request: the compiler counts what
+        // is in flight, and a request that may or may not have been made turns every later wait into a wait for everything)
+        {
+            const long long tile = min((g * CHK_T + wib) * stride, ntiles - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rn + (size_t)tile * 32 + 4 * (lane & 7)),
+                                             (__attribute__((address_space(3))) void *)&wn[wib * 64], 16, 0, 0);
         }
     };
     if (g0 < g1) {
         f16v acc[CHK_T][CHK_QT];
-        issue(0, g0, 0);
-        __syncthreads();   // (waits for the DMA: hipcc drains vmcnt in front of the barrier)
-        int buf = 0;
-        for (long long g = g0; g < g1; ++g) {
-            for (int chunk = 0; chunk < nchunks; ++chunk, buf ^= 1) {
-                // the next stage is in flight while this one is scored
-                if (chunk + 1 < nchunks)
-                    issue(buf ^ 1, g, chunk + 1);
-                else if (g + 1 < g1)
-                    issue(buf ^ 1, g + 1, 0);
-                h8 qf[CHK_QT][CHK_KC];
-#pragma unroll
-                for (int t = 0; t < CHK_QT; ++t)
-#pragma unroll
-                    for (int kk = 0; kk < CHK_KC; ++kk)
-                        qf[t][kk] = qfg[((size_t)qtile[t] * kt + (size_t)chunk * CHK_KC + kk) * 64 + lane];
+        h8 qf[CHK_QT][CHK_KC];   // the B fragments of the stage being scored (loaded one stage ahead, see the stage)
+        // one stage: scored out of (ra, rn_) while the next one is on its way into (wa, wn)
+        auto stage = [&](const h8 *ra, const f4v *rn_, h8 *wa, f4v *wn, long long g, int chunk) __attribute__((always_inline)) {
+            {
+                // the next stage (behind the last one: that one again — requests nobody reads, but no branch)
+                const bool wrap = chunk + 1 == nchunks;
+                const long long gn = wrap ? min(g + 1, g1 - 1) : g;
+                const int cn = wrap ? (g + 1 < g1 ? 0 : chunk) : chunk + 1;
+                issue(wa, wn, gn, cn);
                 if (chunk == 0) {
 #pragma unroll
                     for (int tt = 0; tt < CHK_T; ++tt) {
                         f16v c;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            const f4v v = s_n[buf][tt * 8 + 2 * gq + (lane >> 5)];
+                            const f4v v = rn_[tt * 64 + 2 * gq + (lane >> 5)];
                             c[4 * gq + 0] = v[0];
                             c[4 * gq + 1] = v[1];
                             c[4 * gq + 2] = v[2];
@@ -1061,15 +1075,24 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
                             acc[tt][t] = c;
                     }
                 }
+                // K-step by K-step over the T tiles: the B fragments of a K-step are dead once its T x QT MFMAs are issued, and
+                // the NEXT stage's fragments of that K-step are requested into the same registers right there (round 4; round 3
+                // requested a stage's 16 KiB of B at its start and waited for them in front of its first MFMA: the chunked
+                // scan ran at 0.30 of the MFMA peak).  The barrier at the end of the stage drains them with the A requests;
+                // inside a stage no MFMA waits for memory.
 #pragma unroll
-                for (int tt = 0; tt < CHK_T; ++tt)
+                for (int kk = 0; kk < CHK_KC; ++kk) {
 #pragma unroll
-                    for (int kk = 0; kk < CHK_KC; ++kk) {
-                        const h8 a = s_a[buf][(tt * CHK_KC + kk) * 64 + lane];
+                    for (int tt = 0; tt < CHK_T; ++tt) {
+                        const h8 a = ra[(tt * CHK_KC + kk) * 64 + lane];
 #pragma unroll
                         for (int t = 0; t < CHK_QT; ++t)
                             acc[tt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[t][kk], acc[tt][t], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int t = 0; t < CHK_QT; ++t)
+                        qf[t][kk] = qfg[((size_t)qtile[t] * kt + (size_t)cn * CHK_KC + kk) * 64 + lane];
+                }
                 if (chunk + 1 == nchunks) {
 #pragma unroll
                     for (int tt = 0; tt < CHK_T; ++tt) {
@@ -1113,6 +1136,29 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
                     }
                 }
                 __syncthreads();   // the next stage has landed; nobody reads this one any more
+            }
+        };
+        issue(s_a0, s_n0, g0, 0);
+#pragma unroll
+        for (int t = 0; t < CHK_QT; ++t)
+#pragma unroll
+            for (int kk = 0; kk < CHK_KC; ++kk)
+                qf[t][kk] = qfg[((size_t)qtile[t] * kt + kk) * 64 + lane];
+        __syncthreads();   // (waits for the DMA: hipcc drains vmcnt in front of the barrier)
+        long long g = g0;
+        int chunk = 0;
+        for (;;) {   // stages (g, chunk) in order, alternating arrays
+            stage(s_a0, s_n0, s_a1, s_n1, g, chunk);
+            if (++chunk == nchunks) {
+                chunk = 0;
+                if (++g >= g1)
+                    break;
+            }
+            stage(s_a1, s_n1, s_a0, s_n0, g, chunk);
+            if (++chunk == nchunks) {
+                chunk = 0;
+                if (++g >= g1)
+                    break;
             }
         }
     }
