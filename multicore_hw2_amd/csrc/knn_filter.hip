@@ -997,6 +997,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     constexpr int WAVES = FILTER_BLOCK / 64;
     constexpr int PIECES = CHK_T * CHK_KC;          // 1 KiB pieces of A per stage
     static_assert(PIECES % WAVES == 0, "a stage's pieces are dealt out evenly to the waves");
+    static_assert(CHK_KC % 2 == 0, "two K-steps per 16x16x32 instruction");
     // (two arrays per operand and the stage loop unrolled by two, as in knn_filter_tiled_kernel: a read of the array a
     // request in flight may write waits for that request)
     __shared__ h8 s_a0[PIECES * 64], s_a1[PIECES * 64];
@@ -1015,21 +1016,34 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     const long long ng = (ns + CHK_T - 1) / CHK_T;                  // groups of T
     const long long g0 = ng * blockIdx.x / gridDim.x, g1 = ng * (blockIdx.x + 1) / gridDim.x;
 
-    float th[CHK_QT], um[CHK_QT];
+    // The 16 x 16 x 32 MFMA shape on the layouts of the 32 x 32 x 16 one (round 4, as knn_filter_tiled_kernel's X16: the chip
+    // holds 1.96 GHz on the 4-pass shape and 1.70 on the 8-pass one, profiles/r04_mfma_shape_probe.txt).  Lane l of a
+    // 16 x 16 sub-tile: query 16 ch + (l & 15) of query tile t, rows 4 (l >> 4) .. + 3 of the 16 references 16 rh ..;
+    // um [t][ch] in um[2 t + ch]; the thresholds are fetched in the epilogue, once per K sweep (four registers the
+    // chunk loop does not have: with them the scan kernel spilled 28 bytes).
+    float um[2 * CHK_QT];
     int qtile[CHK_QT];
 #pragma unroll
     for (int t = 0; t < CHK_QT; ++t) {
         qtile[t] = min(qt0 + min(t, max(nq - 1, 0)), qtiles - 1);
-        th[t] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + (lane & 31)] : -INFINITY;
-        um[t] = INFINITY;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+            um[2 * t + ch] = INFINITY;
     }
     const size_t list = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wib;
     u64 *__restrict__ my_rec = SAMPLE ? nullptr : rec + list * slice;
     unsigned short *__restrict__ my_rows = SAMPLE ? nullptr : rec_rows + list * slice;
     unsigned cnt = 0u;
+    const int g4 = lane >> 4;   // which four rows of a 16 x 16 sub-tile this lane holds
+    // B operand of K-step pair j of a chunk for the 16 queries 16 ch .. of a query tile: lane l takes dimensions
+    // 32 j + 8 (l >> 4) .., i.e. the stored fragment of K-step 2 j + (l >> 5), half (l >> 4) & 1
+    const int b_lane = ((lane >> 4) & 1) * 32 + (lane & 15);
+    auto b_at = [&](int t, int chunk, int j, int ch) __attribute__((always_inline)) {
+        return qfg[((size_t)qtile[t] * kt + (size_t)chunk * CHK_KC + 2 * j + (lane >> 5)) * 64 + b_lane + 16 * ch];
+    };
 
-    // stage = (group, chunk): the A fragments of the group's T tiles for K-steps [8 chunk, 8 chunk + 8), and with chunk 0
-    // the tiles' norms.  Tiles past the end are clamped to the last one (their scores are dropped in the epilogue).
+    // stage = (group, chunk): the A fragments of the group's T tiles for K-steps [8 chunk, 8 chunk + 8), and the tiles'
+    // norms.  Tiles past the end are clamped to the last one (their scores are dropped in the epilogue).
     auto issue = [&](h8 *wa, f4v *wn, long long g, int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int pp = 0; pp < PIECES / WAVES; ++pp) {
@@ -1048,84 +1062,107 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
         }
     };
     if (g0 < g1) {
-        f16v acc[CHK_T][CHK_QT];
-        h8 qf[CHK_QT][CHK_KC];   // the B fragments of the stage being scored (loaded one stage ahead, see the stage)
+        f4v acc[CHK_T][CHK_QT][2][2];          // [tile][query tile][ch][rh]
+        h8 qf[CHK_QT][CHK_KC];                 // [t][2 j + ch]: the B fragments of the stage being scored (loaded one stage ahead)
         // one stage: scored out of (ra, rn_) while the next one is on its way into (wa, wn)
         auto stage = [&](const h8 *ra, const f4v *rn_, h8 *wa, f4v *wn, long long g, int chunk) __attribute__((always_inline)) {
-            {
-                // the next stage (behind the last one: that one again — requests nobody reads, but no branch)
-                const bool wrap = chunk + 1 == nchunks;
-                const long long gn = wrap ? min(g + 1, g1 - 1) : g;
-                const int cn = wrap ? (g + 1 < g1 ? 0 : chunk) : chunk + 1;
-                issue(wa, wn, gn, cn);
-                if (chunk == 0) {
+            // the next stage (behind the last one: that one again — requests nobody reads, but no branch)
+            const bool wrap = chunk + 1 == nchunks;
+            const long long gn = wrap ? min(g + 1, g1 - 1) : g;
+            const int cn = wrap ? (g + 1 < g1 ? 0 : chunk) : chunk + 1;
+            issue(wa, wn, gn, cn);
+            if (chunk == 0) {   // the norms of the lane's rows start the accumulators
 #pragma unroll
-                    for (int tt = 0; tt < CHK_T; ++tt) {
-                        f16v c;
+                for (int tt = 0; tt < CHK_T; ++tt)
 #pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const f4v v = rn_[tt * 64 + 2 * gq + (lane >> 5)];
-                            c[4 * gq + 0] = v[0];
-                            c[4 * gq + 1] = v[1];
-                            c[4 * gq + 2] = v[2];
-                            c[4 * gq + 3] = v[3];
-                        }
+                    for (int rh = 0; rh < 2; ++rh) {
+                        const f4v c = rn_[tt * 64 + 4 * rh + g4];
 #pragma unroll
                         for (int t = 0; t < CHK_QT; ++t)
-                            acc[tt][t] = c;
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch)
+                                acc[tt][t][ch][rh] = c;
                     }
-                }
-                // K-step by K-step over the T tiles: the B fragments of a K-step are dead once its T x QT MFMAs are issued, and
-                // the NEXT stage's fragments of that K-step are requested into the same registers right there (round 4; round 3
-                // requested a stage's 16 KiB of B at its start and waited for them in front of its first MFMA: the chunked
-                // scan ran at 0.30 of the MFMA peak).  The barrier at the end of the stage drains them with the A requests;
-                // inside a stage no MFMA waits for memory.
+            }
+            // K-step pair by K-step pair over the T tiles: the B fragments of a pair are dead once its MFMAs are issued, and
+            // the NEXT stage's fragments of that pair are requested into the same registers right there (round 4; round 3
+            // requested a stage's 16 KiB of B at its start and waited for them in front of its first MFMA).  The barrier at
+            // the end of the stage drains them with the A requests; inside a stage no MFMA waits for memory.
 #pragma unroll
-                for (int kk = 0; kk < CHK_KC; ++kk) {
+            for (int j = 0; j < CHK_KC / 2; ++j) {
 #pragma unroll
-                    for (int tt = 0; tt < CHK_T; ++tt) {
-                        const h8 a = ra[(tt * CHK_KC + kk) * 64 + lane];
+                for (int tt = 0; tt < CHK_T; ++tt)
+#pragma unroll
+                    for (int rh = 0; rh < 2; ++rh) {
+                        // A operand: reference 16 rh + (l & 15) of tile tt, dimensions 32 j + 8 (l >> 4) ..
+                        const h8 a = ra[(tt * CHK_KC + 2 * j + (lane >> 5)) * 64 + ((lane >> 4) & 1) * 32 + 16 * rh + (lane & 15)];
 #pragma unroll
                         for (int t = 0; t < CHK_QT; ++t)
-                            acc[tt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[t][kk], acc[tt][t], 0, 0, 0);
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch)
+                                acc[tt][t][ch][rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[t][2 * j + ch], acc[tt][t][ch][rh], 0, 0, 0);
                     }
+#pragma unroll
+                for (int t = 0; t < CHK_QT; ++t)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        qf[t][2 * j + ch] = b_at(t, cn, j, ch);
+            }
+            if (chunk + 1 == nchunks) {
+                // (no MFMA may be scheduled down among the trees: see knn_filter_tiled_kernel)
+                __builtin_amdgcn_sched_barrier(0);
+                // everything the epilogue derives from the lane's number is worked out HERE, from a value the compiler cannot
+                // see through: as loop invariants the thresholds' address, the row-mask shifts and the shuffle's lane went to
+                // scratch across the stage loop (44 bytes — and a kernel that touches scratch at all pays for it on every launch)
+                unsigned le = threadIdx.x;
+                asm volatile("" : "+v"(le));
+                const unsigned l15 = le & 15u, ge = (le >> 4) & 3u;
+                float th[2 * CHK_QT];
+#pragma unroll
+                for (int t = 0; t < CHK_QT; ++t)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        th[2 * t + ch] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + 16 * ch + l15] : -INFINITY;
+#pragma unroll
+                for (int tt = 0; tt < CHK_T; ++tt) {
+                    const long long i = g * CHK_T + tt;   // (sampled) tile number
+                    if (i >= ns)
+                        continue;   // block-uniform: a clamped copy of the last tile
 #pragma unroll
                     for (int t = 0; t < CHK_QT; ++t)
-                        qf[t][kk] = qfg[((size_t)qtile[t] * kt + (size_t)cn * CHK_KC + kk) * 64 + lane];
-                }
-                if (chunk + 1 == nchunks) {
 #pragma unroll
-                    for (int tt = 0; tt < CHK_T; ++tt) {
-                        const long long i = g * CHK_T + tt;   // (sampled) tile number
-                        if (i >= ns)
-                            continue;   // block-uniform: a clamped copy of the last tile
-#pragma unroll
-                        for (int t = 0; t < CHK_QT; ++t) {
-                            const f16v &x = acc[tt][t];
-                            const float m0 = min3f(x[0], x[1], x[2]);
-                            const float m1 = min3f(x[3], x[4], x[5]);
-                            const float m2 = min3f(x[6], x[7], x[8]);
-                            const float m3 = min3f(x[9], x[10], x[11]);
-                            const float m4 = min3f(x[12], x[13], x[14]);
-                            const float m5 = min3f(m0, m1, m2);
-                            const float m6 = min3f(m3, m4, x[15]);
+                        for (int ch = 0; ch < 2; ++ch) {
+                            const f4v &x0 = acc[tt][t][ch][0], &x1 = acc[tt][t][ch][1];
+                            const float m0 = min3f(x0[0], x0[1], x0[2]);
+                            const float m1 = min3f(x0[3], x1[0], x1[1]);
+                            const float m2 = min3f(x1[2], x1[3], m0);
                             if (SAMPLE) {
-                                um[t] = min3f(m5, m6, um[t]);
+                                um[2 * t + ch] = min3f(m1, m2, um[2 * t + ch]);
                             } else {
-                                const float mn = min3f(m5, m6, th[t]);
-                                const bool hit = mn < th[t];
-                                const u64 mask = __ballot(hit);
-                                if (__builtin_expect(mask != 0ull, 0)) {
+                                const float thq = th[2 * t + ch];
+                                const float mn = min3f(m1, m2, thq);
+                                const bool hit = mn < thq;
+                                if (__builtin_expect(__ballot(hit) != 0ull, 0)) {
+                                    // the record format of the 32 x 32 scan, one record per (query, half): see the X16
+                                    // epilogue of knn_filter_tiled_kernel
+                                    unsigned rm = 0u;
                                     if (hit) {
+                                        const unsigned sh = 4u * (ge >> 1);
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) {
+                                            rm |= x0[r] < thq ? (1u << (sh + r)) : 0u;
+                                            rm |= x1[r] < thq ? (256u << (sh + r)) : 0u;
+                                        }
+                                    }
+                                    rm |= (unsigned)__builtin_amdgcn_ds_bpermute((int)(((le ^ 32u) & 63u) << 2), (int)rm);   // lane l ^ 32's rows
+                                    const bool emit = (le & 32u) == 0u && rm != 0u;
+                                    const u64 mask = __ballot(emit);
+                                    if (emit) {
                                         const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                         if (pos < slice) {
-                                            my_rec[pos] = ((u64)(unsigned)((qt0 + t) * 32 + (lane & 31)) << 32) |
-                                                          ((u64)(i * stride) << 1) | (u64)(lane >> 5);
-                                            unsigned rm = 0u;
-#pragma unroll
-                                            for (int r16 = 0; r16 < 16; ++r16)
-                                                rm |= x[r16] < th[t] ? (1u << r16) : 0u;
+                                            const unsigned qv = (unsigned)((qt0 + t) * 32 + 16 * ch) + l15;
+                                            my_rec[pos] = ((u64)qv << 32) | ((u64)(i * stride) << 1) | (u64)(ge & 1u);
                                             my_rows[pos] = (unsigned short)rm;
                                         }
                                     }
@@ -1133,17 +1170,18 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
                                 }
                             }
                         }
-                    }
                 }
-                __syncthreads();   // the next stage has landed; nobody reads this one any more
             }
+            __syncthreads();   // the next stage has landed; nobody reads this one any more
         };
         issue(s_a0, s_n0, g0, 0);
 #pragma unroll
         for (int t = 0; t < CHK_QT; ++t)
 #pragma unroll
-            for (int kk = 0; kk < CHK_KC; ++kk)
-                qf[t][kk] = qfg[((size_t)qtile[t] * kt + kk) * 64 + lane];
+            for (int j = 0; j < CHK_KC / 2; ++j)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    qf[t][2 * j + ch] = b_at(t, 0, j, ch);
         __syncthreads();   // (waits for the DMA: hipcc drains vmcnt in front of the barrier)
         long long g = g0;
         int chunk = 0;
@@ -1164,11 +1202,15 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     }
     if (SAMPLE) {
 #pragma unroll
-        for (int t = 0; t < CHK_QT; ++t) {
-            const float v = fminf(um[t], __shfl_xor(um[t], 32, KNN_WAVE));
-            if (lane < 32 && t < nq)
-                umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + lane] = v;
-        }
+        for (int t = 0; t < CHK_QT; ++t)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {   // a query's column sits on the four lanes l & 15, one per group of rows
+                float v = um[2 * t + ch];
+                v = fminf(v, __shfl_xor(v, 16, KNN_WAVE));
+                v = fminf(v, __shfl_xor(v, 32, KNN_WAVE));
+                if (lane < 16 && t < nq)
+                    umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + 16 * ch + lane] = v;
+            }
     } else if (lane == 0) {
         counts[list] = cnt;
         if (cnt > slice)
