@@ -602,7 +602,7 @@ def main():
         # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json).  Quoted only when the profile
         # was taken on the kernel source that is running now (the profile records the sha256 of
         # the filter / cells / exact sources); a stale profile is named, not used.
-        pmc_name = "r03_c3_pmc_traffic.json"
+        pmc_name = "r04_c3_pmc_traffic.json"
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if wname == "C3" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -731,7 +731,7 @@ def main():
 def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
-    for name in ("knn_filter.hip", "knn_cells.hip", "knn_filter_dev.h", "knn_exact.hip"):
+    for name in ("knn_filter.hip", "knn_cells.hip", "knn_filter_dev.h", "knn_exact.hip", "knn_exact_dev.h", "knn_common.h"):
         with open(os.path.join(ROOT, "multicore_hw2_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -51,7 +51,7 @@ def main():
     # bench.py quotes roofline.traffic from this file only while the kernels it was measured on are the ones running
     import hashlib
     h = hashlib.sha256()
-    for name in ("knn_filter.hip", "knn_cells.hip", "knn_filter_dev.h", "knn_exact.hip"):
+    for name in ("knn_filter.hip", "knn_cells.hip", "knn_filter_dev.h", "knn_exact.hip", "knn_exact_dev.h", "knn_common.h"):
         with open(os.path.join(root, "multicore_hw2_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     with open(path, "w") as fo:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copies what tools/collect_profiles.sh gathered (gpurun_out/<dir>) into profiles/ under the round's prefix:
 bench lines, rocprofv3 kernel-stats CSVs, PMC traffic (tools/pmc_traffic.py), SQ counters per kernel, text records.
-usage: publish_profiles.py gpurun_out/r03_final_b r03"""
+usage: publish_profiles.py gpurun_out/r04_final r04"""
 import collections
 import csv
 import glob
@@ -25,10 +25,15 @@ for path in sorted(glob.glob(os.path.join(src, "*_bench.json"))):
     shutil.copy(path, os.path.join(dst, f"{tag}_{os.path.basename(path)}"))
 for name in ("build_trace", "cells_trace", "dropin_timing", "ingest_timing", "distribution_check"):
     shutil.copy(os.path.join(src, name + ".txt"), os.path.join(dst, f"{tag}_{name}.txt"))
+for name in ("deepk_sq_counters", "scan_timeline_final"):
+    if os.path.exists(os.path.join(src, name + ".txt")):
+        shutil.copy(os.path.join(src, name + ".txt"), os.path.join(dst, f"{tag}_{name}.txt"))
 for d, out in (("kt_c3", "c3_kernel_stats"), ("kt_c2", "c2_kernel_stats"), ("kt_c5", "c5_kernel_stats"),
-               ("kt_c3_serial", "c3_serial_kernel_stats"), ("kt_c3_serial_block_counter", "c3_serial_block_counter_kernel_stats"),
+               ("kt_c3_serial", "c3_serial_kernel_stats"),
                ("kt_2097152_serial", "16_1024_2097152_serial_kernel_stats"),
-               ("kt_2097152_r02chain_serial", "16_1024_2097152_r02chain_serial_kernel_stats"),
+               ("kt_c3_rank_0_of_8", "c3_rank_0_of_8_kernel_stats"),
+               ("kt_c3_rank_0_of_8_serial", "c3_rank_0_of_8_serial_kernel_stats"),
+               ("kt_k1024", "1024_16384_65536_kernel_stats"),
                ("kt_clusters64", "clusters64_kernel_stats"), ("kt_heavy_tail", "heavy_tail_kernel_stats")):
     shutil.copy(one(f"{d}/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{out}.csv"))
 subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), f"{tag}_c3",
