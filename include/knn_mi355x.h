@@ -96,7 +96,7 @@ void knn_index_destroy(knn_index *idx);
  *     splits the reference set so that the GPUs' scans ADD UP to the scan of one GPU holding everything.
  *     The reference splits by index range (core.cu:875-883) and so does cudaCallback here — rows arrive in the caller's
  *     order.  For a resident set that costs work: each range is gridded by itself at 1 / N of the resolution, and the ranks
- *     together score 3.5x the (cell, query) pairs of one GPU at N = 8 (profiles/r04_shard_sim.txt).  Instead:
+ *     together do 3.8x the tile steps of one GPU at N = 8 (profiles/r04_shard_sim.txt).  Instead:
  *       1. every rank takes a strided sample of its rows; the samples are gathered (a few hundred KB) and
  *          knn_geom_create builds ONE grid from them — identical input, identical grid on every rank;
  *       2. knn_geom_assign says which rank's cell range each row falls into; the caller moves the rows there (one
@@ -104,7 +104,7 @@ void knn_index_destroy(knn_index *idx);
  *       3. knn_index_create_sharded sorts a rank's rows into ITS cells of the global grid;
  *       4. knn_index_seed_export writes the first few tiles of each of the rank's cells into its part of a buffer of
  *          knn_geom_info()[5] bytes; the caller all-gathers the parts and hands the whole layer to knn_index_seed_attach
- *          (replicated: 151 MB for 2^16 cells).  A query bounds its answer from 16 seed cells around it — this rank's
+ *          (replicated: 151 MB for 2^16 cells).  A query bounds its answer from the 4 seed cells around it (16 measured slower, profiles/r04_seed_sweep.txt) — this rank's
  *          whole, the others' through the layer — so a rank prunes almost as if it saw everybody's rows.
  *     Queries, keys and the exchange step (min over the ranks' keys) are the same calls as for index-range shards: the
  *     keys carry global row numbers (gids) when the batch's last kernel has run.

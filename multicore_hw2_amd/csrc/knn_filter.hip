@@ -992,7 +992,9 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int kt, int qtiles, long long ntiles, long long stride,
     float *__restrict__ umin, int m_padded, u64 *__restrict__ rec, unsigned *__restrict__ counts,
-    unsigned *__restrict__ ctl, unsigned slice, unsigned short *__restrict__ rec_rows)
+    unsigned *__restrict__ ctl, unsigned slice, unsigned short *__restrict__ rec_rows,
+    // != 0: a ONE-dimensional grid of ranges x (query groups rounded up to eight) blocks, see below
+    unsigned ranges, unsigned qgroups)
 {
     constexpr int WAVES = FILTER_BLOCK / 64;
     constexpr int PIECES = CHK_T * CHK_KC;          // 1 KiB pieces of A per stage
@@ -1008,13 +1010,30 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qt0 = (blockIdx.y * WAVES + wib) * CHK_QT;   // this wave's first query tile
+    // Which (range of reference tiles, group of 256 queries) a block scores.  Round 4: workgroups go to the XCDs round
+    // robin by their linear number, and with the plain (x = range, y = query group) grid of eight ranges an XCD's 64
+    // resident blocks were 64 DIFFERENT query groups on one range — 32 MB of B fragments cycling through a 4 MB L2, every
+    // block fetching its 512 KiB of B again for each group of tiles: 68 GB per launch at (1024, 65536, 65536), which
+    // ran at 0.31 of the MFMA peak where (1024, 16384, 65536) ran at 0.49.  So the launch is one-dimensional and block L
+    // is the (L / 8)-th block of XCD L % 8, which walks ITS query groups (g ≡ XCD mod 8) one after the other, all `ranges`
+    // ranges of a query group side by side: 64 / ranges query groups' B (2 MB at 16 ranges) stay in the L2, each range's A
+    // is shared by those few blocks, and what comes from beyond the L2 is every operand about once per XCD pass.
+    unsigned bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+    if (ranges != 0u) {
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        bx = j % ranges;
+        by = (j / ranges) * 8u + xcd;
+        nbx = ranges;
+        if (by >= qgroups)
+            return;   // (the grid is rounded up to eight query groups; block-uniform, before any barrier)
+    }
+    const int qt0 = (int)(by * WAVES + wib) * CHK_QT;   // this wave's first query tile
     const int nq = max(0, min(CHK_QT, qtiles - qt0));      // wave-uniform; 0 = padding wave
     const int nchunks = kt / CHK_KC;
 
     const long long ns = (ntiles + stride - 1) / stride;            // (sampled) tiles
     const long long ng = (ns + CHK_T - 1) / CHK_T;                  // groups of T
-    const long long g0 = ng * blockIdx.x / gridDim.x, g1 = ng * (blockIdx.x + 1) / gridDim.x;
+    const long long g0 = ng * bx / nbx, g1 = ng * (bx + 1) / nbx;
 
     // The 16 x 16 x 32 MFMA shape on the layouts of the 32 x 32 x 16 one (round 4, as knn_filter_tiled_kernel's X16: the chip
     // holds 1.96 GHz on the 4-pass shape and 1.70 on the 8-pass one, profiles/r04_mfma_shape_probe.txt).  Lane l of a
@@ -1030,7 +1049,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
         for (int ch = 0; ch < 2; ++ch)
             um[2 * t + ch] = INFINITY;
     }
-    const size_t list = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wib;
+    const size_t list = ((size_t)by * nbx + bx) * WAVES + wib;
     u64 *__restrict__ my_rec = SAMPLE ? nullptr : rec + list * slice;
     unsigned short *__restrict__ my_rows = SAMPLE ? nullptr : rec_rows + list * slice;
     unsigned cnt = 0u;
@@ -1209,7 +1228,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
                 v = fminf(v, __shfl_xor(v, 16, KNN_WAVE));
                 v = fminf(v, __shfl_xor(v, 32, KNN_WAVE));
                 if (lane < 16 && t < nq)
-                    umin[(size_t)blockIdx.x * m_padded + (size_t)(qt0 + t) * 32 + 16 * ch + lane] = v;
+                    umin[(size_t)bx * m_padded + (size_t)(qt0 + t) * 32 + 16 * ch + lane] = v;
             }
     } else if (lane == 0) {
         counts[list] = cnt;
@@ -2372,7 +2391,11 @@ static hipError_t launch_filter_chunked(FilterState &st, FilterWorkspace &w, int
     const int m_padded = qtiles * 32;
     const unsigned gy = (unsigned)((qtiles + 4 * CHK_QT - 1) / (4 * CHK_QT));
     const long long groups = (st.ntiles + CHK_T - 1) / CHK_T;
-    unsigned gx = ((unsigned)num_cu * 8 + gy - 1) / gy;
+    // ranges of reference tiles: enough blocks for the chip, and at least 16 so that an XCD's 64 resident blocks are FEW
+    // query groups (see the kernel: their B fragments have to fit its L2)
+    // (measured: 8 / 16 / 32 / 64 ranges within 2 % of each other at (1024, 65536, 65536); four blocks per CU in all instead of
+    // eight: the mid-size shapes' step 2-9 % shorter — profiles/r04_deepk.txt)
+    unsigned gx = std::max(16u, ((unsigned)num_cu * 4u + gy - 1) / gy);
     if ((long long)gx > groups)
         gx = (unsigned)groups;
     if (gx < 1)
@@ -2404,7 +2427,7 @@ static hipError_t launch_filter_chunked(FilterState &st, FilterWorkspace &w, int
     }
     hipLaunchKernelGGL(knn_filter_chunked_kernel<true>, dim3(sb, gy), dim3(FILTER_BLOCK), 0, s, (const h8 *)st.ref_frags,
                        st.ref_norms, (const h8 *)w.qry_frags, w.thr, st.kt, qtiles, st.ntiles, stride, w.umin, m_padded, w.records,
-                       w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap));
+                       w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap), 0u, gy);
     FTRY(hipGetLastError());
     hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
                        (int)sb, w.qry_norms, w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
@@ -2412,9 +2435,9 @@ static hipError_t launch_filter_chunked(FilterState &st, FilterWorkspace &w, int
     FTRY(hipGetLastError());
     if (w.ev_begin)
         FTRY(hipEventRecord(w.ev_begin, s));
-    hipLaunchKernelGGL(knn_filter_chunked_kernel<false>, dim3(gx, gy), dim3(FILTER_BLOCK), 0, s, (const h8 *)st.ref_frags,
-                       st.ref_norms, (const h8 *)w.qry_frags, w.thr, st.kt, qtiles, st.ntiles, 1ll, w.umin, m_padded, w.records,
-                       w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap));
+    hipLaunchKernelGGL(knn_filter_chunked_kernel<false>, dim3(gx * ((gy + 7u) / 8u) * 8u), dim3(FILTER_BLOCK), 0, s,
+                       (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, st.kt, qtiles, st.ntiles, 1ll, w.umin,
+                       m_padded, w.records, w.counts, w.ctl, w.slice, (unsigned short *)(w.records + w.rec_cap), gx, gy);
     w.has_rows = true;
     w.pieces = RerankPieces();
     FTRY(hipGetLastError());

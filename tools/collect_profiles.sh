@@ -46,8 +46,8 @@ echo done a
 fi
 if [ "$1" = b ]; then
 step "emulated ranks of a cell-range sharded C3 (one GPU plays rank r of N; no collective in the step)"
-for e in 2:0 2:1 4:0 4:1 4:3 8:0 8:3 8:7; do B c3_rank_${e/:/_of_} --emulate $e --cpu-queries 0; done
-for e in 8:0 8:3; do B c3_rank_${e/:/_of_}_serial --emulate $e --cpu-queries 0 --serial; done
+for e in 2:0 2:1 4:0 4:1 4:3 8:0 8:3 8:7; do B c3_rank_${e#*:}_of_${e%:*} --emulate $e --cpu-queries 0; done
+for e in 8:0 8:3; do B c3_rank_${e#*:}_of_${e%:*}_serial --emulate $e --cpu-queries 0 --serial; done
 B c3_rank_0_of_8_index_shards --workload 16,1024,2097152 --cpu-queries 0
 step "a rank of 8 of C4 (n = 2^27: the rank's 2^24 rows on the global 2^19-cell grid)"
 B c4_rank_0_of_8 --workload c4 --emulate 8:0 --cpu-queries 0
