@@ -726,6 +726,7 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 // instead: 115-138 VGPRs, slower at every size — tools/arms/README.md.)
 #define CELL_SCAN_WAVES 12
 #define CELL_SCAN_CHUNK 256   // slots of a block's share whose tile ranges and list lengths sit in LDS at a time (DYN)
+#define CELL_INLINE_RERANK_MAX 64u   // records a scan wave re-ranks itself; a longer list is left to the tail kernel
 #define CELL_SCAN_RUN 16      // DYN: consecutive items a block takes at a time; its next run lies gridDim.x runs further on
 
 // One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         ctl_next[KNN_CTL_DENSE_CELLS] = 0u;
         ctl_next[KNN_CTL_EXACT_CELLS] = 0u;
         ctl_next[KNN_CTL_SCAN_DONE] = 0u;
+        ctl_next[KNN_CTL_DEFERRED] = 0u;
         ctl_next[KNN_CTL_TAIL_DONE] = 0u;
     }
     const int half = lane >> 5;
@@ -1398,7 +1400,14 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     // ---- this wave's records, re-ranked on the spot (round 4; rounds 1-3 launched knn_rerank_kernel behind the scan: one
     // wave per list, 8-9 us for ~3000 records spread over 6144 lists).  16 lanes per record: its 16 rows with v0's
     // arithmetic on the fp32 rows, min-folded, ONE guarded atomic per record.  The loop above is over: its registers are free.
-    if (nrec != 0u && !dead) {
+    // A LONG list is not re-ranked here: it is left where it is and the tail kernel, which sees the whole batch, either
+    // re-ranks it with every CU or — when the shared area ended up over-full — drops it for the exact evaluation of the
+    // batch's listed pairs.  (Round 4's first form re-ranked whatever a wave had: on 64 tight clusters (n 2^22) every wave
+    // filled its slice of 586 records while the shared area was still filling, re-ranked them for 270 us on average — and the
+    // batch then went to the exact evaluation anyway: scan 69 -> 566 us, step 0.32 -> 0.78 ms, profiles/r04_distribution_check.txt.)
+    if (nrec > CELL_INLINE_RERANK_MAX && !dead && lane == 0)
+        __hip_atomic_store(&ctl[KNN_CTL_DEFERRED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every writer stores 1)
+    if (nrec != 0u && nrec <= CELL_INLINE_RERANK_MAX && !dead) {
         // the records were stored by other lanes of this wave: wait for the stores, no more — workgroup scope is this CU's own
         // cache.  (An agent-scope fence here, __threadfence(), is a write-back AND an invalidate of the XCD's whole L2 — one per
         // wave with records: the scan took 261 us instead of 110 at C3 with it.)
@@ -1466,7 +1475,8 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
         s_last = __hip_atomic_fetch_add(&ctl[KNN_CTL_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (s_last != 0u && !fin.defer) {   // block-uniform
-        const unsigned have = __hip_atomic_load(&ctl[KNN_CTL_RECORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned have = __hip_atomic_load(&ctl[KNN_CTL_RECORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                              __hip_atomic_load(&ctl[KNN_CTL_DEFERRED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (have == 0u)
             cells_finalize(keys, m, fin, threadIdx.x, 64u * CELL_SCAN_WAVES);
     }
@@ -1489,11 +1499,14 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
     const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
     const unsigned short *__restrict__ lists, unsigned cap, const unsigned *__restrict__ perm,
     const u64 *__restrict__ rec, unsigned ovf_base, unsigned ovf_cap, unsigned *__restrict__ ctl, u64 *__restrict__ keys,
-    CellFinal fin)
+    CellFinal fin,
+    // the scan's record lists (counts[nlists], `slice` records each): lists longer than CELL_INLINE_RERANK_MAX are re-ranked here
+    const unsigned *__restrict__ counts, unsigned nlists, unsigned slice)
 {
 #pragma clang fp contract(off)
     const unsigned fb = ctl[KNN_CTL_FALLBACK], have = ctl[KNN_CTL_RECORDS];   // final: prep and the scan are complete
-    if (!fin.defer && fb == 0u && have == 0u)
+    const unsigned deferred = ctl[KNN_CTL_DEFERRED];
+    if (!fin.defer && fb == 0u && have == 0u && deferred == 0u)
         return;
     if (fb != 0u) {
         if constexpr (K == 16) {
@@ -1509,8 +1522,32 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
                 ctl[KNN_CTL_EXACT_CELLS] = 1u;   // (statistics: knn_index_last_stats[2] = 2)
             cells_exact_items<K>(Q, R, krt, m, base, items, nitems, cell_counts, lists, cap, perm, keys,
                                  blockIdx.x * (unsigned)KNN_WAVES + (threadIdx.x >> 6), gridDim.x * (unsigned)KNN_WAVES);
-        } else if (have != 0u) {
-            const int k = K > 0 ? K : krt;
+        } else {
+          const int k = K > 0 ? K : krt;
+          if (deferred != 0u) {   // the long lists the scan's waves left alone: a block per list, 16 lanes per record
+            for (unsigned l = blockIdx.x; l < nlists; l += gridDim.x) {
+                const unsigned n = min(counts[l], slice);   // block-uniform
+                if (n <= CELL_INLINE_RERANK_MAX)
+                    continue;
+                const u64 *__restrict__ lr = rec + (size_t)l * slice;
+                const unsigned pairs = n * 16u;
+                const unsigned padded = (pairs + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
+                for (unsigned c = threadIdx.x; c < padded; c += KNN_BLOCK) {
+                    u64 key = ~0ull;
+                    unsigned qi = 0u;
+                    if (c < pairs)
+                        key = rerank_pair<K>(Q, R, k, npos, base, lr[c >> 4], c & 15u, 0xFFFFu, 0u, perm, qi);
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) {
+                        const u64 o = __shfl_xor(key, off, KNN_WAVE);
+                        key = o < key ? o : key;
+                    }
+                    if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
+                        key_atomic_min(&keys[qi], key);
+                }
+            }
+          }
+          if (have != 0u) {
             const u64 *__restrict__ ovf = rec + ovf_base;
             const unsigned pairs = have * 16u;
             const unsigned padded = (pairs + KNN_BLOCK - 1) / KNN_BLOCK * KNN_BLOCK;
@@ -1527,6 +1564,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
                 if ((threadIdx.x & 15u) == 0u && key != ~0ull && key < keys[qi])
                     key_atomic_min(&keys[qi], key);
             }
+          }
         }
     }
     if (!fin.gids && !fin.out_idx)
@@ -2140,7 +2178,7 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
 #define KNN_TAIL_LAUNCH(KV)                                                                                                \
     hipLaunchKernelGGL(knn_cells_tail_kernel<KV>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, st.n, npos, base, c.items,  \
                        c.nitems, w.cell_counts, w.cell_lists, c.cap, c.perm, w.records, w.ovf_base, w.ovf_cap, w.ctl_cur,   \
-                       keys, fin)
+                       keys, fin, w.counts, w.nlists, w.slice)
         switch (st.k) {
         case 16: KNN_TAIL_LAUNCH(16); break;
         case 8: KNN_TAIL_LAUNCH(8); break;

@@ -66,6 +66,7 @@ enum {
                              // the rows of a tight cluster apart): the listed (cell, query) pairs are evaluated exactly instead
     KNN_CTL_SCAN_DONE = 9,   // cell-pruned path: blocks of the scan that have finished (the last one finalises a clean batch)
     KNN_CTL_TAIL_DONE = 10,  // cell-pruned path: blocks of the tail kernel that have finished
+    KNN_CTL_DEFERRED = 11,   // cell-pruned path, != 0: some wave of the scan left a long record list to the tail kernel
     KNN_CTL_WORDS = 12
 };
 

@@ -138,6 +138,30 @@ def test_clustered_and_degenerate_data_stay_on_the_pruned_path(oracle, dist, k, 
     assert st2[2] == st[2]
 
 
+@pytest.mark.parametrize("k,n", [(16, 1 << 20), (12, (1 << 19) + 4099)])
+def test_long_record_lists_left_to_the_tail_kernel(oracle, k, n):
+    """A scan wave re-ranks up to 64 of its own records; a longer list stays where it is and the tail kernel re-ranks it (round 4:
+    re-ranking whatever a wave had cost 0.5 ms on data whose batches ended in the exact evaluation anyway).  Heavy-tailed rows —
+    a coarse fp16 grid for most of them, tens of candidates per query — give many waves more than 64 records WITHOUT filling
+    the shared area: the batch must stay on the filter (stats[2] == 0), leave far more records than 64 per list on average
+    over the lists that have any, and be bit-exact."""
+    m = 1024
+    rng = np.random.default_rng(k * 1009 + 3)
+    R = (rng.normal(0, 1, (n, k)) / np.sqrt(rng.random((n, 1)))).astype(np.float32)
+    Q = (rng.normal(0, 1, (m, k)) / np.sqrt(rng.random((m, 1)))).astype(np.float32)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    ix = pkg.KnnIndex(k, R)
+    try:
+        got, st = _query(ix, Q)
+        again, _ = _query(ix, Q)
+    finally:
+        ix.close()
+    np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
+    np.testing.assert_array_equal(again, got)
+    assert st[0] == 4 and st[2] == 0, st
+    assert st[1] > 64 * 256, st     # records: enough that many of the scan's record lists are beyond what a wave re-ranks itself
+
+
 def test_equidistant_rows_in_different_cells_resolve_to_the_lower_index(oracle):
     """Pairs of rows mirrored about a query along one axis (exactly equal v0 distances, different cells on
     either side of a cut): the answer is the lower index, wherever it sits."""
