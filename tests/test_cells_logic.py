@@ -145,3 +145,46 @@ def test_scan_plan_refuses_batches_longer_than_one_pass():
     for bad in ((256, 2, 100, 1025), (256, 3, 100, 64), (0, 1, 100, 64), (256, 1, 100, 0)):
         with pytest.raises(pkg.KnnError):
             pkg.debug_scan_plan(*bad)
+
+
+@pytest.mark.parametrize("nitems", [1, 15, 16, 17, 8192, 65536, 65536 * 3 + 7])
+@pytest.mark.parametrize("blocks", [1, 2, 256, 512, 304])
+def test_block_counter_deal_hands_every_item_to_exactly_one_block(nitems, blocks):
+    """knn_cells_scan_kernel<DYN = true>: a block's share is one run of CELL_SCAN_RUN items out of every stripe of `blocks`
+    runs, the run rotated by a golden-ratio step from stripe to stripe.  The slot -> item arithmetic restated: every item
+    belongs to exactly one (block, slot), holes only behind the last item, and a block's runs are spread over the stripe."""
+    RUN = 16
+    nruns = (nitems + RUN - 1) // RUN
+    slots = (nruns + blocks - 1) // blocks * RUN            # i1 in the kernel: the share, in slots
+    rot = ((blocks * 2654435769) >> 32) | 1                 # __umulhi(gridDim.x, 2654435769u) | 1u
+    s = np.arange(slots, dtype=np.int64)
+    seen = np.zeros(nitems, dtype=np.int64)
+    stripe = s // RUN
+    for b in range(blocks):
+        run = stripe * blocks + (b + stripe * rot) % blocks
+        it = run * RUN + s % RUN
+        ok = (run < nruns) & (it < nitems)
+        np.add.at(seen, it[ok], 1)
+    assert (seen == 1).all()
+    if blocks >= 256 and nitems >= 65536:                   # the rotation walks a block's runs over the stripe: no two stripes at one position
+        pos = (0 + np.arange(slots // RUN) * rot) % blocks
+        assert len(set(pos.tolist())) == len(pos)
+
+
+@pytest.mark.parametrize("ranges,qgroups", [(16, 256), (16, 3), (32, 64), (16, 1), (128, 8), (16, 255), (20, 17)])
+def test_chunked_scan_block_order_covers_every_pair_once(ranges, qgroups):
+    """knn_filter_chunked_kernel's one-dimensional grid (round 4): block L is the (L / 8)-th block of XCD L % 8, which walks its
+    query groups (g = XCD mod 8) with all `ranges` tile ranges of a group side by side.  Restated: every (range, query group)
+    pair is scored by exactly one block, blocks past the last query group do nothing, and the 64 blocks an XCD has resident
+    at a time cover at most ceil(64 / ranges) + 1 query groups (their B fragments are what has to fit its L2)."""
+    grid = ranges * ((qgroups + 7) // 8) * 8
+    L = np.arange(grid, dtype=np.int64)
+    xcd, j = L & 7, L >> 3
+    bx, by = j % ranges, (j // ranges) * 8 + xcd
+    live = by < qgroups
+    pairs = set(zip(bx[live].tolist(), by[live].tolist()))
+    assert len(pairs) == int(live.sum()) == ranges * qgroups
+    for c in range(8):                                      # per XCD, in dispatch order: any 64 consecutive blocks
+        mine = by[(xcd == c) & live]
+        for start in range(0, max(1, len(mine) - 64), 64):
+            assert len(set(mine[start:start + 64].tolist())) <= (64 + ranges - 1) // ranges + 1
