@@ -652,8 +652,6 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     // more than the table loads at 2^13 cells, where a list holds ~125 of 1024 queries), lists in query order.
     // (64 loads outstanding — a wave's whole run of the queue in one round trip instead of three — measured in round 4: 76-80
     // registers instead of 55-58, C3 one batch at a time 0.150 -> 0.155 ms, pipelined 0.1195 -> 0.1235.  16 stays.)
-    // (64 loads outstanding — a wave's whole run of the queue in one round trip instead of three — measured in round 4: 76-80
-    // registers instead of 55-58, C3 one batch at a time 0.150 -> 0.155 ms, pipelined 0.1195 -> 0.1235.  16 stays.)
     constexpr int EPW = 1024 / CELL_MATCH_WAVES, INFLIGHT = 16;   // entries per wave; low-table loads outstanding
     const unsigned per = (npass + CELL_MATCH_WAVES - 1u) / CELL_MATCH_WAVES;
     const unsigned e_begin = min((unsigned)wib * per, npass), e_end = min(e_begin + per, npass);

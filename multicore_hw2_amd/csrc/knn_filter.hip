@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(FILTER_BLOCK, 2) void knn_filter_chunked_kernel(
     // ranges of a query group side by side: 64 / ranges query groups' B (2 MB at 16 ranges) stay in the L2, each range's A
     // is shared by those few blocks, and what comes from beyond the L2 is every operand about once per XCD pass.
     unsigned bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
-    if (ranges != 0u) {
+    if (!SAMPLE && ranges != 0u) {   // (the sample pass keeps the plain grid: it is launched that way, and its registers are all taken)
         const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
         bx = j % ranges;
         by = (j / ranges) * 8u + xcd;

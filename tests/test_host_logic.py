@@ -175,6 +175,16 @@ def test_filter_kernels_keep_mfma_results_12_wait_states_from_their_readers(tmp_
         bad2, _ = mfma_hazard_audit.audit_operands(asm.read_text())
         assert not bad2, (name, bad2[:5])
         total += n_mfma
+        if name == "knn_filter.hip":
+            # the deep-K scans sit at 246-256 registers: a constant hoisted out of the stage loop is a spill (round 4: 20-52 bytes
+            # of scratch in the chunked-K scan until its epilogue's lane-derived values were worked out inside the epilogue)
+            deep = 0
+            for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm.read_text(), flags=re.S):
+                if re.search(r"knn_filter_(tiled|chunked)_kernel", m.group(1)):
+                    scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+                    assert scratch == 0, (m.group(1), scratch)
+                    deep += 1
+            assert deep >= 10, deep
     assert total >= 300, total
 
 
