@@ -68,6 +68,9 @@ def parse_args():
                     help="one GPU plays rank r (default 0) of an N-rank cell-range sharded run: the whole set is generated here, "
                          "all N shards are built (their seed layer is needed), rank r's step is timed — no collective.  For the "
                          "per-rank projections under profiles/ when no multi-GPU node is at hand")
+    ap.add_argument("--group", type=int, default=0,
+                    help="N > 1: batches whose keys ONE all-reduce folds (0 = 16, or the batches in flight when that is more): "
+                         "the collective's host cost (~50 us per call through torch.distributed) is shared by the group")
     ap.add_argument("--scan-stamps", default="", metavar="FILE.npz",
                     help="development: with a library built by tools/build_timeline_lib.sh (KNN_MI355X_LIB), save the "
                          "per-wave wall-clock stamps of the last pruned-scan launch, pipelined and one batch at a time")
@@ -341,8 +344,15 @@ def main():
     inflight = args.inflight if args.inflight > 0 else (2 if long_scan and not cells_expected else 4 if cells_expected and k > 4 else 3)
     nbuf = 1 if args.serial else max(1, min(8, inflight))
     # Key / result buffers: [group][batch]; without a collective only group 0 is used.
-    keys_all = torch.empty((2, nbuf, m), dtype=torch.int64, device=dev)
-    outs_all = torch.empty((2, nbuf, m), dtype=torch.int32, device=dev)
+    # gsize = batches per exchange step (N > 1).  Round 4: a group was the nbuf batches in flight; with a rank of eight at 26 us of
+    # GPU work per batch the host became the limit — one all-reduce through torch.distributed costs the host ~50 us, 12 us per
+    # step at four batches per group (one rank, n_local 2^21: 0.048 ms per step against 0.037 without a collective).  Sixteen
+    # batches per group: the same 8 KiB-per-batch exchange, one call per 16 steps.  The batches still run nbuf at a time on
+    # nbuf streams / workspace slots; a batch's indices are final when its group's reduction has run (inside the timed region:
+    # the last group is flushed before the closing fence).
+    gsize = nbuf if dist is None or args.serial else max(nbuf, args.group if args.group > 0 else 16)
+    keys_all = torch.empty((2, gsize, m), dtype=torch.int64, device=dev)
+    outs_all = torch.empty((2, gsize, m), dtype=torch.int32, device=dev)
     keys = [keys_all[0, b] for b in range(nbuf)]
     outs = [outs_all[0, b] for b in range(nbuf)]
     # index build: the first one of a process also loads the code objects and fills the library's buffer pool (13 ms at C3
@@ -388,22 +398,31 @@ def main():
     # 85 us step of a 2M-row shard.
     reduce_stream = torch.cuda.Stream(device=dev) if dist is not None else None
     group_done = [None, None]      # event: group g's buffers hold final indices and may be reused
-    batch_done = [None] * nbuf     # events of the current group's scans
     state = {"filled": 0, "group": 0, "last": (0, 0)}
+
+    # (everything the distributed hot loop needs per step is made here once: the host side of a step was ~25 us of torch stream
+    # contexts, tensor views and fresh events where a rank of eight's GPU work is 26 us)
+    key_ptrs_all = [[keys_all[g_, b_].data_ptr() for b_ in range(gsize)] for g_ in range(2)]
+    stream_events = [[torch.cuda.Event() for _ in range(nstreams)] for _ in range(2)]   # "this stream's batches of the group are done"
+    group_events = [torch.cuda.Event(), torch.cuda.Event()]
+    group_views = [[keys_all[g_, :f_] for f_ in range(gsize + 1)] for g_ in range(2)]
+    group_key_ptr = [keys_all[g_].data_ptr() for g_ in range(2)]
+    group_out_ptr = [outs_all[g_].data_ptr() for g_ in range(2)]
 
     def flush_group():
         """All-reduce + unpack the batches enqueued so far in the current group."""
         g, filled = state["group"], state["filled"]
         if dist is None or filled == 0:
             return
-        for b in range(filled):
-            reduce_stream.wait_event(batch_done[b])
-        with torch.cuda.stream(reduce_stream):
+        for s_ in range(min(filled, nstreams)):   # every stream that carried batches of the group: one event each, recorded now
+            stream_events[g][s_].record(streams[s_])
+            reduce_stream.wait_event(stream_events[g][s_])
+        with torch.cuda.stream(reduce_stream):      # (torch.distributed launches on torch's current stream)
             # keys < 2^63 (distance bits of a non-negative float): int64 MIN == unsigned MIN
-            dist.all_reduce(keys_all[g, :filled], op=dist.ReduceOp.MIN)
-            pkg.keys_to_indices(keys_all[g].data_ptr(), filled * m, outs_all[g].data_ptr(), device=local_rank,
-                                stream=reduce_stream.cuda_stream)
-            group_done[g] = reduce_stream.record_event()
+            dist.all_reduce(group_views[g][filled], op=dist.ReduceOp.MIN)
+        pkg.keys_to_indices(group_key_ptr[g], filled * m, group_out_ptr[g], device=local_rank, stream=reduce_stream.cuda_stream)
+        group_events[g].record(reduce_stream)
+        group_done[g] = group_events[g]
         state["group"], state["filled"] = g ^ 1, 0
 
     raw_streams = [st_.cuda_stream for st_ in streams]
@@ -421,28 +440,40 @@ def main():
                              indices_dev=out_ptrs[b])
             state["last"] = (0, b)
             return
+        if dist is not None and not args.separate_init:
+            # the N > 1 hot loop: wait for the buffers' previous use, one library call, one event — on explicit streams
+            b, g = state["filled"], state["group"]
+            slot = b % nstreams
+            st = streams[slot]
+            if b < nstreams and group_done[g] is not None:
+                st.wait_event(group_done[g])     # the previous use of these buffers is complete (later batches: stream order)
+            index.query_keys(m, q_ptr, key_ptrs_all[g][b], stream=raw_streams[slot], slot=slot, init_keys=True)
+            state["last"] = (g, b)
+            state["filled"] = b + 1
+            if b + 1 == gsize:
+                flush_group()
+            return
         b = state["filled"] if dist is not None else i % nbuf
-        st = streams[b % nstreams]
+        slot = b % nstreams
+        st = streams[slot]
         with torch.cuda.stream(st):
             if dist is not None:
                 g = state["group"]
-                if group_done[g] is not None:
+                if b < nstreams and group_done[g] is not None:
                     st.wait_event(group_done[g])     # the previous use of these buffers is complete
                 kb, ob = keys_all[g, b], outs_all[g, b]
             else:
                 g, kb, ob = 0, keys[b], outs[b]
             if args.separate_init:
                 pkg.keys_init(kb.data_ptr(), m, device=local_rank, stream=st.cuda_stream)
-            index.query_keys(m, q_d.data_ptr(), kb.data_ptr(), stream=st.cuda_stream, slot=b,
+            index.query_keys(m, q_d.data_ptr(), kb.data_ptr(), stream=st.cuda_stream, slot=slot,
                              init_keys=not args.separate_init)
-            if dist is not None:
-                batch_done[b] = st.record_event()
-            else:
+            if dist is None:
                 pkg.keys_to_indices(kb.data_ptr(), m, ob.data_ptr(), device=local_rank, stream=st.cuda_stream)
         state["last"] = (g, b)
         if dist is not None:
             state["filled"] += 1
-            if state["filled"] == nbuf:
+            if state["filled"] == gsize:
                 flush_group()
 
     def drain():
@@ -476,7 +507,7 @@ def main():
         t_extra = torch.tensor([extra], dtype=torch.int64, device=dev)
         dist.broadcast(t_extra, src=0)
         extra = int(t_extra.item())
-    extra = (extra + nbuf - 1) // nbuf * nbuf
+    extra = (extra + gsize - 1) // gsize * gsize
     for i in range(extra):
         step(i)
     drain()
@@ -545,8 +576,8 @@ def main():
         with torch.cuda.stream(reduce_stream):
             ev0.record()
             for _ in range(reps):
-                dist.all_reduce(keys_all[0, :nbuf], op=dist.ReduceOp.MIN)
-                pkg.keys_to_indices(keys_all[0].data_ptr(), nbuf * m, outs_all[0].data_ptr(), device=local_rank,
+                dist.all_reduce(keys_all[0, :gsize], op=dist.ReduceOp.MIN)
+                pkg.keys_to_indices(keys_all[0].data_ptr(), gsize * m, outs_all[0].data_ptr(), device=local_rank,
                                     stream=reduce_stream.cuda_stream)
             ev1.record()
         torch.cuda.synchronize()
@@ -691,10 +722,10 @@ def main():
                        "batches_in_flight": nstreams, "setup_steps": setup_steps,
                        "keys_init": "separate launch" if args.separate_init else "inside the query (KNN_QUERY_INIT_KEYS)",
                        "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %
-                                      ("gloo (one-GPU rehearsal)" if rehearse else "rccl", nbuf, m, nbuf))
+                                      ("gloo (one-GPU rehearsal)" if rehearse else "rccl", gsize, m, gsize))
                        if dist is not None else None,
                        "collective_ms_per_group_alone": collective_ms,
-                       "collective_ms_per_step_alone": collective_ms / nbuf if collective_ms is not None else None},
+                       "collective_ms_per_step_alone": collective_ms / gsize if collective_ms is not None else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu_all is not None:
