@@ -248,15 +248,25 @@ def main():
                 raise
             sys.stderr.write("bench.py: %s\nbench.py: falling back to index-range shards\n" % exc)
             shard_mode = "index"
-    def partition_by_cells():
-        """2. where every row belongs; rows and their global numbers sorted by destination (stable: ascending per destination),
-        moved there by one all-to-all.  -> (this rank's rows, their global numbers, note)"""
-        nonlocal layer_d
+    def partition_local():
+        """2a. LOCAL work only (no collective inside: a rank that fails here has not left its peers blocked in an all-to-all —
+        ADVICE r04): where every row belongs; rows and their global numbers sorted by destination (stable: ascending per
+        destination).  -> what partition_exchange needs"""
         owner = torch.empty(n_local, dtype=torch.int32, device=dev)
         geom.assign(rows2d.data_ptr(), n_local, owner.data_ptr(), device=local_rank, stream=stream)
         torch.cuda.synchronize()
-        my = emu_r if emu_n else rank
         counts = torch.bincount(owner, minlength=nshards).to(torch.int64)
+        if emu_n:
+            return owner, counts, None, None
+        order = torch.argsort(owner, stable=True)
+        send_rows = rows2d[order].contiguous()
+        send_gids = (order + lo).to(torch.int32)
+        return owner, counts, send_rows, send_gids
+
+    def partition_exchange(owner, counts, send_rows, send_gids):
+        """2b. the rows move to their ranks by one all-to-all (entered only when EVERY rank got through 2a).
+        -> (this rank's rows, their global numbers, note)"""
+        nonlocal layer_d
 
         def all_to_all(send, in_split, out_split):
             """rows of `send` (sorted by destination) -> the rows every rank sends here, in source order"""
@@ -276,7 +286,8 @@ def main():
                 g_ = torch.nonzero(owner == r_).reshape(-1)
                 rows_r = rows2d[g_].contiguous()
                 gids_r = (g_ + lo).to(torch.int32)
-                ix_ = pkg.KnnIndex.sharded(geom, r_, rows_r.data_ptr(), gids_r.data_ptr(), rows_r.shape[0], device=local_rank, stream=stream)
+                ix_ = pkg.KnnIndex.sharded(geom, r_, rows_r.data_ptr(), gids_r.data_ptr(), rows_r.shape[0], device=local_rank, stream=stream,
+                                           owners=(rows_r, gids_r))
                 ix_.seed_export(layer_d.data_ptr(), stream=stream)
                 torch.cuda.synchronize()
                 ix_.close()
@@ -285,9 +296,6 @@ def main():
                 del rows_r, gids_r, g_
             rows_d, gids_d = mine_rows, mine_gids
         else:
-            order = torch.argsort(owner, stable=True)
-            send_rows = rows2d[order].contiguous()
-            send_gids = (order + lo).to(torch.int32)
             cnt_out = torch.empty(world, dtype=torch.int64, device=dev)
             if rehearse:
                 c_cpu = torch.empty(world, dtype=torch.int64)
@@ -298,8 +306,6 @@ def main():
             in_split, out_split = [int(c_) for c_ in counts.tolist()], [int(c_) for c_ in cnt_out.tolist()]
             rows_d = all_to_all(send_rows, in_split, out_split)
             gids_d = all_to_all(send_gids, in_split, out_split)
-            del send_rows, send_gids, order
-        del owner
         torch.cuda.synchronize()
         note = {"partition": "cell ranges of one global grid of 2^%d cells (%d per rank at most), seed layer %d tile(s) per cell = "
                              "%.0f MB replicated" % (geom.bits, geom.cells_per_rank, geom.seed_tiles, geom.layer_bytes / 1e6),
@@ -310,20 +316,25 @@ def main():
 
     if shard_mode == "cells":
         assert not args.separate_init, "a cell-range shard starts its keys itself (KNN_QUERY_INIT_KEYS)"
-        # (a failure here — an all-to-all the transport does not support, a geometry a rank refuses — must not take the whole
-        # run down: every rank reports, and if any failed all of them keep the index-range shards they already hold)
-        parted, why = None, ""
+        # Two phases.  A LOCAL failure — a geometry a rank refuses, an allocation — must not take the whole run
+        # down: every rank reports after the local phase, and if any failed all of them keep the index-range shards they
+        # already hold.  The collectives are entered only when every rank is ready for them; an error INSIDE a collective is
+        # not recoverable (the peers are blocked in it) and ends the run through the process group's timeout.
+        local, why = None, ""
         try:
-            parted = partition_by_cells()
+            local = partition_local()
         except Exception as exc:     # noqa: BLE001
             why = "%s: %s" % (type(exc).__name__, exc)
-        ok = 1 if parted is not None else 0
+        if os.environ.get("KNN_BENCH_TEST_PARTITION_FAIL_RANK") == str(rank):    # (test hook: tests/test_shards_logic.py)
+            local, why = None, "KNN_BENCH_TEST_PARTITION_FAIL_RANK"
+        ok = 1 if local is not None else 0
         if dist is not None:
             flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearse else dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
         if ok:
-            rows_d, gids_d, shard_note = parted
+            rows_d, gids_d, shard_note = partition_exchange(*local)
+            del local
             r_d = rows_d.reshape(-1)            # this rank's rows from here on
             n_local = rows_d.shape[0]
             if emu_n:
@@ -360,8 +371,9 @@ def main():
     def make_index():
         if shard_mode == "cells":
             return pkg.KnnIndex.sharded(geom, emu_r if emu_n else rank, r_d.data_ptr(), gids_d.data_ptr(), n_local,
-                                        device=local_rank, stream=stream)
-        return pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo, refs_on_device=True, stream=stream)
+                                        device=local_rank, stream=stream, owners=(r_d, gids_d))
+        return pkg.KnnIndex(k, r_d.data_ptr(), n_local=n_local, device=local_rank, base_index=lo, refs_on_device=True, stream=stream,
+                            owners=(r_d,))
 
     t0 = time.perf_counter()
     index = make_index()
@@ -386,7 +398,7 @@ def main():
                 layer_d.copy_(torch.cat(gl).to(dev))
             else:
                 dist.all_gather_into_tensor(layer_d, part)
-        index.seed_attach(layer_d.data_ptr())
+        index.seed_attach(layer_d.data_ptr(), owner=layer_d)
         torch.cuda.synchronize()
         shard_note["seed_layer_ms"] = (time.perf_counter() - t0) * 1e3
     nstreams = nbuf
@@ -521,6 +533,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_issued = time.perf_counter() - t0      # the host is done enqueueing (launches are asynchronous): host-bound if ~ elapsed
     drain()
     fence()
     elapsed = time.perf_counter() - t0
@@ -592,106 +605,13 @@ def main():
     result_idx = outs_all[state["last"][0], state["last"][1]].cpu().numpy()
 
     if rank == 0:
-        # Roofline of the dominant kernel.  Basis: the bytes (or flops) the kernel has to move,
-        # divided by the duration of a SINGLE launch with the GPU to itself (HIP events on its stream, 20 launches after
-        # the timed region) — so frac <= 1 by construction and reproducible from the serial kernel trace under profiles/.
-        # The north_star's figure — SURVEY 8(d)'s algorithmic bytes over the step time — is kept under its own name.
-        kern_avg_ms = kern_ms / max(launches, 1)                  # a launch inside the pipelined timed region
-        # (the headline fraction stays on the directly measured bracket; the figure with the event pair's own
-        # cost taken off — what rocprofv3 reports as AverageNs — is published under its own keys)
-        kern_ms_alone = alone_ms / max(alone_n, 1)                # the same kernel, nothing else on the GPU, between two events
-        kern_ms_minus_pair = max(kern_ms_alone - event_pair_ms, 0.5 * kern_ms_alone)
-        alg_bytes = 4.0 * k * n_local + 4.0 * k * m + 8.0 * m      # the fp32 rows once, queries, keys
-        path_taken = int(stats[0])
-        roof = {}
-        if path_taken == 2:
-            flops = 2.0 * k * m * n_local
-            ach = flops / (kern_ms_alone * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "knn_filter (f16 MFMA 32x32x16 over every pair + exact re-rank)",
-                    "flops_per_launch": flops}
-        elif path_taken == 4:
-            # cell-pruned scan: ~4 % of the pairs are scored; the kernel reads the cell-sorted fp16 layout once —
-            # 32 B of fragment + 4 B of norm per position, cells padded to whole tiles (~4 %)
-            phys = 36.0 * n_local * 1.04
-            roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
-                    "kernel": "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",
-                    "bytes_per_launch": phys, "bytes_source": "layout size (36 B per position, 4 % padding)"}
-        else:
-            roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
-                    "kernel": "knn_grid_query (uniform-grid ring search, one wave per query: latency-bound, touches a few "
-                              "hundred rows per query instead of n)" if path_taken == 3 else
-                              "knn_exact (fp32 VALU scan of the rows; HBM-bound only for m <~ 10)",
-                    "bytes_per_launch": alg_bytes if path_taken != 3 else None,
-                    "bytes_source": "the fp32 rows once (SURVEY 8d)" if path_taken != 3 else
-                                    "not a streaming kernel: no byte model (see kernel_ms)"}
-            if path_taken == 1:
-                lane_ops = (3.0 * k + 3.0) * m * n_local
-                roof["valu_frac"] = lane_ops / (kern_ms_alone * 1e-3) / VALU_LANE_OPS_PEAK
-        # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json).  Quoted only when the profile
-        # was taken on the kernel source that is running now (the profile records the sha256 of
-        # the filter / cells / exact sources); a stale profile is named, not used.
-        pmc_name = "r04_c3_pmc_traffic.json"
-        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-        if wname == "C3" and world == 1 and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc_doc = json.load(f)
-            if pmc_doc.get("kernel_source_sha256") == kernel_source_sha():
-                kname = {2: ("_Z17knn_filter", "void knn_filter_kernel"),
-                         4: ("_Z21knn_cells_scan", "void knn_cells_scan_kernel")
-                         }.get(path_taken, ("void knn_exact_qreg<16, 2>",))
-                best = None
-                for name, ent in pmc_doc["kernels"].items():
-                    if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
-                        if best is None or ent["hbm_bytes_per_launch"] > best["hbm_bytes_per_launch"]:
-                            best = ent
-                if best is not None:
-                    roof["traffic"] = best["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; " \
-                                             "read bytes = 2 x FETCH_SIZE KiB, gfx950); same kernel source" % pmc_name
-                    if path_taken == 4:
-                        roof["bytes_per_launch"] = best["hbm_bytes_per_launch"]
-                        roof["bytes_source"] = "PMC (traffic)"
-            else:
-                roof["traffic_source"] = "profiles/%s is from another build of the kernels: not quoted" % pmc_name
-        if path_taken == 4 and m < 512 and roof.get("traffic") is None:
-            # a small batch lists only some of the cells: the kernel reads a fraction of the layout and there is no byte model
-            # for it short of a PMC pass (m = 1 at C3 reads its ~1600 cells: 2.5 % of the layout)
-            roof["bytes_per_launch"] = None
-            roof["bytes_source"] = "batch too small to touch every cell: the layout size is not what the kernel reads"
-        if roof.get("bound") == "hbm":
-            bpl = roof.get("bytes_per_launch")
-            roof["achieved"] = bpl / (kern_ms_alone * 1e-3) / 1e9 if bpl else None
-            roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS if bpl else None
-        roof["kernel_ms"] = kern_ms_alone
-        roof["kernel_ms_basis"] = ("HIP events around the kernel on its stream, %d single launches, nothing else on the GPU "
-                                   "(the bracket as measured; an EMPTY event pair on the same stream reads event_pair_ms)" % alone_n)
-        roof["event_pair_ms"] = event_pair_ms
-        roof["kernel_ms_minus_event_pair"] = kern_ms_minus_pair   # ~ rocprofv3's AverageNs of the same launches
-        if roof.get("bound") == "hbm" and roof.get("bytes_per_launch"):
-            roof["frac_minus_event_pair"] = roof["bytes_per_launch"] / (kern_ms_minus_pair * 1e-3) / 1e9 / HBM_PEAK_GBPS
-        roof["kernel_in_pipeline_ms"] = kern_avg_ms           # a launch that shares the GPU with the other batches in flight
-        roof["kernel_launches_timed_in_pipeline"] = launches
-        roof["algorithmic_bytes_per_launch"] = alg_bytes
-        roof["algorithmic_frac_per_step"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
-        roof["algorithmic_frac_note"] = "SURVEY 8(d) bytes (the fp32 rows once) / ms_per_step / 8 TB/s: the north_star's figure; " \
-                                        "can exceed what the wires carry because the scan reads the fp16 layout (36 B per row, not 64)"
-        roof["serial_step_ms"] = serial_step_ms
-        if path_taken == 2 and k <= 16:
-            pairs_per_simd = (n_local / 32.0) * ((m + 31) // 32) / (256 * 4)
-            roof["ceiling"] = {
-                "what": "vector-issue floor of 'score every pair' at k <= 16: 1 MFMA + 8 v_min3_f32 per 32x32 tile pair",
-                "cycles_per_tile_pair": 50.0, "tile_pairs_per_simd": pairs_per_simd,
-                "ms_at_2.4GHz": pairs_per_simd * 50.0 / 2.4e9 * 1e3,
-                "ms_at_measured_clock_1.8GHz": pairs_per_simd * 50.0 / 1.8e9 * 1e3,
-                "source": "profiles/r02_filter_probe.txt (variants 21-39), profiles/r02_cvt_probe.txt"}
-        if path_taken == 4:
-            roof["ceiling"] = {
-                "what": "HBM read rate a bare reader of the same access pattern reaches on this chip",
-                "GBps": 6500.0, "ms_for_this_launch": (roof["bytes_per_launch"] / 6500e9 * 1e3) if roof["bytes_per_launch"] else None,
-                "source": "tools/read_probe2.hip, tools/read_probe.hip (profiles/r02_cells_probes.txt), DESIGN 4.5"}
+        stats_path = int(stats[0])
+        roof = roofline_block(k=k, m=m, n_local=n_local, path_taken=stats_path, kern_ms=kern_ms, launches=launches,
+                              alone_ms=alone_ms, alone_n=alone_n, event_pair_ms=event_pair_ms, ms_per_step=ms_per_step,
+                              serial_step_ms=serial_step_ms,
+                              pmc_key=pmc_workload_key(k, m, n_local, shard_mode, emu_n, emu_r, world),
+                              source_sha=kernel_source_sha())
+        path_taken = stats_path
 
         cpu = None
         cpu_all = None
@@ -720,6 +640,7 @@ def main():
                        "rerank_candidates": int(stats[1]), "index_prep_ms": prep_ms,
                        "index_prep_first_in_process_ms": prep_first_ms,
                        "batches_in_flight": nstreams, "setup_steps": setup_steps,
+                       "host_enqueue_ms_per_step": t_issued * 1e3 / args.steps,
                        "keys_init": "separate launch" if args.separate_init else "inside the query (KNN_QUERY_INIT_KEYS)",
                        "collective": ("%s all_reduce(min) of %d x %d packed keys per %d batches" %
                                       ("gloo (one-GPU rehearsal)" if rehearse else "rccl", gsize, m, gsize))
@@ -757,6 +678,164 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_workload_key(k, m, n_local, shard_mode, emu_n, emu_r, world):
+    """What a PMC traffic file must have been taken on to be quoted for this run: the shape the dominant kernel saw (k, m, the
+    rows of THIS rank's shard), how the shard was cut, and which rank of how many it is.  (Round 4 quoted the whole-set C3 file
+    under --emulate 8:3, where the shard is an eighth: a committed roofline.frac of 2.95.)"""
+    key = "k%d_m%d_n%d_%s" % (k, m, n_local, shard_mode if (emu_n or world > 1) else "whole")
+    if emu_n:
+        key += "_rank%dof%d" % (emu_r, emu_n)
+    elif world > 1:
+        key += "_world%d" % world
+    return key
+
+
+def find_pmc_profile(pmc_key, source_sha, profiles_dir=None):
+    """The newest profiles/*_pmc_traffic.json taken on this workload key -> (name, doc or None, why-not)."""
+    import glob
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    stale = None
+    for path in sorted(glob.glob(os.path.join(profiles_dir, "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if doc.get("workload_key") != pmc_key:
+            continue
+        if doc.get("kernel_source_sha256") == source_sha:
+            return os.path.basename(path), doc, None
+        stale = stale or os.path.basename(path)
+    if stale:
+        return stale, None, "profiles/%s is from another build of the kernels: not quoted" % stale
+    return None, None, "no PMC pass under profiles/ for workload key %s" % pmc_key
+
+
+READER_CEILING_GBPS = 6500.0    # a bare reader of the scan's access pattern (tools/read_probe2.hip, profiles/r02_cells_probes.txt)
+
+
+def roofline_block(k, m, n_local, path_taken, kern_ms, launches, alone_ms, alone_n, event_pair_ms, ms_per_step, serial_step_ms,
+                   pmc_key, source_sha, profiles_dir=None):
+    """Roofline of the dominant kernel (pure: tests/test_host_logic.py calls it on the CPU).  Basis: the
+    bytes (or flops) the kernel has to move, divided by the duration of a SINGLE launch with the GPU to itself (HIP events on its
+    stream, 20 launches after the timed region) — reproducible from the serial kernel trace under profiles/.  The north_star's
+    figure — SURVEY 8(d)'s algorithmic bytes over the step time — is kept under its own name.
+    Rules: PMC bytes are quoted only from a file taken on THIS workload key and THIS kernel source; a
+    physical fraction above 1, or a byte MODEL that would put the kernel above what a bare reader of its pattern reaches, is not
+    printed — `frac` is null and `frac_withheld` says why."""
+    kern_avg_ms = kern_ms / max(launches, 1)                  # a launch inside the pipelined timed region
+    # (ADVICE r03: the headline fraction stays on the directly measured bracket; the figure with the event pair's own
+    # cost taken off — what rocprofv3 reports as AverageNs — is published under its own keys)
+    kern_ms_alone = alone_ms / max(alone_n, 1)                # the same kernel, nothing else on the GPU, between two events
+    kern_ms_minus_pair = max(kern_ms_alone - event_pair_ms, 0.5 * kern_ms_alone)
+    alg_bytes = 4.0 * k * n_local + 4.0 * k * m + 8.0 * m      # SURVEY.md 8(d): the fp32 rows once, queries, keys
+    roof = {}
+    if path_taken == 2:
+        flops = 2.0 * k * m * n_local
+        ach = flops / (kern_ms_alone * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                "kernel": "knn_filter (f16 MFMA 32x32x16 over every pair + exact re-rank)",
+                "flops_per_launch": flops}
+    elif path_taken == 4:
+        # cell-pruned scan: ~4 % of the pairs are scored; the kernel reads the cell-sorted fp16 layout once —
+        # 32 B of fragment (k <= 16; 64 B for 16 < k <= 32) + 4 B of norm per position, cells padded to whole tiles (~4 %)
+        per_pos = 32.0 * ((k + 15) // 16) + 4.0
+        phys = per_pos * n_local * 1.04
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
+                "kernel": "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",
+                "bytes_per_launch": phys, "bytes_source": "layout size (%d B per position, 4 %% padding)" % per_pos}
+    else:
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
+                "kernel": "knn_grid_query (uniform-grid ring search, one wave per query: latency-bound, touches a few "
+                          "hundred rows per query instead of n)" if path_taken == 3 else
+                          "knn_exact (fp32 VALU scan of the rows; HBM-bound only for m <~ 10)",
+                "bytes_per_launch": alg_bytes if path_taken != 3 else None,
+                "bytes_source": "the fp32 rows once (SURVEY 8d)" if path_taken != 3 else
+                                "not a streaming kernel: no byte model (see kernel_ms)"}
+        if path_taken == 1:
+            lane_ops = (3.0 * k + 3.0) * m * n_local
+            roof["valu_frac"] = lane_ops / (kern_ms_alone * 1e-3) / VALU_LANE_OPS_PEAK
+    # HBM bytes per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this
+    # same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json).  Quoted only when the profile was taken on this
+    # workload key (shape of the rank's shard, shard mode, rank) AND on the kernel source that is running now.
+    roof["pmc_key"] = pmc_key
+    pmc_name, pmc_doc, why_not = find_pmc_profile(pmc_key, source_sha, profiles_dir)
+    if pmc_doc is not None:
+        kname = {2: ("_Z17knn_filter", "void knn_filter_kernel"),
+                 4: ("_Z21knn_cells_scan", "void knn_cells_scan_kernel")
+                 }.get(path_taken, ("void knn_exact_qreg<16, 2>",))
+        best = None
+        for name, ent in pmc_doc["kernels"].items():
+            if name.startswith(kname) and ent["hbm_bytes_per_launch"] > 1e6:
+                if best is None or ent["hbm_bytes_per_launch"] > best["hbm_bytes_per_launch"]:
+                    best = ent
+        if best is not None:
+            roof["traffic"] = best["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; " \
+                                     "read bytes = 2 x FETCH_SIZE KiB, gfx950); same kernel source, same workload key" % pmc_name
+            if path_taken == 4:
+                roof["bytes_per_launch"] = best["hbm_bytes_per_launch"]
+                roof["bytes_source"] = "PMC (traffic)"
+    else:
+        roof["traffic_source"] = why_not
+    if path_taken == 4 and m < 512 and roof.get("traffic") is None:
+        # a small batch lists only some of the cells: the kernel reads a fraction of the layout and there is no byte model
+        # for it short of a PMC pass (m = 1 at C3 reads its ~1600 cells: 2.5 % of the layout)
+        roof["bytes_per_launch"] = None
+        roof["bytes_source"] = "batch too small to touch every cell: the layout size is not what the kernel reads"
+    if roof.get("bound") == "hbm":
+        bpl = roof.get("bytes_per_launch")
+        roof["achieved"] = bpl / (kern_ms_alone * 1e-3) / 1e9 if bpl else None
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS if bpl else None
+    roof["kernel_ms"] = kern_ms_alone
+    roof["kernel_ms_basis"] = ("HIP events around the kernel on its stream, %d single launches, nothing else on the GPU "
+                               "(the bracket as measured; an EMPTY event pair on the same stream reads event_pair_ms)" % alone_n)
+    roof["event_pair_ms"] = event_pair_ms
+    roof["kernel_ms_minus_event_pair"] = kern_ms_minus_pair   # ~ rocprofv3's AverageNs of the same launches
+    if roof.get("bound") == "hbm" and roof.get("bytes_per_launch"):
+        roof["frac_minus_event_pair"] = roof["bytes_per_launch"] / (kern_ms_minus_pair * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    # ---- nothing above what the wires can carry leaves this function
+    if roof.get("bound") == "hbm" and roof.get("frac") is not None:
+        modelled = roof.get("bytes_source", "").startswith("layout size")
+        limit = READER_CEILING_GBPS / HBM_PEAK_GBPS if modelled else 1.0
+        worst = max(roof["frac"], roof.get("frac_minus_event_pair") or 0.0)
+        if worst > limit:
+            roof["frac_withheld"] = (
+                "%.3f of 8 TB/s from %s is above %s: these are not the bytes this launch moved (a shard whose batch lists only "
+                "some of its cells reads less than its layout) — take a PMC pass for workload key %s (tools/pmc_traffic.py)"
+                % (worst, roof.get("bytes_source"), "what a bare reader of the pattern reaches (6.5 TB/s)" if modelled else "the peak", pmc_key))
+            roof["achieved"] = None
+            roof["frac"] = None
+            roof.pop("frac_minus_event_pair", None)
+    elif roof.get("frac") is not None and roof["frac"] > 1.0:
+        roof["frac_withheld"] = "%.3f of the peak: not a physical figure" % roof["frac"]
+        roof["achieved"] = None
+        roof["frac"] = None
+    roof["kernel_in_pipeline_ms"] = kern_avg_ms           # a launch that shares the GPU with the other batches in flight
+    roof["kernel_launches_timed_in_pipeline"] = launches
+    roof["algorithmic_bytes_per_launch"] = alg_bytes
+    roof["algorithmic_frac_per_step"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    roof["algorithmic_frac_note"] = "SURVEY 8(d) bytes (the fp32 rows once) / ms_per_step / 8 TB/s: the north_star's figure; " \
+                                    "can exceed what the wires carry because the scan reads the fp16 layout (36 B per row, not 64)"
+    roof["serial_step_ms"] = serial_step_ms
+    if path_taken == 2 and k <= 16:
+        pairs_per_simd = (n_local / 32.0) * ((m + 31) // 32) / (256 * 4)
+        roof["ceiling"] = {
+            "what": "vector-issue floor of 'score every pair' at k <= 16: 1 MFMA + 8 v_min3_f32 per 32x32 tile pair",
+            "cycles_per_tile_pair": 50.0, "tile_pairs_per_simd": pairs_per_simd,
+            "ms_at_2.4GHz": pairs_per_simd * 50.0 / 2.4e9 * 1e3,
+            "ms_at_measured_clock_1.8GHz": pairs_per_simd * 50.0 / 1.8e9 * 1e3,
+            "source": "profiles/r02_filter_probe.txt (variants 21-39), profiles/r02_cvt_probe.txt"}
+    if path_taken == 4:
+        roof["ceiling"] = {
+            "what": "HBM read rate a bare reader of the same access pattern reaches on this chip",
+            "GBps": READER_CEILING_GBPS,
+            "ms_for_this_launch": (roof["bytes_per_launch"] / (READER_CEILING_GBPS * 1e9) * 1e3) if roof.get("bytes_per_launch") and not roof.get("frac_withheld") else None,
+            "source": "tools/read_probe2.hip, tools/read_probe.hip (profiles/r02_cells_probes.txt), DESIGN 4.5"}
+    return roof
 
 
 def kernel_source_sha():

@@ -123,7 +123,10 @@ long long knn_geom_first_cell(const knn_geom *g, int rank);
 /* owner_dev[i] = rank whose cell range holds rows_dev[i] (device arrays on `device`; synchronous on return). */
 int knn_geom_assign(const knn_geom *g, int device, const float *rows_dev, long long n, int *owner_dev, void *stream);
 /* refs_dev: the rank's rows (device, borrowed); gids_dev[i]: global row number of refs_dev[i], STRICTLY ASCENDING, < 2^31
- * (device, borrowed) — v0's lowest-index tie-break is decided by local row order.  KNN_EINVAL when a row lies outside the
+ * (device, borrowed) — v0's lowest-index tie-break is decided by local row order.
+ * LIFETIME: refs_dev, gids_dev and the layer given to knn_index_seed_attach are BORROWED for the index's whole life: the prep,
+ * scan and finalise kernels of every later query read them.  They must stay allocated and unchanged until knn_index_destroy
+ * returns (a caller that lets them go gets use-after-free reads inside those kernels).  KNN_EINVAL when a row lies outside the
  * rank's cell range of the geometry.  The index must be given the seed layer (export on every rank, gather, attach) before
  * it is queried by more than one rank's worth of queries: without it the bound comes from the rank's own cells only —
  * still exact, only slower. */
@@ -233,6 +236,10 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^15 cells while the index's last
  *             eight calls named more than one workspace slot — batches in flight side by side: the scan alone gets 10-20 %
  *             longer and the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
+ *   "cells_lists" who makes a cell's list of queries (those of the batch that cannot rule the cell out) on the pruned path:
+ *             1 = knn_cells_match_kernel in a launch of its own between the preparation and the scan (lists in memory),
+ *             2 = the scan's waves for the items they take (same test, same arithmetic, lists in LDS: one launch and one
+ *             dependent round trip per item fewer), 0 = auto: 2 for shards of up to 2^13 cells queried one batch at a time
  *   "scan_deal" how the pruned scan's waves get their work items (runs of tiles of one cell): 1 = fixed (wave w takes items
  *             w, w + W, ...), 2 = a block owns a contiguous run and its waves take items from a counter in LDS (the launch
  *             is 6-8 % shorter: no wave is left with twice the average), 0 = auto: 2 for callers that query one batch at a
@@ -277,6 +284,9 @@ int knn_debug_shard_policy(int k, int m, long long n, int ndev);
  * out = {scan blocks, record lists (= scan waves), records per list, first record of the shared overflow area, its
  * capacity, dynamic LDS bytes of the scan, records a workspace holds, list counters a workspace holds}. */
 int knn_debug_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, int m, long long out[8]);
+/* The same with the list maker named: self_lists != 0 = the scan's waves list their own items (option "cells_lists" 2): the
+ * dynamic LDS then also holds the batch's Dup values and one list room per wave. */
+int knn_debug_scan_plan_ex(int num_cu, int blocks_per_cu, unsigned nitems, int m, int self_lists, long long out[8]);
 
 /* Test hook for the filter's error bound: raw MFMA filter scores S[m][n_local] (row-major,
  * device) for a query batch, the fp32 squared norms M[m] of the fp16 query rows (device), and

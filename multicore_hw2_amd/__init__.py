@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
     "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim", "knn_keys_allreduce_min",
-    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_shard_policy", "knn_index_query",
+    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_scan_plan_ex", "knn_debug_shard_policy", "knn_index_query",
     "knn_geom_create", "knn_geom_destroy", "knn_geom_info", "knn_geom_assign", "knn_index_create_sharded",
     "knn_index_seed_export", "knn_index_seed_attach", "knn_geom_first_cell",
 ]
@@ -132,12 +132,12 @@ def debug_shard_policy(k, m, n, ndev):
     return rc
 
 
-def debug_scan_plan(num_cu, blocks_per_cu, nitems, m):
-    """knn_debug_scan_plan: sizes of one scan launch of the cell-pruned path (host arithmetic; works without a GPU)."""
+def debug_scan_plan(num_cu, blocks_per_cu, nitems, m, self_lists=False):
+    """knn_debug_scan_plan[_ex]: sizes of one scan launch of the cell-pruned path (host arithmetic; works without a GPU)."""
     out = (ctypes.c_longlong * 8)()
-    f = lib().knn_debug_scan_plan
-    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
-    _check(f(int(num_cu), int(blocks_per_cu), int(nitems), int(m), out))
+    f = lib().knn_debug_scan_plan_ex
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
+    _check(f(int(num_cu), int(blocks_per_cu), int(nitems), int(m), 1 if self_lists else 0, out))
     return dict(zip(("blocks", "nlists", "slice", "ovf_base", "ovf_cap", "lds_bytes", "rec_cap", "max_lists"), list(out)))
 
 
@@ -214,12 +214,16 @@ class KnnIndex:
     """Device-resident shard of the reference set (knn_index_* in include/knn_mi355x.h)."""
 
     @classmethod
-    def sharded(cls, geom, rank, refs_dev, gids_dev, n_local, device=0, stream=0):
+    def sharded(cls, geom, rank, refs_dev, gids_dev, n_local, device=0, stream=0, owners=None):
         """A cell-range shard (knn_index_create_sharded): this rank's rows of the global grid `geom` (device pointers;
-        gids strictly ascending).  Give it the seed layer (seed_export on every rank, gather, seed_attach) before querying."""
+        gids strictly ascending).  Give it the seed layer (seed_export on every rank, gather, seed_attach) before querying.
+        LIFETIME: the index BORROWS refs_dev and gids_dev (and the layer given to seed_attach) until close() — its prep, scan
+        and finalise kernels read them on every query.  Pass the objects that own that memory (torch tensors, ...) as
+        `owners` and the wrapper keeps them alive; with raw pointers the caller must."""
         self = cls.__new__(cls)
         self._h = ctypes.c_void_p()
-        self.k, self.device, self.base, self.n, self._keep = geom.k, int(device), 0, int(n_local), None
+        self.k, self.device, self.base, self.n, self._keep = geom.k, int(device), 0, int(n_local), owners
+        self._layer = None
         _check(lib().knn_index_create_sharded(ctypes.byref(self._h), self.device, geom._h, int(rank), self.n,
                                               ctypes.c_void_p(int(refs_dev)), ctypes.c_void_p(int(gids_dev)),
                                               ctypes.c_void_p(stream)))
@@ -228,11 +232,16 @@ class KnnIndex:
     def seed_export(self, layer_dev, stream=0):
         _check(lib().knn_index_seed_export(self._h, ctypes.c_void_p(int(layer_dev)), ctypes.c_void_p(stream)))
 
-    def seed_attach(self, layer_dev):
+    def seed_attach(self, layer_dev, owner=None):
+        """The replicated seed layer (device pointer, borrowed until close(): `owner` keeps its memory alive)."""
         _check(lib().knn_index_seed_attach(self._h, ctypes.c_void_p(int(layer_dev))))
+        self._layer = owner
 
-    def __init__(self, k, refs, n_local=None, device=0, base_index=0, refs_on_device=False, stream=0):
+    def __init__(self, k, refs, n_local=None, device=0, base_index=0, refs_on_device=False, stream=0, owners=None):
+        """refs_on_device: `refs` is a device pointer the index BORROWS until close() (`owners`: what keeps it alive);
+        else host rows, copied."""
         self._h = ctypes.c_void_p()
+        self._layer = None
         self.k, self.device, self.base = int(k), int(device), int(base_index)
         if refs_on_device:
             if n_local is None:
@@ -250,7 +259,7 @@ class KnnIndex:
         self.n = int(n_local)
         _check(lib().knn_index_create(ctypes.byref(self._h), self.device, self.k, self.n, ptr,
                                       1 if refs_on_device else 0, self.base, ctypes.c_void_p(stream)))
-        self._keep = None
+        self._keep = owners if refs_on_device else None   # (host rows were copied: nothing to hold)
 
     def query_keys(self, m, queries_dev, keys_dev, stream=0, slot=0, init_keys=False, indices_dev=None):
         """Async: fold this shard's nearest (distance, global index) keys into keys_dev[m].
@@ -312,6 +321,7 @@ class KnnIndex:
         if self._h:
             lib().knn_index_destroy(self._h)
             self._h = ctypes.c_void_p()
+        self._keep = self._layer = None   # (the borrowed buffers may go now)
 
     def __del__(self):
         try:

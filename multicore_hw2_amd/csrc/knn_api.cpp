@@ -70,6 +70,7 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
+std::atomic<long long> g_opt_cells_lists{0};     // pruned scan, who lists a cell's queries: 0 auto, 1 the match launch, 2 the scan's own waves
 std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
 std::atomic<long long> g_opt_cells_build{0};     // cell-sorted layout: 0 two-pass build, 1 the one-pass placement (A/B, tests)
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
@@ -353,6 +354,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_cells_build = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "cells_lists")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: cells_lists must be 0 (auto), 1 (match launch) or 2 (the scan lists its own items)");
+        g_opt_cells_lists = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "scan_deal")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: scan_deal must be 0 (auto), 1 (fixed deal) or 2 (block counter)");
@@ -410,6 +417,8 @@ long long knn_get_option(const char *name)
         return g_opt_scan_blocks;
     if (name && !strcmp(name, "scan_deal"))
         return g_opt_scan_deal;
+    if (name && !strcmp(name, "cells_lists"))
+        return g_opt_cells_lists;
     if (name && !strcmp(name, "cells_build"))
         return g_opt_cells_build;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -864,6 +873,7 @@ int knn_index_query(knn_index *idx, int slot, int m, const float *queries_dev, u
         }
         idx->filter.scan_blocks = (int)g_opt_scan_blocks;
         idx->filter.scan_deal = (int)g_opt_scan_deal;
+        idx->filter.cells_lists = (int)g_opt_cells_lists;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys, indices_dev));
@@ -989,10 +999,15 @@ int knn_index_debug_counters(knn_index *idx, long long out[4])
 
 int knn_debug_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, int m, long long out[8])
 {
+    return knn_debug_scan_plan_ex(num_cu, blocks_per_cu, nitems, m, 0, out);
+}
+
+int knn_debug_scan_plan_ex(int num_cu, int blocks_per_cu, unsigned nitems, int m, int self_lists, long long out[8])
+{
     if (!out || num_cu < 1 || blocks_per_cu < 1 || blocks_per_cu > 2 || m < 1 || m > KNN_CELL_BATCH)
         return fail(KNN_EINVAL, "knn_debug_scan_plan: bad arguments");
     const int m_padded = (m + 31) / 32 * 32;
-    const CellScanPlan p = knn_cells_scan_plan(num_cu, blocks_per_cu, nitems, KNN_RECORD_CAPACITY, m_padded);
+    const CellScanPlan p = knn_cells_scan_plan(num_cu, blocks_per_cu, nitems, KNN_RECORD_CAPACITY, m_padded, self_lists != 0);
     out[0] = p.blocks;
     out[1] = p.nlists;
     out[2] = p.slice;
@@ -1332,6 +1347,18 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
     std::string rccl_why;
     const bool rccl_wanted = g_opt_rccl != 2 && shards == ndev && (g_opt_rccl == 1 || shards > 1);
     const bool use_rccl = rccl_wanted && knn_rccl_available(&rccl_why) != 0;
+    if (g_opt_rccl == 1 && shards > 1 && shards != ndev) {
+        // (`rccl` = 1 means "always, and die when RCCL cannot serve" — a call that the policy or option `shards`
+        // splits over another number of GPUs than are visible has no communicator set, and merging on the host in silence
+        // would break that contract)
+        char why[160];
+        snprintf(why, sizeof why, "%lld shards on %d visible GPU(s): the one communicator set of the process spans all visible devices", shards, ndev);
+        fail(KNN_EINVAL, "cudaCallback: option rccl = 1 but the call's shards are not the visible devices", why);
+        die(__FILE__, __LINE__, KNN_EINVAL, g_err.c_str());
+    }
+    if (trace && shards > 1 && !use_rccl)
+        fprintf(stderr, "[knn call] keys merged on the host: %s\n",
+                g_opt_rccl == 2 ? "option rccl = 2" : shards != ndev ? "the shards are not the visible devices" : rccl_why.c_str());
     if (rccl_wanted && !use_rccl && g_opt_rccl == 1) {
         fail(KNN_EHIP, "cudaCallback: option rccl = 1 but RCCL cannot be used", rccl_why.c_str());
         die(__FILE__, __LINE__, KNN_EHIP, g_err.c_str());

@@ -167,6 +167,17 @@ __device__ __forceinline__ f16v zero_acc()
     return (f16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 }
 
+// Before a block counts itself done on a counter another block's finaliser watches: every vector-memory operation of this
+// wave — the no-return global atomics on keys[] and ctl[] among them — has been performed.  `s_waitcnt vmcnt(0)` only
+// (0x0F70: expcnt and lgkmcnt left alone): gfx9 counts stores and no-return atomics in vmcnt and releases the count when the
+// memory side has acknowledged them; an agent-scope release fence would add `buffer_wbl2 sc1`, a write-back of the XCD's
+// whole L2 per wave (110 -> 261 us at C3, round 4), which atomics performed at the memory side do not need.
+__device__ __forceinline__ void cells_wait_own_atomics()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 // LDS written by some lanes of a wave, read by others of the SAME wave: order the two without a block barrier.
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -781,7 +792,8 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
     const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, SeedLayer layer, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
     float *__restrict__ hi_tab, float bmax, float nmax, float amax_limit, float *__restrict__ thr,
     float *__restrict__ dup_out, unsigned *__restrict__ ctl, unsigned *__restrict__ ctl_next,
-    unsigned *__restrict__ counts, unsigned nlists, u64 *__restrict__ keys_init)
+    unsigned *__restrict__ counts, unsigned nlists, u64 *__restrict__ keys_init,
+    int lo_by_entry)   // != 0: the low table as [entry][query] (what the self-listing scan reads: a cell's row is contiguous)
 {
 #pragma clang fp contract(off)
     constexpr int SEEDS = 1 << SD, NS = SEEDS / PW;   // seed cells in all, per wave
@@ -966,7 +978,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         const float v = __double2float_rd(sum);
         if (e < nl + nh) {
             if (low)
-                lo_tab[(size_t)qi * nl + e] = v;
+                lo_tab[lo_by_entry ? (size_t)e * m_padded + qi : (size_t)qi * nl + e] = v;
             else
                 hi_tab[(size_t)(e - nl) * m_padded + qi] = v;
         }
@@ -1150,7 +1162,9 @@ extern "C" int knn_debug_scan_stamps(unsigned long long *out)
 #define SCAN_STAMP(i) do { } while (0)
 #endif
 // K: 16 = compile-time dimension of the inline re-rank, 0 = run-time k <= 16
-template <bool DYN, int K>
+// SELF: the waves make the lists of their own items (cell_self_list, knn_exact_dev.h) — no match launch in front of the scan;
+//       cell_counts / lists are unused and `cap` is CELL_SELF_CAP
+template <bool DYN, int K, bool SELF>
 __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
@@ -1159,13 +1173,16 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     unsigned ovf_base, unsigned ovf_cap,
     // the exact re-rank of this wave's own records (v0 arithmetic on the fp32 rows, through perm) and the end of the batch
     const float *__restrict__ Q, const float *__restrict__ R, int krt, const unsigned *__restrict__ perm, long long npos,
-    long long base, u64 *__restrict__ keys, CellFinal fin)
+    long long base, u64 *__restrict__ keys, CellFinal fin, CellSelf self)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
     f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
+    // SELF: the batch's Dup values and one list room per wave behind the norm windows (knn_cells_scan_plan sizes it)
+    float *s_dup = (float *)(s_dyn + (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v));   // [m_padded]
+    unsigned short *s_lists = (unsigned short *)(s_dup + m_padded);     // [waves][CELL_SELF_CAP]
     __shared__ unsigned s_flag;
     SCAN_STAMP(0);
     if (threadIdx.x == 0)
@@ -1217,7 +1234,10 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             const u64 item = it != 0xFFFFFFFFu ? items[it] : 0ull;
             s_imeta[i] = (unsigned)(item >> 40);
             s_itb[i] = (unsigned)item;
-            s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;   // (a hole: nobody lists it)
+            if constexpr (SELF)
+                s_inq[i] = it != 0xFFFFFFFFu ? 1u : 0u;   // (the list is made when the item is taken)
+            else
+                s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;   // (a hole: nobody lists it)
         }
         if (threadIdx.x == 0)
             s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
@@ -1227,11 +1247,15 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
         s_qf[i] = qfg[i];
     for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
         s_thr[i] = thrg[i];
+    if constexpr (SELF)
+        for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
+            s_dup[i] = self.dup[i];
     __syncthreads();
     if (s_flag != 0u)
         return;
     SCAN_STAMP(1);
     f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
+    unsigned short *my_list = s_lists + (SELF ? wib * (int)CELL_SELF_CAP : 0);
 
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
     unsigned cnt = 0u;
@@ -1260,7 +1284,10 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                     const u64 item = it != 0xFFFFFFFFu ? items[it] : 0ull;
                     s_imeta[i] = (unsigned)(item >> 40);
                     s_itb[i] = (unsigned)item;
-                    s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;
+                    if constexpr (SELF)
+                        s_inq[i] = it != 0xFFFFFFFFu ? 1u : 0u;
+                    else
+                        s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;
                 }
                 if (threadIdx.x == 0)
                     s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
@@ -1284,11 +1311,27 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             const u64 item = in ? items[mine] : 0ull;
             v_meta = (unsigned)(item >> 40);   // cell << 8 | tiles
             v_tb = (unsigned)item;
-            v_nq = in ? cell_counts[v_meta >> 8] : 0u;
+            if constexpr (SELF)
+                v_nq = in ? 1u : 0u;   // (the list is made when the item is taken)
+            else
+                v_nq = in ? cell_counts[v_meta >> 8] : 0u;
         }
         for (u64 todo = __ballot(v_nq != 0u); todo != 0ull && !dead; todo &= todo - 1ull) {
             const int j = (int)__builtin_ctzll(todo);
-            unsigned nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
+            const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
+            const unsigned meta = (unsigned)__builtin_amdgcn_readlane((int)v_meta, j);
+            const unsigned te = tb + (meta & 0xFFu);
+            const unsigned cellj = meta >> 8;
+            unsigned nq;
+            if constexpr (SELF) {
+                __builtin_amdgcn_wave_barrier();   // the previous item's reads of the list room are done
+                nq = cell_self_list(self, cellj, m, s_dup, my_list, lane);
+                wave_lds_sync();
+                if (nq == 0u)   // (wave-uniform) nobody wants this cell
+                    continue;
+            } else {
+                nq = (unsigned)__builtin_amdgcn_readlane((int)v_nq, j);
+            }
             // a list longer than its room (a thousand copies of one query all want the same cells) is cut short by the
             // match kernel: the cell is then scored `dense`, against every query of the batch — what a list that long
             // asks for anyway — instead of sending the batch to the exact scan as round 2 did
@@ -1298,16 +1341,13 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                 if (lane == 0)
                     atomicAdd(&ctl[KNN_CTL_DENSE_CELLS], 1u);   // rare; statistics only
             }
-            const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)v_tb, j);
-            const unsigned meta = (unsigned)__builtin_amdgcn_readlane((int)v_meta, j);
-            const unsigned te = tb + (meta & 0xFFu);
-            const unsigned cellj = meta >> 8;
-            const unsigned short *__restrict__ list = lists + (size_t)cellj * cap;
+            const unsigned short *__restrict__ list = SELF ? my_list : lists + (size_t)cellj * cap;
             // the first two blocks of the list travel with the tiles (one round trip per cell)
-            const unsigned l0 = dense ? (unsigned)lane : (unsigned)list[min((unsigned)lane, nq - 1u)];
+            // (SELF: the list is in LDS — every block of 32 is read from there)
+            const unsigned l0 = SELF ? 0u : dense ? (unsigned)lane : (unsigned)list[min((unsigned)lane, nq - 1u)];
             // (round 3: blocks three and four of the list too — lists average 120 entries on the 2^21-row shards of an
             // 8-GPU run, and every block beyond the second was a dependent read from memory)
-            const unsigned l1 = dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
+            const unsigned l1 = SELF ? 0u : dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
             for (unsigned t0 = tb; t0 < te && !dead; t0 += CELL_TILES_PER_PASS) {
                 const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
                 h8 ar[CELL_TILES_PER_PASS];
@@ -1329,7 +1369,9 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                     const unsigned idx = q0 + (unsigned)col;
                     const bool valid = idx < nq;
                     unsigned qid;
-                    if (q0 < 64u) {
+                    if constexpr (SELF) {
+                        qid = dense ? (valid ? idx : 0u) : (unsigned)my_list[valid ? idx : 0u];
+                    } else if (q0 < 64u) {
                         const unsigned from = __shfl(l0, (int)idx, KNN_WAVE);
                         qid = valid ? from : __shfl(l0, 0, KNN_WAVE);
                     } else if (q0 < 128u) {
@@ -1463,11 +1505,13 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     // (records in the shared area, an over-full area, rows outside the box) — then the tail kernel does, which sees the
     // same two words and returns at once in the case handled here.
     // (What the finaliser reads from other blocks are words they changed with agent-scope ATOMICS — the keys, the record
-    // counter: those are performed at the memory side, no cache to write back.  Every wave waits for its own atomics to have
-    // been performed before the block counts itself done; the finaliser reads with agent-scope loads.)
+    // counter, the DEFERRED flag: those are performed at the memory side, no cache to write back.  Every wave waits for its
+    // own atomics to have been PERFORMED before the block counts itself done — cells_wait_own_atomics: the workgroup-scope
+    // release fence alone compiles to `s_waitcnt lgkmcnt(0)` on gfx950 and leaves the no-return atomics in flight (ADVICE
+    // r04; tests/test_host_logic.py reads the ISA for the vmcnt(0)) — and the finaliser reads with agent-scope loads.)
     __shared__ unsigned s_last;
     SCAN_STAMP(3);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    cells_wait_own_atomics();
     __syncthreads();
     if (threadIdx.x == 0)
         s_last = __hip_atomic_fetch_add(&ctl[KNN_CTL_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
@@ -1499,9 +1543,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
     const u64 *__restrict__ rec, unsigned ovf_base, unsigned ovf_cap, unsigned *__restrict__ ctl, u64 *__restrict__ keys,
     CellFinal fin,
     // the scan's record lists (counts[nlists], `slice` records each): lists longer than CELL_INLINE_RERANK_MAX are re-ranked here
-    const unsigned *__restrict__ counts, unsigned nlists, unsigned slice)
+    const unsigned *__restrict__ counts, unsigned nlists, unsigned slice,
+    CellSelf self)   // lo_t != null: the scan made its own lists; the exact evaluation of the listed pairs makes them again
 {
 #pragma clang fp contract(off)
+    __shared__ unsigned short s_tail_list[KNN_WAVES][CELL_SELF_CAP];
     const unsigned fb = ctl[KNN_CTL_FALLBACK], have = ctl[KNN_CTL_RECORDS];   // final: prep and the scan are complete
     const unsigned deferred = ctl[KNN_CTL_DEFERRED];
     if (!fin.defer && fb == 0u && have == 0u && deferred == 0u)
@@ -1519,7 +1565,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
             if (blockIdx.x == 0 && threadIdx.x == 0)
                 ctl[KNN_CTL_EXACT_CELLS] = 1u;   // (statistics: knn_index_last_stats[2] = 2)
             cells_exact_items<K>(Q, R, krt, m, base, items, nitems, cell_counts, lists, cap, perm, keys,
-                                 blockIdx.x * (unsigned)KNN_WAVES + (threadIdx.x >> 6), gridDim.x * (unsigned)KNN_WAVES);
+                                 blockIdx.x * (unsigned)KNN_WAVES + (threadIdx.x >> 6), gridDim.x * (unsigned)KNN_WAVES, self,
+                                 &s_tail_list[threadIdx.x >> 6][0]);
         } else {
           const int k = K > 0 ? K : krt;
           if (deferred != 0u) {   // the long lists the scan's waves left alone: a block per list, 16 lanes per record
@@ -1568,7 +1615,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
     if (!fin.gids && !fin.out_idx)
         return;
     __shared__ unsigned s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (as in the scan: this wave's atomics have been performed)
+    cells_wait_own_atomics();   // (as in the scan: this wave's atomics have been performed)
     __syncthreads();
     if (threadIdx.x == 0)
         s_last = __hip_atomic_fetch_add(&ctl[KNN_CTL_TAIL_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
@@ -2014,7 +2061,7 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
 //   slice    records [w x slice, (w + 1) x slice) belong to wave w
 //   ovf      records [ovf_base, ovf_base + ovf_cap) are the area all waves share; nlists x slice <= ovf_base
 //   lds      dynamic LDS of the scan: m_padded x (32 B operand + 4 B threshold) + one norm window per wave
-CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded)
+CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded, bool self_lists)
 {
     CellScanPlan p;
     p.blocks = (unsigned)num_cu * (unsigned)blocks_per_cu;
@@ -2029,7 +2076,20 @@ CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems,
     p.ovf_base = rec_cap - p.ovf_cap;
     p.slice = p.ovf_base / p.nlists;
     p.lds_bytes = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    if (self_lists)   // the self-listing scan: the batch's Dup values + one list room per wave
+        p.lds_bytes += (size_t)m_padded * sizeof(float) + (size_t)CELL_SCAN_WAVES * CELL_SELF_CAP * sizeof(unsigned short);
     return p;
+}
+
+// Who lists the queries of a cell (option `cells_lists` 0 = this policy, 1 = the match launch, 2 = the scan's own waves).
+// Measured (round 5, one MI355X, k 16, m 1024, uniform; profiles/r05_self_lists.txt): the self-listing scan saves the match
+// launch and a dependent round trip per item, and pays with 16 steps of table arithmetic per item inside the hot kernel.  One
+// batch at a time on a rank of 8 of C3 (2^13 cells): 0.0469 -> 0.0439 ms; with four batches in flight the match launch hides
+// behind the other batches and the longer scan does not: 0.0252 -> 0.0288 per step.  2^14 cells: 0.0599 -> 0.0616 / 0.0397 ->
+// 0.0433; C3: 0.1430 -> 0.1448 / 0.1176 -> 0.1280.
+bool knn_cells_lists_policy(unsigned ncells, bool several_slots)
+{
+    return !several_slots && ncells <= 8192u;
 }
 
 // One batch of <= KNN_CELL_BATCH queries, the whole chain: prep -> match -> scan (its waves re-rank their own records) ->
@@ -2054,7 +2114,10 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // (2^15 cells, n = 2^23: step 0.0795 -> 0.0777 with one, three runs each on one box; 2^16 cells, C3: 0.1237 -> 0.1223, not
     // worth the 8 % the launch itself gets longer)
     const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 32768u);
-    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded);
+    // Who makes the cells' lists of queries: knn_cells_match_kernel in a launch of its own (rounds 2-4), or the scan's waves
+    // for the items they take (round 5, cell_self_list).  Policy in knn_cells_lists_policy.
+    const bool self_lists = st.cells_lists == 2 || (st.cells_lists == 0 && knn_cells_lists_policy(c.ncells, st.several_slots));
+    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded, self_lists);
     const unsigned gx = plan.blocks;
     w.nlists = plan.nlists;
     w.ovf_cap = plan.ovf_cap;
@@ -2082,7 +2145,7 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     hipLaunchKernelGGL((knn_cells_prep_kernel<PWV, SDV>), dim3((unsigned)m_padded), dim3(64 * PWV), 0, s, q, m, m_padded, g, \
                        c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,            \
                        st.ref_norms2, layer, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr,    \
-                       w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init)
+                       w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init, self_lists ? 1 : 0)
     // (cell-range shards take the same four seed cells — those of another rank through the seed layer.  Sixteen seed cells
     // (SD = 4) leave 20 % fewer candidates, as the simulation said, and cost more than they save: the prep kernel is a chain
     // of dependent round trips, and at a rank's size the step is made of those — emulated rank of N = 8, ms per step / one
@@ -2094,15 +2157,27 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         KNN_PREP_LAUNCH(4, 2);
 #undef KNN_PREP_LAUNCH
     FTRY(hipGetLastError());
-    if (c.ncells <= 16384u)
+    if (self_lists) {
+        // no match launch: the scan's waves list their own items
+    } else if (c.ncells <= 16384u)
         hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
                            m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
     else
         hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
                            m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
     FTRY(hipGetLastError());
+    CellSelf self;
+    memset(&self, 0, sizeof self);
+    if (self_lists) {
+        self.lo_t = w.lo_tab;
+        self.hi = w.hi_tab;
+        self.dup = w.dup;
+        self.sa = c.sa;
+        self.m_padded = m_padded;
+    }
+    const unsigned list_cap = self_lists ? CELL_SELF_CAP : c.cap;
     static const bool trace_cells = getenv("KNN_MI355X_TRACE_CELLS") != nullptr;   // (read once: a query may run beside a thread that changes the environment)
-    if (trace_cells) {   // development aid: the lists of this batch and how evenly the scan's waves are loaded (synchronises)
+    if (trace_cells && !self_lists) {   // development aid: the lists of this batch and how evenly the scan's waves are loaded (synchronises)
         std::vector<unsigned> hc((size_t)c.ncells), ht((size_t)c.ncells + 1);
         FTRY(hipStreamSynchronize(s));
         FTRY(hipMemcpy(hc.data(), w.cell_counts, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -2144,22 +2219,30 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     fin.out_idx = out_idx;
     fin.defer = st.n_outliers != 0u ? 1 : 0;
     const long long npos = st.ntiles * 32;
-#define KNN_SCAN_LAUNCH(DYNV, KV)                                                                                          \
-    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, \
+#define KNN_SCAN_LAUNCH(DYNV, KV, SELFV)                                                                                   \
+    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV, SELFV>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, \
                        st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded, w.cell_counts,        \
-                       w.cell_lists, c.cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap, q, r, st.k,    \
-                       c.perm, npos, base, keys, fin)
+                       w.cell_lists, list_cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap, q, r, st.k, \
+                       c.perm, npos, base, keys, fin, self)
+#define KNN_SCAN_LAUNCH_K(DYNV, SELFV)                                                                                     \
+    do {                                                                                                                   \
+        if (st.k == 16)                                                                                                    \
+            KNN_SCAN_LAUNCH(DYNV, 16, SELFV);                                                                              \
+        else                                                                                                               \
+            KNN_SCAN_LAUNCH(DYNV, 0, SELFV);                                                                               \
+    } while (0)
     if (dyn) {
-        if (st.k == 16)
-            KNN_SCAN_LAUNCH(true, 16);
+        if (self_lists)
+            KNN_SCAN_LAUNCH_K(true, true);
         else
-            KNN_SCAN_LAUNCH(true, 0);
+            KNN_SCAN_LAUNCH_K(true, false);
     } else {
-        if (st.k == 16)
-            KNN_SCAN_LAUNCH(false, 16);
+        if (self_lists)
+            KNN_SCAN_LAUNCH_K(false, true);
         else
-            KNN_SCAN_LAUNCH(false, 0);
+            KNN_SCAN_LAUNCH_K(false, false);
     }
+#undef KNN_SCAN_LAUNCH_K
 #undef KNN_SCAN_LAUNCH
     FTRY(hipGetLastError());
     if (timed && w.ev_end)
@@ -2175,8 +2258,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
             blocks = std::max(2u, (c.nitems + KNN_WAVES - 1u) / KNN_WAVES);
 #define KNN_TAIL_LAUNCH(KV)                                                                                                \
     hipLaunchKernelGGL(knn_cells_tail_kernel<KV>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, st.n, npos, base, c.items,  \
-                       c.nitems, w.cell_counts, w.cell_lists, c.cap, c.perm, w.records, w.ovf_base, w.ovf_cap, w.ctl_cur,   \
-                       keys, fin, w.counts, w.nlists, w.slice)
+                       c.nitems, w.cell_counts, w.cell_lists, list_cap, c.perm, w.records, w.ovf_base, w.ovf_cap, w.ctl_cur, \
+                       keys, fin, w.counts, w.nlists, w.slice, self)
         switch (st.k) {
         case 16: KNN_TAIL_LAUNCH(16); break;
         case 8: KNN_TAIL_LAUNCH(8); break;

@@ -213,6 +213,7 @@ struct FilterState {
     bool several_slots = false;   // a query has used a workspace slot other than 0: batches are in flight side by side
     int scan_deal = 0;            // pruned scan: 0 auto (block counter unless several_slots), 1 fixed deal, 2 items from a block counter
     int scan_blocks = 0;          // pruned scan, blocks per CU: 0 auto (one for small shards when several_slots, else two), 1, 2
+    int cells_lists = 0;          // pruned scan, who lists a cell's queries: 0 auto, 1 knn_cells_match_kernel, 2 the scan's own waves
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run
     // 15 % slower than back to back; only the small preparation kernels are meant to overlap.
@@ -238,7 +239,9 @@ struct CellScanPlan {
     unsigned blocks = 0, nlists = 0, slice = 0, ovf_base = 0, ovf_cap = 0;
     size_t lds_bytes = 0;
 };
-CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded);
+CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded,
+                                 bool self_lists = false);
+bool knn_cells_lists_policy(unsigned ncells, bool several_slots);
 hipError_t knn_cells_place_rows(FilterState &st, const float *r_dev, const unsigned *code, unsigned *fill, unsigned *out,
                                 unsigned ocap, hipStream_t s);
 void knn_cells_free(CellIndex *&c);

@@ -200,12 +200,67 @@ __device__ __forceinline__ void exact_qreg_body(const float *__restrict__ Q, con
 // when it finds the shared overflow area over-full.  K > 0: compile-time dimension; 0: run-time k <= 16.
 // ------------------------------------------------------------------------------------------
 #define CX_ROWS 4
+
+// ---- the self-listing scan (round 5) -------------------------------------------------------------------------------
+// A cell's list of queries — those of the batch that cannot rule the cell out — made by the wave that is about to score
+// the cell instead of by a match launch in front of the scan: knn_cells_match_kernel's test with the same arithmetic
+// (fl32(lo + hi) against Dup; lo, hi rounded down and Dup up with slack by the prep kernel) over ALL queries of the batch,
+// 64 per step on the lanes, survivors compacted into the wave's own LDS room in query order.  The pruning tables come
+// from the L2: a cell's row of the low table is contiguous (prep's `lo_by_entry` layout: [entry][query]) like its row of the
+// high table, 2 x 4 KiB per cell at 1024 queries.  Saves the match launch (9 us at 2^13 cells, 18 at 2^16, one batch at a
+// time), its lists' trip through memory and one dependent round trip per item (list length -> tiles).
+#define CELL_SELF_CAP 256u     // list entries a wave's LDS room holds (with the Dup values the scan stays within 64 KiB of dynamic LDS at 1024 queries); a longer list: the cell is scored dense (every query)
+#define CELL_SELF_GROUP 8      // steps of 64 queries whose table entries are in flight together (16 registers)
+struct CellSelf {
+    const float *lo_t;   // device [2^sa][m_padded]; null: the lists were made by knn_cells_match_kernel
+    const float *hi;     // device [high entries][m_padded]
+    const float *dup;    // device [m_padded]
+    int sa, m_padded;
+};
+
+// -> the list's length; entries beyond CELL_SELF_CAP are counted, not stored.  `dupv`: the batch's Dup values (LDS in the
+// scan, global memory in the tail kernel).  The caller orders the LDS writes against its reads (wave_lds_sync in knn_cells.hip).
+__device__ __forceinline__ unsigned cell_self_list(const CellSelf &sf, unsigned cell, int m, const float *__restrict__ dupv,
+                                                   unsigned short *__restrict__ my_list, int lane)
+{
+    const float *__restrict__ lrow = sf.lo_t + (size_t)(cell & ((1u << sf.sa) - 1u)) * sf.m_padded;
+    const float *__restrict__ hrow = sf.hi + (size_t)(cell >> sf.sa) * sf.m_padded;
+    unsigned nq = 0u;
+    for (int q0 = 0; q0 < m; q0 += 64 * CELL_SELF_GROUP) {   // (wave-uniform)
+        float lo[CELL_SELF_GROUP], hi[CELL_SELF_GROUP];
+#pragma unroll
+        for (int u = 0; u < CELL_SELF_GROUP; ++u) {
+            const int q = q0 + 64 * u + lane;
+            lo[u] = q < m ? lrow[q] : 0.0f;
+            hi[u] = q < m ? hrow[q] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < CELL_SELF_GROUP; ++u) {
+            const int q = q0 + 64 * u + lane;
+            if (q0 + 64 * u < m) {   // (wave-uniform)
+                const float lb = lo[u] + hi[u];
+                const bool pass = q < m && !(lb > dupv[q < m ? q : 0]);   // (a NaN keeps the cell, as in the match kernel)
+                const u64 mask = __ballot(pass);
+                if (mask != 0ull) {   // (wave-uniform)
+                    const unsigned pos = nq + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (pass && pos < CELL_SELF_CAP)
+                        my_list[pos] = (unsigned short)q;
+                    nq += (unsigned)__popcll(mask);
+                }
+            }
+        }
+    }
+    return nq;
+}
+
+// self.lo_t != null: the batch's lists are not in memory (the scan made its own) — this wave makes the list of every item it
+// takes the same way, in `my_list` (CELL_SELF_CAP entries of LDS per wave); cell_counts / lists are then unused.
 template <int K>
 __device__ __forceinline__ void cells_exact_items(
     const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long base,
     const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
     const unsigned short *__restrict__ lists, unsigned cap, const unsigned *__restrict__ perm,
-    u64 *__restrict__ keys, unsigned wave, unsigned nwaves)
+    u64 *__restrict__ keys, unsigned wave, unsigned nwaves, const CellSelf &self, unsigned short *__restrict__ my_list)
 {
 #pragma clang fp contract(off)
     constexpr int KD = K > 0 ? K : 16;
@@ -216,13 +271,24 @@ __device__ __forceinline__ void cells_exact_items(
         const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item >> 48));
         const unsigned tb = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item & 0xFFFFFFFFull));
         const unsigned nt = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(item >> 40) & 0xFFu));
-        unsigned nq = (unsigned)__builtin_amdgcn_readfirstlane((int)cell_counts[cell]);
+        unsigned nq;
+        const unsigned short *__restrict__ list;
+        if (self.lo_t) {   // (kernel-uniform)
+            __builtin_amdgcn_wave_barrier();   // the previous item's reads of the list are done
+            nq = cell_self_list(self, cell, m, self.dup, my_list, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            list = my_list;
+        } else {
+            nq = (unsigned)__builtin_amdgcn_readfirstlane((int)cell_counts[cell]);
+            list = lists + (size_t)cell * cap;
+        }
         if (nq == 0u)
             continue;
         const bool dense = nq > cap;   // the list was cut short: every query of the batch (as in the MFMA scan)
         if (dense)
             nq = (unsigned)m;
-        const unsigned short *__restrict__ list = lists + (size_t)cell * cap;
         const unsigned p_end = (tb + nt) * 32u;
         for (unsigned p0 = tb * 32u; p0 < p_end; p0 += 64u * CX_ROWS) {
             float rv[CX_ROWS][KD];

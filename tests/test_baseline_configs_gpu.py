@@ -161,3 +161,21 @@ def test_two_rank_bench_flow_rehearsed_on_one_gpu(shard):
         assert "cell ranges of one global grid of 2^13 cells" in doc["config"]["shards"]["partition"]
     assert "all_reduce(min)" in doc["config"]["collective"]
     assert doc["parity_spot_check"].startswith("8/8 sampled queries identical")
+
+
+def test_two_rank_flow_falls_back_to_index_ranges_when_one_rank_fails_before_the_exchange():
+    """the guarded fallback from cell-range to index-range shards must work when ONE rank fails — its peers
+    must not already be waiting in the all-to-all.  The partition's local phase (owner of every row, sort by destination)
+    is agreed on with a MIN all-reduce BEFORE any rank enters the all-to-alls; a rank that fails there (test hook) takes
+    every rank to the index-range shards it already holds, and the run ends with the same answers."""
+    env = dict(os.environ, KNN_BENCH_REHEARSE_ON_ONE_GPU="1", KNN_BENCH_TEST_PARTITION_FAIL_RANK="1")
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KNN_BENCH_FORCE_DIST"):
+        env.pop(name, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "16,1024,2097152",
+                        "--steps", "8", "--warmup", "2", "--cpu-queries", "8"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    doc = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "index ranges" in doc["config"]["shards"] and doc["config"]["n_per_gpu"] == 1 << 20
+    assert "index-range shards instead" in r.stderr
+    assert doc["parity_spot_check"].startswith("8/8 sampled queries identical")

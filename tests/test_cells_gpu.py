@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells", "scan_deal", "cells_build"):
+    for name in ("path", "shards", "cells", "scan_deal", "cells_build", "cells_lists"):
         pkg.set_option(name, 0)
 
 
@@ -436,3 +436,59 @@ def test_one_pass_placement_still_builds_a_correct_layout(oracle, k, dist, n):
         pkg.set_option("cells_build", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"{dist} k={k} stats={st}")
     assert st[0] == 4, st
+
+
+@pytest.mark.parametrize("deal", [1, 2], ids=["fixed_deal", "block_counter"])
+@pytest.mark.parametrize("lists", [1, 2], ids=["match_launch", "self_listing_scan"])
+@pytest.mark.parametrize("k,dist,n,m", [(16, "uniform", (1 << 18) + 5, 1024), (16, "uniform", 1 << 21, 1000), (16, "clustered", 1 << 17, 900),
+                                        (8, "lattice", (1 << 17) + 99, 333), (12, "copies", (1 << 17) + 7, 1024), (16, "tight_clusters", 1 << 22, 1024),
+                                        (16, "low_rank", 1 << 19, 700), (5, "queries_outside", 1 << 18, 64), (16, "one_point", 1 << 19, 1024)])
+def test_both_makers_of_the_cells_query_lists_are_bit_exact(oracle, lists, deal, k, dist, n, m):
+    """Round 5: `cells_lists` 1 = knn_cells_match_kernel writes every cell's list of queries in a launch of its own (rounds
+    2-4), 2 = the scan's waves list the items they take (cell_self_list: same test, same arithmetic, lists in LDS, no match
+    launch).  Both must give v0's answers for both ways of dealing the items — on the batch that overflows into the exact
+    evaluation of its listed pairs (tight clusters: the tail kernel makes the lists again), on cells whose lists outgrow a
+    wave's room (one point: dense), on ties (lattice, copies) and with fewer queries than a step of 64."""
+    rng = np.random.default_rng(k * 7 + deal + 3 * lists + len(dist))
+    Q, R = _off_the_cube(rng, dist, k, m, n) if dist in ("tight_clusters", "low_rank", "one_point") else _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("scan_deal", deal)
+    pkg.set_option("cells_lists", lists)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        again, st2 = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("scan_deal", 0)
+        pkg.set_option("cells_lists", 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"lists {lists} deal {deal} {dist} k={k} stats={st}")
+    np.testing.assert_array_equal(again, got)
+    assert st[0] == 4 and st[2] in (0, 2), st
+    if dist == "tight_clusters":     # (64 clusters of 2^16 rows: more candidates than the record buffers hold)
+        assert st[2] == 2, st        # the exact evaluation of the listed pairs ran (with the lists either maker gives)
+
+
+@pytest.mark.parametrize("lists", [1, 2], ids=["match_launch", "self_listing_scan"])
+def test_c3_full_shape_with_either_list_maker(oracle, lists):
+    """C3 (k = 16, m = 1024, n = 2^24), every query against the oracle, with the list maker forced (the policy picks one of
+    the two by the shard's cell count: both must be right at the metric's shape)."""
+    k, m, n = 16, 1024, 1 << 24
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
+    pkg.synth_fill_device(r_d.data_ptr(), n * k, 1001, device=0, stream=stream)
+    torch.cuda.synchronize()
+    Q = oracle.synth(m * k, 1000).reshape(m, k)
+    pkg.set_option("cells_lists", lists)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True, stream=stream)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells_lists", 0)
+    assert st[0] == 4 and st[2] == 0, st
+    want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
+    np.testing.assert_array_equal(got, want)

@@ -138,6 +138,12 @@ def test_scan_launch_sizes_fit_the_buffers_the_kernels_index(m, cells_log2, bloc
         assert p["lds_bytes"] == m_padded * 36 + CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * 16
         assert p["lds_bytes"] + 4 * (3 * 256 + 8) <= DEFAULT_DYNAMIC_LDS_LIMIT   # + the kernel's static tables
         assert p["lds_bytes"] % 16 == 0 and (m_padded * 36) % 16 == 0     # the window is read with ds_read_b128
+        # the self-listing scan (round 5): + the batch's Dup values and one list room of 256 entries per wave; two blocks of it
+        # must still fit a CU's 160 KiB beside each other
+        ps = pkg.debug_scan_plan(num_cu, blocks_per_cu, nitems, m, self_lists=True)
+        assert ps["lds_bytes"] == p["lds_bytes"] + m_padded * 4 + CELL_SCAN_WAVES * 256 * 2
+        assert {k_: v for k_, v in ps.items() if k_ != "lds_bytes"} == {k_: v for k_, v in p.items() if k_ != "lds_bytes"}
+        assert ps["lds_bytes"] + 4 * (3 * 256 + 8) <= DEFAULT_DYNAMIC_LDS_LIMIT and 2 * (ps["lds_bytes"] + 4 * (3 * 256 + 8)) <= 160 * 1024
 
 
 def test_scan_plan_refuses_batches_longer_than_one_pass():

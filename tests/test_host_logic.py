@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: partitioning, ABI surface, build hygiene, N>1 reduce."""
 import ctypes
+import json
 import os
 import re
 import shutil
@@ -76,7 +77,7 @@ def test_option_hooks_reject_unknown_names():
     with pytest.raises(pkg.KnnError):
         pkg.set_option("cells", 3)
     # round 3's switches: every legal value round-trips, the first illegal one is refused
-    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_build", (1, 0))):
+    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_build", (1, 0)), ("cells_lists", (1, 2, 0))):
         for v in legal:
             pkg.set_option(name, v)
             assert pkg.get_option(name) == v, name
@@ -150,6 +151,28 @@ def test_hot_kernels_of_the_pruned_path_use_no_scratch_memory(tmp_path):
             assert vgprs <= 80, (name, vgprs)       # six waves per SIMD: 512 / 6 rounded down to the allocation granule
         seen += 1
     assert seen >= 10, seen
+    # a block counts itself done (ctl[SCAN_DONE] = word 9 in the scan, ctl[TAIL_DONE] = word 10 in the tail
+    # kernel) only after every wave's own atomics on keys[] / ctl[] have been performed: the barrier in front of the counter's
+    # add is preceded by `s_waitcnt vmcnt(0)` with no vector-memory instruction in between.  (The workgroup-scope release fence
+    # alone compiled to `s_waitcnt lgkmcnt(0)`.)
+    checked = 0
+    for name, body in re.findall(r"^(_Z\w*knn_cells_(?:scan|tail)_kernel\w*):(.*?)^\.Lfunc_end", asm.read_text(), flags=re.S | re.M):
+        off = 36 if "scan" in name else 40
+        lines = body.splitlines()
+        adds = [i for i, ln in enumerate(lines) if re.search(r"global_atomic_add\b.*offset:%d sc0" % off, ln)]
+        assert adds, name
+        for at in adds:
+            bar = max(i for i in range(at) if "s_barrier" in lines[i])
+            waited = False
+            for ln in reversed(lines[:bar]):
+                ln = ln.split(";")[0].strip()
+                if not ln or ln.endswith(":") or ln.startswith("s_or_b64 exec") or ln.startswith("v_cmp"):
+                    continue
+                waited = ln.startswith("s_waitcnt") and "vmcnt(0)" in ln
+                break
+            assert waited, (name, lines[max(0, bar - 4):bar + 1])
+            checked += 1
+    assert checked >= 7, checked
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
@@ -467,3 +490,66 @@ def test_rccl_entry_point_validates_its_arguments_without_a_gpu():
         pkg.set_option("rccl", 3)
     with pytest.raises(pkg.KnnError):
         pkg.set_option("ingest", 2)
+
+
+# ---- bench.py's roofline block (a committed frac of 2.95 and one above the reader ceiling) --------------
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _write_pmc(tmp_path, name, key, sha, scan_bytes):
+    doc = {"workload_key": key, "kernel_source_sha256": sha,
+           "kernels": {"_Z21knn_cells_scan_kernelILb1ELi16EEvPK": {"hbm_bytes_per_launch": scan_bytes}}}
+    (tmp_path / name).write_text(json.dumps(doc))
+
+
+def test_roofline_quotes_pmc_bytes_only_for_the_workload_they_were_taken_on(tmp_path):
+    b = _bench_module()
+    whole = b.pmc_workload_key(16, 1024, 1 << 24, "index", 0, 0, 1)
+    rank3 = b.pmc_workload_key(16, 1024, 2093056, "cells", 8, 3, 1)
+    assert whole != rank3 and "rank3of8" in rank3 and "whole" in whole
+    assert b.pmc_workload_key(16, 1024, 1 << 21, "index", 0, 0, 8) != b.pmc_workload_key(16, 1024, 1 << 21, "index", 0, 0, 1)
+    _write_pmc(tmp_path, "r05_c3_pmc_traffic.json", whole, "sha-now", 659.2e6)
+    common = dict(k=16, m=1024, path_taken=4, kern_ms=0.11 * 8, launches=8, alone_n=20, event_pair_ms=0.0046,
+                  serial_step_ms=0.145, source_sha="sha-now", profiles_dir=str(tmp_path))
+    # the whole set: the PMC bytes are quoted, 659.2 MB / 0.1086 ms = 0.759 of 8 TB/s
+    r = b.roofline_block(n_local=1 << 24, alone_ms=0.1086 * 20, ms_per_step=0.1241, pmc_key=whole, **common)
+    assert r["bytes_source"] == "PMC (traffic)" and abs(r["frac"] - 0.7587) < 2e-3 and r["traffic"] == 659.2e6
+    # an emulated rank of eight must NOT get the whole set's bytes (round 4: 659 MB / 0.028 ms = 2.95 "of peak")
+    r = b.roofline_block(n_local=2093056, alone_ms=0.0279 * 20, ms_per_step=0.0262, pmc_key=rank3, **common)
+    assert r["traffic"] is None and r["bytes_source"].startswith("layout size")
+    assert r["frac"] is not None and r["frac"] < 0.5
+    assert "no PMC pass" in r["traffic_source"]
+    # the same file taken on other kernel sources: named, not used
+    r = b.roofline_block(n_local=1 << 24, alone_ms=0.1086 * 20, ms_per_step=0.1241, pmc_key=whole,
+                         **dict(common, source_sha="sha-later"))
+    assert r["traffic"] is None and "another build" in r["traffic_source"]
+
+
+def test_roofline_never_prints_a_fraction_the_wires_cannot_carry(tmp_path):
+    b = _bench_module()
+    common = dict(k=16, m=1024, path_taken=4, kern_ms=1.0, launches=8, alone_n=20, event_pair_ms=0.0046, serial_step_ms=0.8,
+                  source_sha="sha-now", profiles_dir=str(tmp_path))
+    # C4 on one GPU, round 4: the layout model (36 B x 2^27 x 1.04) over 0.725 ms = 6.93 TB/s, above what a bare reader gets
+    key = b.pmc_workload_key(16, 1024, 1 << 27, "index", 0, 0, 1)
+    r = b.roofline_block(n_local=1 << 27, alone_ms=0.725 * 20, ms_per_step=0.737, pmc_key=key, **common)
+    assert r["frac"] is None and r["achieved"] is None and "frac_minus_event_pair" not in r
+    assert "PMC pass" in r["frac_withheld"] and key in r["frac_withheld"]
+    # PMC bytes that would read above the PEAK (a file matched by mistake, a wrong duration): withheld as well
+    _write_pmc(tmp_path, "r05_x_pmc_traffic.json", key, "sha-now", 9.0e9)
+    r = b.roofline_block(n_local=1 << 27, alone_ms=0.725 * 20, ms_per_step=0.737, pmc_key=key, **common)
+    assert r["frac"] is None and "frac_withheld" in r
+    # every printed fraction over a sweep of durations stays <= 1 (and <= 6.5 / 8 on the byte model)
+    for ms in (0.01, 0.03, 0.06, 0.09, 0.12, 0.5):
+        for n_local in (1 << 21, 1 << 24):
+            r = b.roofline_block(n_local=n_local, alone_ms=ms * 20, ms_per_step=ms, pmc_key="nothing", **common)
+            for name in ("frac", "frac_minus_event_pair"):
+                assert r.get(name) is None or r[name] <= 6.5 / 8 + 1e-9, (ms, n_local, name, r[name])
+    # the MFMA and exact branches: a fraction above 1 is withheld too
+    r = b.roofline_block(n_local=65536, alone_ms=0.0001 * 20, ms_per_step=0.001, pmc_key="nothing",
+                         **dict(common, k=128, m=65536, path_taken=2))
+    assert r["frac"] is None and "frac_withheld" in r

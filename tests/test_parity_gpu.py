@@ -10,6 +10,8 @@ import multicore_hw2_amd as pkg
 from tests.oracle_lib import TA_SAMPLES
 from tests.test_oracle import read_golden_indices
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 THREADS = min(16, os.cpu_count() or 1)
 
@@ -1051,3 +1053,25 @@ def test_one_index_driven_from_several_host_threads(oracle):
         th.join()
     ix.close()
     assert not errors, errors
+
+
+def test_rccl_always_refuses_a_call_whose_shards_are_not_the_visible_devices():
+    """option rccl = 1 is documented as "always; the call dies when RCCL cannot serve".  A call split over another
+    number of GPUs than are visible (option `shards`, or the policy picking fewer) has no communicator set: round 4 merged it
+    on the host in silence.  Now it prints the reference's error line and exits 1 (child process: the entry point exit()s)."""
+    import subprocess
+    import sys
+    child = (
+        "import sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import multicore_hw2_amd as pkg\n"
+        "pkg.set_option('rccl', 1)\n"
+        "pkg.set_option('shards', pkg.device_count() + 2)\n"
+        "rng = np.random.default_rng(1)\n"
+        "Q, R = rng.random(16 * 8, dtype=np.float32), rng.random(16 * 4000, dtype=np.float32)\n"
+        "pkg.cudaCallback(16, 8, 4000, Q, R)\n"
+        "print('returned')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "returned" not in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-300:])
+    assert "rccl = 1 but the call's shards are not the visible devices" in r.stdout, r.stdout[-500:]

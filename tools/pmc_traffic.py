@@ -4,7 +4,11 @@ profiles/<tag>_pmc_traffic.json.  HBM bytes per launch follow MI355X_MICROARCH.m
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced
 streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B stores.
 
-usage: pmc_traffic.py <tag> <fetch_dir> <write_dir> [<l2_dir>]
+usage: pmc_traffic.py <tag> <fetch_dir> <write_dir> [<l2_dir>] [--key KEY | --bench-json FILE] [--cmd "bench.py ..."]
+
+KEY = the workload key bench.py prints as roofline.pmc_key (shape of the rank's shard, shard mode, rank of N): bench.py quotes
+a traffic file only for a run with the same key and the same kernel sources (round 4 quoted the whole-set C3 file for an
+emulated rank of eight).  --bench-json: the JSON line one of the passes printed; the key is read from it.
 """
 import csv
 import glob
@@ -25,8 +29,22 @@ def load(dirname):
 
 
 def main():
-    tag, fetch_dir, write_dir = sys.argv[1:4]
-    l2_dir = sys.argv[4] if len(sys.argv) > 4 else None
+    argv = list(sys.argv[1:])
+    key, cmd = None, "bench.py --steps 5 --warmup 1 --cpu-queries 0"
+    for flag in ("--key", "--bench-json", "--cmd"):
+        if flag in argv:
+            at = argv.index(flag)
+            val = argv[at + 1]
+            del argv[at:at + 2]
+            if flag == "--key":
+                key = val
+            elif flag == "--cmd":
+                cmd = val
+            else:
+                with open(val) as f:
+                    key = json.loads([ln for ln in f if ln.lstrip().startswith("{")][-1])["roofline"]["pmc_key"]
+    tag, fetch_dir, write_dir = argv[0:3]
+    l2_dir = argv[3] if len(argv) > 3 else None
     fetch, write = load(fetch_dir), load(write_dir)
     l2 = load(l2_dir) if l2_dir else {}
     out = {}
@@ -56,7 +74,8 @@ def main():
             h.update(f.read())
     with open(path, "w") as fo:
         json.dump({"note": "rocprofv3 --pmc, separate passes; read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 correction, "
-                           "MI355X_MICROARCH.md HBM section); command: bench.py --steps 5 --warmup 1 --cpu-queries 0",
+                           "MI355X_MICROARCH.md HBM section); command: " + cmd,
+                   "workload_key": key,
                    "kernel_source_sha256": h.hexdigest(),
                    "kernels": out}, fo, indent=1)
     for k, v in out.items():
