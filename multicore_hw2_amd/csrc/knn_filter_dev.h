@@ -88,7 +88,14 @@ __host__ __device__ inline BoundConsts knn_bound_consts(int k, int kt, double si
     BoundConsts c;
     c.eta2 = k * emax * emax;
     c.eta = sqrt(c.eta2);
-    const double omega = kt * 0x1p-18;                // MFMA internal accumulation, per chained K-step (assumed bound)
+    // MFMA internal accumulation of one score, relative to the sum of the magnitudes it adds (norm + k products), per chained
+    // K-step.  The matrix core's adder tree is not documented, so kt 2^-18 is an allowance, not a derivation; it is pinned by
+    // MEASURED WORST CASES on gfx950 (tests/test_parity_gpu.py::test_mfma_accumulation_error_on_adversarial_operands, round 5:
+    // operands exactly representable in fp16, float64 reference exact): one product per K-step 2^10 times the others
+    // 2^-22.6 (kt 1) .. 2^-20.0 (kt 256); fp16-subnormal operands 2^-21.9 (kt 1: they are NOT flushed); magnitudes 2^0..2^-12
+    // mixed 2^-22.9 (kt 1) .. 2^-19.9 (kt 256); alternating +P, -P products: exact; gaussian data <= 2^-20 (kt <= 64).
+    // The worst of all, 2^-19.9 at k = 4096, is 2^9.9 inside its allowance (2^-10); at kt = 1 the margin is 2^3.9.
+    const double omega = kt * 0x1p-18;
     c.gam = (kp + 2.0) * u;
     const double mmax = kp * amax * amax;
     c.rho = (omega + 2.0 * c.gam) * 2.0 * (nmax + mmax) + kp * 0x1p-27;

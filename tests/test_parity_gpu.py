@@ -496,6 +496,89 @@ def test_mfma_accumulation_error_is_far_inside_the_assumed_allowance(k):
     assert rel <= 2.0 ** -20, rel   # in practice about one fp32 rounding per 16-wide K-step
 
 
+def _kt_of(k):
+    return 1 if k <= 16 else 2 if k <= 32 else 4 if k <= 64 else 8 if k <= 128 else 16 if k <= 256 else 32 if k <= 512 else 8 * ((k + 127) // 128)
+
+
+OMEGA_CASES = ["alternating", "one_large_term", "subnormal_operands", "mixed_magnitudes"]
+OMEGA_WORST = {}
+
+
+@pytest.mark.parametrize("k", [16, 40, 128, 512, 1024, 4096])
+@pytest.mark.parametrize("case", OMEGA_CASES)
+def test_mfma_accumulation_error_on_adversarial_operands(case, k):
+    """omega = kt * 2^-18 (knn_filter_dev.h) bounds the matrix core's internal accumulation of one score,
+    relative to the sum of the magnitudes of what it adds (the norm and the k products).  The gaussian test above cannot see a
+    worst case; these operands are built for one, every fp16 value exactly representable so that the float64 reference is
+    exact:
+      alternating        every row is one value in all dimensions, every query the same with alternating sign: the k products
+                         of a pair are +P, -P, +P, ... — total cancellation against k P of magnitude
+      one_large_term     dimension 0 of every 16-wide K-step spans [-1, 1], the other fifteen [-2^-5, 2^-5]: one product per
+                         step is 2^10 times the others (alignment shifts in the adder tree)
+      subnormal_operands the other fifteen dimensions span 2^-15: their fp16 operands are subnormal (a core that flushes them
+                         loses those products entirely)
+      mixed_magnitudes   magnitudes 2^0 .. 2^-12 cycling over the dimensions with random signs
+    The assertion is the bound the threshold derivation uses; the worst figure seen goes into knn_filter_dev.h's comment."""
+    rng = np.random.default_rng(k * 31 + len(case))
+    m, n = (64, 2048) if k <= 1024 else (16, 512)
+    grid = lambda size: (rng.integers(-512, 513, size) / 512.0).astype(np.float32)     # multiples of 2^-9 in [-1, 1]
+    d = np.arange(k)
+    if case == "alternating":
+        R = np.repeat(grid((n, 1)), k, axis=1)
+        Q = np.repeat(grid((m, 1)), k, axis=1) * np.where(d % 2 == 0, 1.0, -1.0).astype(np.float32)
+        scale = np.ones(k, dtype=np.float32)
+    else:
+        if case == "one_large_term":
+            scale = np.where(d % 16 == 0, 1.0, 2.0 ** -5).astype(np.float32)
+        elif case == "subnormal_operands":
+            scale = np.where(d % 16 == 0, 1.0, 2.0 ** -15).astype(np.float32)
+        else:
+            scale = (2.0 ** -(d % 13).astype(np.float64)).astype(np.float32)
+        R = grid((n, k)) * scale
+        Q = grid((m, k)) * scale
+    R[0], R[1] = -scale, scale                           # the range of every dimension is symmetric: the centre is 0 exactly
+    R, Q = np.ascontiguousarray(R, dtype=np.float32), np.ascontiguousarray(Q, dtype=np.float32)
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    pkg.set_option("path", 2)
+    try:
+        ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+    finally:
+        pkg.set_option("path", 0)
+    scores = torch.empty((m, n), dtype=torch.float32, device=dev)
+    qn = torch.empty(m, dtype=torch.float32, device=dev)
+    sigma = np.float32(ix.debug_filter_scores(m, q_d.data_ptr(), scores.data_ptr(), qn.data_ptr())[0])
+    torch.cuda.synchronize()
+    ix.close()
+    lo, hi = R.min(axis=0), R.max(axis=0)
+    c = (np.float32(0.5) * lo + np.float32(0.5) * hi).astype(np.float32)
+    assert (c == 0).all() and sigma == np.float32(0.5), (sigma, np.abs(c).max())   # box [-1, 1]: scale 2^-1
+    b32 = ((R - c) * sigma).astype(np.float32)
+    b = b32.astype(np.float16)
+    a32 = ((Q - c) * sigma).astype(np.float32)
+    a2 = (a32.astype(np.float16).astype(np.float32) * np.float32(-2)).astype(np.float16)
+    if case != "subnormal_operands":                     # every operand exactly representable (else: the nearest subnormal)
+        assert (b.astype(np.float32) == b32).all() and (a2.astype(np.float32) == a32 * np.float32(-2)).all()
+    else:
+        tiny = np.abs(b.astype(np.float32)) < 2.0 ** -14
+        assert tiny[:, d % 16 != 0].all() and (b != 0).any()
+    bn = b.astype(np.float32)
+    N = np.zeros(n, dtype=np.float32)
+    for dd in range(k):
+        N = (N + bn[:, dd] * bn[:, dd]).astype(np.float32)
+    A, B = a2.astype(np.float64), b.astype(np.float64)
+    exact = N.astype(np.float64)[None, :] + A @ B.T      # (products of fp16 values are exact in float64; the float64 sums of
+    mag = np.abs(N.astype(np.float64))[None, :] + np.abs(A) @ np.abs(B).T   #  <= 4096 terms are good to 2^-40 of `mag`)
+    S = scores.cpu().numpy().astype(np.float64)
+    ok = mag > 0
+    rel = float((np.abs(S - exact)[ok] / mag[ok]).max())
+    kt = _kt_of(k)
+    OMEGA_WORST[(case, k)] = rel
+    print("omega %-20s k %5d kt %3d: worst |S - exact| / magnitudes = 2^%.2f (allowance kt 2^-18 = 2^%.2f)"
+          % (case, k, kt, np.log2(max(rel, 1e-300)), np.log2(kt * 2.0 ** -18)))
+    assert rel <= kt * 2.0 ** -18, (case, k, rel)
+
+
 @pytest.mark.parametrize("k,m", [(16, 1), (16, 7), (16, 300), (3, 5), (8, 64)])
 def test_device_pointers_that_are_only_4_byte_aligned(oracle, path, k, m):
     """A borrowed device reference set / query batch may start at any float: the 16-byte fast paths
