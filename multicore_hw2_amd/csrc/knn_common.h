@@ -80,7 +80,8 @@ struct FilterWorkspace {
     void *qry_frags = nullptr; // device [qtiles][kt][64] x 16 B: B operands (-2 * scaled query)
     float *qry_norms = nullptr;// device [qtiles*32]
     float *qry_amax = nullptr; // device [qtiles*32]: max |scaled fp16 coordinate| of each query
-    float *thr = nullptr;      // device [qtiles*32]
+    float *thr = nullptr;      // device [4][qtiles*32]: thresholds | margins | floors | running thresholds (ordered uints) — the
+                               // last three feed the deep-K scan's in-launch tightening (knn_filter.hip, "running thresholds")
     unsigned *ctl = nullptr;   // device [3][KNN_CTL_WORDS]: block 0 = the full-scan path (reset by its fragment kernel);
                                // blocks 1, 2 alternate between the batches of the cell-pruned path, whose first
                                // kernel clears the block the NEXT batch will use (no reset launch, no race with
@@ -213,6 +214,7 @@ struct FilterState {
     bool several_slots = false;   // a query has used a workspace slot other than 0: batches are in flight side by side
     int scan_deal = 0;            // pruned scan: 0 auto (block counter unless several_slots), 1 fixed deal, 2 items from a block counter
     int scan_blocks = 0;          // pruned scan, blocks per CU: 0 auto (one for small shards when several_slots, else two), 1, 2
+    int run_thresholds = 0;       // deep-K scan (64 < k <= 128): 0 / 1 thresholds tighten during the launch, 2 they stay as the sample pass left them
     int cells_lists = 0;          // pruned scan, who lists a cell's queries: 0 auto, 1 knn_cells_match_kernel, 2 the scan's own waves
     FilterWorkspace ws[KNN_SLOTS];
     // The slots' big scan kernels are chained through this event: two of them sharing the CUs run

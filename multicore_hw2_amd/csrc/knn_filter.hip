@@ -376,7 +376,10 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
                                                       unsigned *__restrict__ ctl,
                                                       const unsigned *__restrict__ qpart, int qblocks,
                                                       unsigned *__restrict__ counts, unsigned nlists,
-                                                      float *__restrict__ dup_out = nullptr)
+                                                      float *__restrict__ dup_out = nullptr,
+                                                      // running thresholds of the deep-K scan (round 5; all three or none):
+                                                      float *__restrict__ marg_out = nullptr, float *__restrict__ floor_out = nullptr,
+                                                      unsigned *__restrict__ run_out = nullptr)
 {
     __shared__ float s_part[THR_PARTS][32];
     // housekeeping folded in here to save launches: zero the record counters of the filter pass
@@ -430,6 +433,29 @@ __global__ __launch_bounds__(32 * THR_PARTS) void knn_thr_kernel(const float *__
     if (dup_out)
         dup_out[i] = dupf;
     thr[i] = t;
+    if (run_out) {
+        // Running thresholds (round 5).  knn_threshold(u) is the threshold implied by the score u of ANY real row; the scan
+        // meets lower scores than the sample pass's minimum u0 as it goes, and every one of them implies a lower threshold.
+        // Recomputing knn_threshold in the scan (double arithmetic, two square roots) per improvement costs more than it
+        // saves; instead: d thr / d u >= 1 wherever the clamp `dt < 0` is not active — thr = dup (1 + ...) + const with
+        // d dup / d u = (1 + g2)^2 (1 + eta / sqrt(dt + 2 eta^2)) >= (1 + g2)^2, and (1 + g2)^2 - 1 >= 2 (k + 3) 2^-24 covers the
+        // 1e-6 |thr| slack term's own slope for k >= 33 (the only callers) — so for a real row's score u' <= u0
+        //     thr(u') <= max(thr(-inf), thr(u0) - (u0 - u')) = max(floor, u' + margin),     margin = thr(u0) - u0,
+        // with thr(-inf) the value under the clamp (the lowest threshold any score implies).  margin is rounded UP with 2^-20
+        // relative slack for the float additions on either side; a larger threshold only keeps more candidates.
+        float mg = INFINITY, fl = -INFINITY;
+        if (i < m && !bad) {
+            const BoundConsts c = knn_bound_consts(k, kt, sigma, qamax[i], bmax, nmax);
+            fl = knn_threshold(c, -INFINITY, qnorm[i]);
+            const double md = (double)t - (double)u + 0x1p-20 * (fabs((double)t) + fabs((double)u)) + 1e-30;
+            mg = (float)md;
+            if ((double)mg < md)
+                mg = nextafterf(mg, INFINITY);
+        }
+        marg_out[i] = mg;
+        floor_out[i] = fl;
+        run_out[i] = f2ord(t);
+    }
     if (bad)
         ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
 }
@@ -659,9 +685,13 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const h8 *__restrict__ qfg,
     const float *__restrict__ thrg, int qtiles, long long ntiles, long long stride,
     float *__restrict__ umin, int m_padded, u64 *__restrict__ rec, unsigned *__restrict__ counts,
-    unsigned *__restrict__ ctl, unsigned slice, unsigned short *__restrict__ rec_rows)
+    unsigned *__restrict__ ctl, unsigned slice, unsigned short *__restrict__ rec_rows,
+    // running thresholds (X16 scans only; null: the thresholds stay what knn_thr_kernel made them): per query the margin and
+    // floor of knn_thr_kernel, and the lowest threshold any block of this launch has derived so far (ordered uints)
+    const float *__restrict__ margg = nullptr, const float *__restrict__ floorg = nullptr, unsigned *__restrict__ rung = nullptr)
 {
     constexpr int WAVES = BLOCK / 64;   // waves that share every staged reference tile
+    constexpr bool RUN = X16 && !SAMPLE && TPB > 1;   // thresholds tighten during the launch
     constexpr int CHUNKS = KT * 64;                 // 16-byte chunks of A per tile
     constexpr int CPT = (CHUNKS + BLOCK - 1) / BLOCK;
     // TPB > 1 (round 3): TPB reference tiles per barrier, staged by LDS-DMA (global_load_lds, no staging registers) — the
@@ -692,6 +722,8 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     h8 qf[QT][KT];
     float th[QT], um[X16 ? 2 * QT : QT];
     __shared__ float s_th16[X16 ? WAVES : 1][X16 ? QT * 32 : 1];
+    __shared__ float s_mg16[RUN ? WAVES : 1][RUN ? QT * 32 : 1], s_fl16[RUN ? WAVES : 1][RUN ? QT * 32 : 1];
+    const bool run = RUN && rung != nullptr;   // (kernel-uniform)
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int tt = min(qt0 + min(t, max(nq - 1, 0)), qtiles - 1);
@@ -705,6 +737,11 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
             // the 256 two waves per SIMD leave each other, and the spill code sat inside the tile loop)
             if (lane < 32)
                 s_th16[wib][t * 32 + lane] = (!SAMPLE && t < nq) ? thrg[(size_t)(qt0 + t) * 32 + lane] : -INFINITY;
+            if constexpr (RUN)
+                if (run && lane < 32) {
+                    s_mg16[wib][t * 32 + lane] = t < nq ? margg[(size_t)(qt0 + t) * 32 + lane] : INFINITY;
+                    s_fl16[wib][t * 32 + lane] = t < nq ? floorg[(size_t)(qt0 + t) * 32 + lane] : -INFINITY;
+                }
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
                 um[2 * t + ch] = INFINITY;
@@ -776,9 +813,24 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
                         um[2 * t + ch] = min3f(m1, m2, um[2 * t + ch]);
                     } else {
                         const float thq = thv[2 * t + ch];
-                        const float mn = min3f(m1, m2, thq);
+                        const float mn = RUN ? fminf(m1, m2) : min3f(m1, m2, thq);   // (RUN: the lowest score itself, a real row's)
                         const bool hit = mn < thq;
                         if (__builtin_expect(__ballot(hit) != 0ull, 0)) {
+                            if constexpr (RUN) {
+                                // a score below the threshold is also a new bound for its query (knn_thr_kernel): the four
+                                // lanes that share the query may each write one — any of them is a valid threshold
+                                if (run && hit) {
+                                    // (indices worked out HERE, behind an asm barrier: hoisted out of the tile loop the eight
+                                    // LDS offsets and eight 64-bit addresses were 28 bytes of scratch at 256 registers)
+                                    unsigned ql = (unsigned)(t * 32 + 16 * ch) + ((unsigned)lane & 15u);
+                                    asm volatile("" : "+v"(ql));
+                                    const float tn = fmaxf(mn + s_mg16[wib][ql], s_fl16[wib][ql]);
+                                    if (tn < thq) {
+                                        s_th16[wib][ql] = tn;
+                                        atomicMin(&rung[(size_t)qt0 * 32 + ql], f2ord(tn));
+                                    }
+                                }
+                            }
                             // the record format of the 32 x 32 scan: (query, tile, half) + a mask over rows
                             // 8 (reg >> 2) + 4 half + (reg & 3).  This lane's rows 16 rh + 4 g + r are half = g & 1,
                             // reg = 8 rh + 4 (g >> 1) + r; lanes l and l ^ 32 (groups g and g ^ 2) hold the other eight rows of
@@ -897,6 +949,26 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
             for (int u = 0; u < TPB; ++u)
                 if (j0 + u < i1)   // block-uniform
                     score_tile(&ra[u * CHUNKS], &rn_[u * 8], j0 + u);
+            if constexpr (RUN) {
+                // what the other blocks that scan these queries (other tile ranges) have found meanwhile: requested in front of
+                // the barrier — it waits for the next tiles anyway, and the scoring registers are dead here — and folded into this
+                // wave's thresholds behind it.  Agent scope: the words are changed by other XCDs' atomics.
+                static_assert(!RUN || QT * 32 == 128, "two words per lane");
+                unsigned o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
+                if (run && nq > 0) {
+                    const size_t qb = (size_t)qt0 * 32;
+                    const size_t last = (size_t)(qt0 + nq) * 32 - 1;
+                    o0 = __hip_atomic_load(&rung[min(qb + (size_t)lane, last)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    o1 = __hip_atomic_load(&rung[min(qb + 64 + (size_t)lane, last)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (run && nq > 0) {
+                    if (lane < nq * 32)
+                        s_th16[wib][lane] = fminf(s_th16[wib][lane], ord2f(o0));
+                    if (64 + lane < nq * 32)
+                        s_th16[wib][64 + lane] = fminf(s_th16[wib][64 + lane], ord2f(o1));
+                }
+            } else
             __syncthreads();   // the next group has landed (hipcc drains vmcnt in front of the barrier); nobody reads this one any more
         };
         if (i0 < i1) {
@@ -2065,7 +2137,7 @@ static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
         (void)KNN_DEV_FREE(w.qry_amax);
         w.qry_amax = nullptr;
         FTRY(KNN_DEV_ALLOC((void **)&w.qry_amax, qtiles * 32 * sizeof(float)));
-        FTRY(KNN_DEV_ALLOC((void **)&w.thr, qtiles * 32 * sizeof(float)));
+        FTRY(KNN_DEV_ALLOC((void **)&w.thr, 4 * qtiles * 32 * sizeof(float)));   // thresholds | margins | floors | running (see knn_thr_kernel)
         (void)KNN_DEV_FREE(w.qpart);
         w.qpart = nullptr;
         FTRY(KNN_DEV_ALLOC((void **)&w.qpart, 3 * ((qtiles * 32 + 255) / 256) * sizeof(unsigned)));
@@ -2323,6 +2395,16 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         stride = 1;
     if (stride > 16)
         stride = 16;
+    // Running thresholds (KT = 8, round 5): the scan tightens every query's threshold as it goes, so the sample pass only has
+    // to give it a start — every 32nd tile instead of every 8th at C5 (2048 tiles): the pass shrinks 4x, the candidates grow
+    // from 210k to 355k of the 642k a fixed threshold left, ms per step 0.9155 (stride 8) / 0.8909 (16) / 0.8829 (32) / 0.9091
+    // (64) / 0.9378 (128) on one box (profiles/r05_c5_running_thresholds.txt).  KNN_MI355X_SAMPLE_STRIDE: the sweep's knob.
+    if (KT == 8 && st.run_thresholds != 2) {
+        static const int stride_env = getenv("KNN_MI355X_SAMPLE_STRIDE") ? atoi(getenv("KNN_MI355X_SAMPLE_STRIDE")) : 0;
+        stride = std::min<long long>(32, std::max<long long>(1, st.ntiles / 64));
+        if (stride_env > 0)
+            stride = std::min<long long>(stride_env, std::max<long long>(1, st.ntiles / 16));
+    }
     const long long ns = (st.ntiles + stride - 1) / stride;
     unsigned sb = gx;
     if ((long long)sb > ns)
@@ -2346,7 +2428,8 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     FTRY(hipGetLastError());
     hipLaunchKernelGGL(knn_thr_kernel, dim3((unsigned)(m_padded / 32)), dim3(32 * THR_PARTS), 0, s, w.umin,
                        (int)sb, w.qry_norms, w.qry_amax, m, m_padded, st.k, st.kt, st.sigma, st.bmax, st.nmax, kAmaxLimit,
-                       w.thr, w.ctl, w.qpart, (m_padded + 255) / 256, w.counts, w.nlists);
+                       w.thr, w.ctl, w.qpart, (m_padded + 255) / 256, w.counts, w.nlists, nullptr,
+                       w.thr + (size_t)w.m_cap, w.thr + 2 * (size_t)w.m_cap, (unsigned *)(w.thr + 3 * (size_t)w.m_cap));
     FTRY(hipGetLastError());
     if (!st.scan_done)
         FTRY(hipEventCreateWithFlags(&st.scan_done, hipEventDisableTiming));
@@ -2367,7 +2450,9 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 4, true>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                           (unsigned short *)(w.records + w.rec_cap));
+                           (unsigned short *)(w.records + w.rec_cap),
+                           st.run_thresholds != 2 ? w.thr + (size_t)w.m_cap : nullptr, w.thr + 2 * (size_t)w.m_cap,
+                           st.run_thresholds != 2 ? (unsigned *)(w.thr + 3 * (size_t)w.m_cap) : nullptr);
     else   // (16 x 16 shape from k = 65 up: measured -8 % at k 128, -6 % at k 256 and 512, +7 % at k 64 where a tile is only 16 MFMAs)
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 1, (KT > 4)>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,

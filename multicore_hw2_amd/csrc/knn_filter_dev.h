@@ -38,6 +38,10 @@ __device__ __forceinline__ unsigned f2ord(float f)
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float ord2f(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
 static inline float ord2f_host(unsigned o)
 {
     const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;

@@ -1158,3 +1158,56 @@ def test_rccl_always_refuses_a_call_whose_shards_are_not_the_visible_devices():
     r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "returned" not in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-300:])
     assert "rccl = 1 but the call's shards are not the visible devices" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("dist", ["uniform", "gaussian", "near_copies", "far_queries"])
+@pytest.mark.parametrize("k,m,n", [(128, 4096, 65536), (100, 1000, 70001), (72, 2500, 40000)])
+def test_thresholds_that_tighten_during_the_deep_k_launch_keep_every_answer(oracle, dist, k, m, n):
+    """Round 5: for 64 < k <= 128 every score below a query's threshold is also a new bound for that
+    query — threshold' = max(floor, score + margin), shared between the blocks that scan other tile ranges for the same
+    queries through atomic minima on one word per query (knn_thr_kernel has the derivation).  Same answers as v0 with the
+    running thresholds on (default) and off (option run_thresholds = 2), FEWER re-ranked candidates with them on; near
+    copies (answers at distance ~0: the clamp region of the threshold function, where the floor takes over) and far-away
+    queries (thresholds that let most rows through) are the edge cases of the margin argument."""
+    rng = np.random.default_rng(k + m)
+    if dist == "uniform":
+        Q, R = oracle.synth(m * k, 91).reshape(m, k), oracle.synth(n * k, 92).reshape(n, k)
+    elif dist == "gaussian":
+        Q, R = rng.normal(0, 1, (m, k)).astype(np.float32), rng.normal(0, 1, (n, k)).astype(np.float32)
+    elif dist == "near_copies":
+        R = oracle.synth(n * k, 92).reshape(n, k).copy()
+        Q = (R[rng.integers(0, n, m)] + rng.normal(0, 1e-4, (m, k))).astype(np.float32)
+        Q[::7] = R[rng.integers(0, n, len(Q[::7]))]                      # exact copies too
+    else:
+        R = oracle.synth(n * k, 92).reshape(n, k)
+        Q = oracle.synth(m * k, 91).reshape(m, k).copy()
+        Q[: m // 4] = (Q[: m // 4] * 3.0 - 1.0).astype(np.float32)       # a quarter of the queries outside the references' box
+    Q, R = np.ascontiguousarray(Q), np.ascontiguousarray(R)
+    want = oracle.v0(k, Q, R)
+    dev = torch.device("cuda:0")
+    q_d, r_d = torch.from_numpy(Q).to(dev), torch.from_numpy(R).to(dev)
+    records = {}
+    try:
+        for mode in (0, 2):
+            pkg.set_option("path", 2)
+            pkg.set_option("run_thresholds", mode)
+            ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
+            keys = torch.empty(m, dtype=torch.int64, device=dev)
+            out = torch.empty(m, dtype=torch.int32, device=dev)
+            for _ in range(2):                                            # (twice: the running words are re-made per batch)
+                pkg.keys_init(keys.data_ptr(), m)
+                ix.query_keys(m, q_d.data_ptr(), keys.data_ptr())
+                pkg.keys_to_indices(keys.data_ptr(), m, out.data_ptr())
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"{dist} {(k, m, n)} run_thresholds={mode}")
+            st = ix.last_stats()
+            ix.close()
+            assert st[0] == 2 and st[2] == 0, st
+            records[mode] = st[1]
+    finally:
+        pkg.set_option("path", 0)
+        pkg.set_option("run_thresholds", 0)
+    assert records[0] <= records[2], records
+    print("run_thresholds %s %s: %d candidates re-ranked with the running thresholds, %d without" % (dist, (k, m, n), records[0], records[2]))
+    if dist in ("uniform", "gaussian") and m >= 4096:      # (few queries: every block sees a handful of tiles — nothing to tighten)
+        assert records[0] < 0.8 * records[2], records      # the point of it: fewer candidates reach the exact re-rank
