@@ -248,8 +248,12 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             (batches in flight fill each other's gaps; the fixed deal's cheaper prologue then gives the shorter step).  The automatic choices follow the caller's recent behaviour: a
  *             caller that goes back to one batch at a time gets the one-batch shapes again after eight calls
  *   "cells_build" how the cell-sorted layout is built: 0 = two passes (rows grouped into 256 buckets of consecutive cells, then
- *             placed bucket by bucket out of one XCD's L2: 3.4 ms for 2^24 rows of 16 floats; needs n x 72 bytes of scratch: used for
- *             shards of up to 2^25 rows, and falls back when the scratch does not fit), 1 = the one-pass placement (4.7 ms).  Read when an index is created
+ *             placed bucket by bucket out of one XCD's L2; needs n x 72 bytes of scratch + 1/8: used for shards of up to 2^25 rows,
+ *             and falls back when the scratch does not fit) in their FAST form — buckets of fixed room, no counting pass over the
+ *             rows, tile ranges and work items from a device prefix, one synchronisation for the whole build; a bucket that
+ *             outgrows its room (rows the cuts do not spread) makes the build start over in the counted form; 1 = the one-pass
+ *             placement; 2 = the counted two-pass build (rounds 3-4: a pass for the bucket counts, two host round trips).
+ *             Read when an index is created
  *   "filter_rounds" tuning: filter workgroups per resident slot (0/1 = one: persistent waves)
  *   "filter_chain" filter scans issued on different workspace slots / streams: 1 = run one
  *             after the other (event-chained), 2 = free to overlap, 0 = auto (chained when the

@@ -73,7 +73,7 @@ std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 
 std::atomic<long long> g_opt_run_thresholds{0};  // deep-K scan: 0 / 1 running thresholds, 2 off (A/B)
 std::atomic<long long> g_opt_cells_lists{0};     // pruned scan, who lists a cell's queries: 0 auto, 1 the match launch, 2 the scan's own waves
 std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
-std::atomic<long long> g_opt_cells_build{0};     // cell-sorted layout: 0 two-pass build, 1 the one-pass placement (A/B, tests)
+std::atomic<long long> g_opt_cells_build{0};     // cell-sorted layout: 0 fast two-pass build (counted one if a bucket overflows), 1 the one-pass placement, 2 the counted two-pass build (A/B, tests)
 std::atomic<long long> g_opt_cells{0};       // cell-sorted layouts (k <= 16): 0 resident indexes large enough to prune (index_create_impl), 1 from 2^17 rows, 2 never
 std::atomic<long long> g_opt_ingest{0};      // indexes created from host rows: 0 layouts built under the copy, 1 copy then build
 std::atomic<long long> g_opt_rccl{0};        // 0 auto (several GPUs, one shard each), 1 always, 2 never
@@ -350,8 +350,8 @@ int knn_set_option(const char *name, long long value)
         return KNN_OK;
     }
     if (!strcmp(name, "cells_build")) {
-        if (value < 0 || value > 1)
-            return fail(KNN_EINVAL, "knn_set_option: cells_build must be 0 (two-pass) or 1 (one-pass placement)");
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: cells_build must be 0 (fast two-pass), 1 (one-pass placement) or 2 (counted two-pass)");
         g_opt_cells_build = value;
         return KNN_OK;
     }
@@ -556,7 +556,7 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
             want_layouts = false;
     }
     if (want_layouts && !layouts_done) {
-        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s, want_cells ? (g_opt_cells_build == 1 ? 2 : 1) : 0);
+        hipError_t e = knn_filter_build(idx->filter, k, n_local, idx->refs, s, want_cells ? (g_opt_cells_build == 1 ? 2 : g_opt_cells_build == 2 ? 3 : 1) : 0);
         if (e == hipErrorOutOfMemory) {
             // no room for the fp16 layouts beside the rows: the index still works, exact kernels only
             (void)hipGetLastError();
@@ -681,7 +681,7 @@ int knn_index_create_sharded(knn_index **out, int device, const knn_geom *g, int
         idx->num_cu = prop.multiProcessorCount;
     if (n_local > 0) {
         unsigned bad_rows = 0u;
-        const hipError_t e = knn_filter_build(idx->filter, idx->k, n_local, refs_dev, s, g_opt_cells_build == 1 ? 2 : 1, &idx->geom,
+        const hipError_t e = knn_filter_build(idx->filter, idx->k, n_local, refs_dev, s, g_opt_cells_build == 1 ? 2 : g_opt_cells_build == 2 ? 3 : 1, &idx->geom,
                                               rank, &bad_rows);
         if (e != hipSuccess || !idx->filter.usable || !idx->filter.cells) {
             char why[160];

@@ -429,16 +429,208 @@ __global__ __launch_bounds__(256) void knn_cells_bucket_scatter_kernel(const flo
     }
 }
 
+// ---- the fast build (round 5): no pass over the rows for counts, no host round trip between the passes ---------------
+// B': A and B in one kernel, for buckets of FIXED room (`cap` records each: the caller sizes it for rows that spread evenly
+// over the buckets + 1/8, which is what the quantile cuts give on data they fit; a bucket that outgrows its room raises
+// `overflow` and the caller builds again with the counted passes above).  The block reads its 4096 rows ONCE from memory —
+// codes worked out from the rows on the fly and parked in LDS, no `code` array — and copies them in bucket order four lanes
+// to a row: every load and store of the copy is a whole 64-byte line (one lane per row was four instructions touching 64
+// different lines each).  The second read of a row comes out of the L2 (the block's rows are 256 KiB).
+__global__ __launch_bounds__(256) void knn_cells_bucket_scatter_fixed_kernel(const float *__restrict__ R, long long n, CellGeom g,
+                                                                             const float *__restrict__ bounds, int bshift, unsigned cap,
+                                                                             unsigned *__restrict__ bucket_fill,
+                                                                             float *__restrict__ trows, u64 *__restrict__ tmeta,
+                                                                             unsigned *__restrict__ overflow)
+{
+    __shared__ unsigned s_h[CELL_BUCKETS], s_start[CELL_BUCKETS], s_cur[CELL_BUCKETS], s_base[CELL_BUCKETS], s_wsum[4];
+    __shared__ unsigned short s_order[CELL_BUILD_ROWS], s_code[CELL_BUILD_ROWS];
+    __shared__ float s_bnd[16 * (CELL_MAX_BINS - 1)];
+    s_h[threadIdx.x] = 0u;
+    if (threadIdx.x < 16 * (CELL_MAX_BINS - 1))
+        s_bnd[threadIdx.x] = bounds[threadIdx.x];
+    __syncthreads();
+    const long long i0 = (long long)blockIdx.x * CELL_BUILD_ROWS;
+    const bool vec = g.k == 16 && ((uintptr_t)R & 15u) == 0;
+    if (vec) {
+        // four lanes to a row, 16 bytes each: the block reads its 256 KiB as one linear stream (a lane per row was four
+        // instructions, each touching 64 different lines).  A lane bins its four dimensions, the quad ORs the pieces.
+        const unsigned q = threadIdx.x & 3u;
+        unsigned nbq[4], shq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            nbq[e] = g.nb[4 * q + e];      // (a dependent load from the kernel arguments per lane: once, outside the loop)
+            shq[e] = g.shift[4 * q + e];
+        }
+#pragma unroll 4
+        for (int it = 0; it < CELL_BUILD_ROWS / 64; ++it) {
+            const unsigned row = (unsigned)it * 64u + (threadIdx.x >> 2);
+            const long long i = i0 + row;
+            unsigned c = 0u;
+            if (i < n) {
+                const f4v v = ((const f4v *)(R + (size_t)i * 16))[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (nbq[e])
+                        c |= cell_bin(s_bnd + (4 * q + e) * (CELL_MAX_BINS - 1), 1 << nbq[e], v[e]) << shq[e];
+            }
+            c |= (unsigned)__shfl_xor((int)c, 1, KNN_WAVE);
+            c |= (unsigned)__shfl_xor((int)c, 2, KNN_WAVE);
+            if (q == 0u && i < n) {
+                s_code[row] = (unsigned short)c;
+                atomicAdd(&s_h[c >> bshift], 1u);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int it = 0; it < CELL_BUILD_ROWS / 256; ++it) {
+            const long long i = i0 + it * 256 + threadIdx.x;
+            if (i < n) {
+                float x[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d)
+                    x[d] = d < g.k ? R[(size_t)i * g.k + d] : 0.0f;
+                const unsigned c = cell_code_of(x, g, s_bnd);   // (no shard geometry on this path: local = global code, < 2^16)
+                s_code[it * 256 + threadIdx.x] = (unsigned short)c;
+                atomicAdd(&s_h[c >> bshift], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    block_prefix_256(s_h, s_start, s_wsum);
+    {
+        const unsigned cnt = s_h[threadIdx.x];   // thread t reserves the block's room in bucket t
+        unsigned at = 0u;
+        if (cnt != 0u) {
+            at = atomicAdd(&bucket_fill[threadIdx.x], cnt);
+            if (at + cnt > cap)
+                atomicOr(overflow, 1u);
+        }
+        s_base[threadIdx.x] = at;   // position INSIDE the bucket; records beyond `cap` are not written
+        s_cur[threadIdx.x] = s_start[threadIdx.x];
+    }
+    __syncthreads();
+    const unsigned nrows = (unsigned)min((long long)CELL_BUILD_ROWS, n - i0);
+    for (unsigned j = threadIdx.x; j < nrows; j += 256u)
+        s_order[atomicAdd(&s_cur[(unsigned)s_code[j] >> bshift], 1u)] = (unsigned short)j;
+    __syncthreads();
+    if (vec) {
+        const unsigned q = threadIdx.x & 3u;
+        for (unsigned slot = threadIdx.x >> 2; slot < nrows; slot += 64u) {
+            const unsigned src = s_order[slot];
+            const unsigned c = s_code[src];
+            const unsigned bk = c >> bshift;
+            const unsigned inb = s_base[bk] + (slot - s_start[bk]);
+            if (inb < cap) {
+                const size_t pos = (size_t)bk * cap + inb;
+                // (streaming stores: the records are read next by another kernel; the block's own rows should stay cached for
+                // this second read of them)
+                __builtin_nontemporal_store(((const f4v *)(R + (size_t)(i0 + src) * 16))[q], &((f4v *)(trows + pos * 16))[q]);
+                if (q == 0u)
+                    __builtin_nontemporal_store(((u64)c << 32) | (u64)(unsigned)(i0 + src), &tmeta[pos]);
+            }
+        }
+    } else {
+        for (unsigned slot = threadIdx.x; slot < nrows; slot += 256u) {
+            const unsigned src = s_order[slot];
+            const unsigned c = s_code[src];
+            const unsigned bk = c >> bshift;
+            const unsigned inb = s_base[bk] + (slot - s_start[bk]);
+            if (inb < cap) {
+                const size_t pos = (size_t)bk * cap + inb;
+                const float *__restrict__ x = R + (size_t)(i0 + src) * g.k;
+                float *__restrict__ t = trows + pos * 16;
+                for (int d = 0; d < g.k; ++d)
+                    t[d] = x[d];
+                tmeta[pos] = ((u64)c << 32) | (u64)(unsigned)(i0 + src);
+            }
+        }
+    }
+}
+
+// C1': the cells' tile ranges and the scan's items from the cell counts, on the device (rounds 2-4: counts to the host, prefix
+// there, tile ranges and items back).  One cell per thread, 1024 cells per block: block b first adds up what the cells in
+// front of its own need (every block reads the counts before its range again — 8 MB out of the L2 in all at 2^16 cells — instead
+// of waiting for its neighbours), then scans its own 1024.  Everything is read and written with consecutive lanes on
+// consecutive words (a first form — one block, 64 consecutive cells per thread — took 97-176 us: 64 lines per instruction
+// from ONE compute unit).  res = {tiles, items, rows of the largest cell}; the caller zeroes counts[] afterwards (it
+// becomes the placement's fill counters).
+__global__ __launch_bounds__(1024) void knn_cells_prefix_kernel(const unsigned *__restrict__ counts, unsigned ncells,
+                                                                unsigned *__restrict__ tile_start, u64 *__restrict__ items,
+                                                                unsigned *__restrict__ res)
+{
+    __shared__ unsigned s_t[1024], s_i[1024], s_red[3][16];
+    const unsigned first = blockIdx.x * 1024u, c = first + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    unsigned bt = 0u, bi = 0u;   // what the cells in front of this block need
+    for (unsigned j = threadIdx.x; j < first; j += 1024u) {
+        const unsigned t = (counts[j] + 31u) / 32u;
+        bt += t;
+        bi += (t + KNN_CELL_ITEM_TILES - 1u) / KNN_CELL_ITEM_TILES;
+    }
+    const unsigned rows = c < ncells ? counts[c] : 0u;
+    const unsigned tiles = (rows + 31u) / 32u, nit = (tiles + KNN_CELL_ITEM_TILES - 1u) / KNN_CELL_ITEM_TILES;
+    unsigned big = rows;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bt += (unsigned)__shfl_xor((int)bt, off, KNN_WAVE);
+        bi += (unsigned)__shfl_xor((int)bi, off, KNN_WAVE);
+        big = max(big, (unsigned)__shfl_xor((int)big, off, KNN_WAVE));
+    }
+    if (lane == 0u) {
+        s_red[0][w] = bt;
+        s_red[1][w] = bi;
+        s_red[2][w] = big;
+    }
+    s_t[threadIdx.x] = tiles;
+    s_i[threadIdx.x] = nit;
+    __syncthreads();
+    bt = bi = big = 0u;
+    for (int j = 0; j < 16; ++j) {
+        bt += s_red[0][j];
+        bi += s_red[1][j];
+        big = max(big, s_red[2][j]);
+    }
+    for (unsigned off = 1u; off < 1024u; off <<= 1) {   // inclusive scans of the block's own cells (Hillis-Steele, 10 steps)
+        const unsigned a = threadIdx.x >= off ? s_t[threadIdx.x - off] : 0u, b = threadIdx.x >= off ? s_i[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_t[threadIdx.x] += a;
+        s_i[threadIdx.x] += b;
+        __syncthreads();
+    }
+    if (c < ncells) {
+        const unsigned tb = bt + s_t[threadIdx.x] - tiles;
+        unsigned ib = bi + s_i[threadIdx.x] - nit;
+        tile_start[c] = tb;
+        for (unsigned t0 = 0u; t0 < tiles; t0 += KNN_CELL_ITEM_TILES)   // (one item per cell on data the cuts fit)
+            items[ib++] = ((u64)c << 48) | ((u64)min((unsigned)KNN_CELL_ITEM_TILES, tiles - t0) << 40) | (u64)(tb + t0);
+    }
+    if (threadIdx.x == 0u)
+        atomicMax(&res[2], big);
+    if (c == ncells - 1u) {   // the last cell's thread has the totals
+        tile_start[ncells] = bt + s_t[threadIdx.x];
+        res[0] = bt + s_t[threadIdx.x];
+        res[1] = bi + s_i[threadIdx.x];
+    }
+}
+
 // C1: rows per cell from the buckets' records (a bucket's cells are consecutive: an LDS histogram per block).
+// (bucket_fill, nullable: the fast build's buckets have fixed room — bucket b holds records [bucket_start[b], + bucket_fill[b]))
+__device__ __forceinline__ unsigned bucket_end(const unsigned *__restrict__ bucket_start, const unsigned *__restrict__ bucket_fill, unsigned b)
+{
+    const unsigned r0 = bucket_start[b], room = bucket_start[b + 1] - r0;
+    return bucket_fill ? r0 + min(bucket_fill[b], room) : r0 + room;
+}
+
 __global__ __launch_bounds__(256) void knn_cells_bucket_cellcount_kernel(const u64 *__restrict__ tmeta,
                                                                          const unsigned *__restrict__ bucket_start, int bshift,
-                                                                         unsigned *__restrict__ counts)
+                                                                         unsigned *__restrict__ counts,
+                                                                         const unsigned *__restrict__ bucket_fill)
 {
     __shared__ unsigned s_h[256];   // cells of one bucket (2^bshift <= 256: bits <= 16)
     const unsigned b = blockIdx.x / CELL_PLACE_PARTS, part = blockIdx.x % CELL_PLACE_PARTS;
     s_h[threadIdx.x] = 0u;
     __syncthreads();
-    const unsigned r0 = bucket_start[b], r1 = bucket_start[b + 1];
+    const unsigned r0 = bucket_start[b], r1 = bucket_end(bucket_start, bucket_fill, b);
     const unsigned len = (r1 - r0 + CELL_PLACE_PARTS - 1u) / CELL_PLACE_PARTS;
     const unsigned a = min(r0 + part * len, r1), e = min(a + len, r1);
     for (unsigned i = a + threadIdx.x; i < e; i += 256u)
@@ -456,14 +648,14 @@ __global__ __launch_bounds__(256) void knn_cells_place_kernel(
     const float *__restrict__ trows, const u64 *__restrict__ tmeta, const unsigned *__restrict__ bucket_start, int k, int bshift,
     const unsigned *__restrict__ tile_start, unsigned *__restrict__ fill, const float *__restrict__ center, float sigma,
     h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ norms2, unsigned *__restrict__ perm,
-    unsigned *__restrict__ out, unsigned *__restrict__ olist, unsigned ocap)
+    unsigned *__restrict__ out, unsigned *__restrict__ olist, unsigned ocap, const unsigned *__restrict__ bucket_fill)
 {
     __shared__ unsigned s_h[256], s_start[256], s_cur[256], s_pos[256], s_wsum[4];
     __shared__ unsigned short s_order[CELL_BUILD_ROWS];
     __shared__ float s_c[16];
     const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
     const unsigned b = (jb / CELL_PLACE_PARTS) * 8u + xcd, part = jb % CELL_PLACE_PARTS;
-    const unsigned r0 = bucket_start[b], r1 = bucket_start[b + 1];
+    const unsigned r0 = bucket_start[b], r1 = bucket_end(bucket_start, bucket_fill, b);
     const unsigned len = (r1 - r0 + CELL_PLACE_PARTS - 1u) / CELL_PLACE_PARTS;
     const unsigned a = min(r0 + part * len, r1), e = min(a + len, r1);
     const unsigned cmask = (1u << bshift) - 1u;
@@ -1792,7 +1984,7 @@ void knn_cells_free(CellIndex *&c)
 // of the build (samples x k).  Synchronous.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                           unsigned **fill_out, bool one_pass, const ShardGeom *geom, int rank, unsigned *bad_rows_out)
+                           unsigned **fill_out, bool one_pass, const ShardGeom *geom, int rank, unsigned *bad_rows_out, bool fast)
 {
     *out = nullptr;
     *code_out = nullptr;
@@ -1840,6 +2032,81 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     while ((1u << lbits) < c->ncells)
         ++lbits;
 
+    // ---- the fast build (round 5): no counting pass over the rows, no host round trip (see the kernels).  Taken for whole
+    // indexes (no shard geometry: their rows' codes are local = global and fit 16 bits) whose scratch fits; everything it
+    // launches is asynchronous — the caller reads c->build_res behind the placement and, if a bucket outgrew its fixed room
+    // (data the quantile cuts do not spread evenly over the 256 buckets), builds again with fast = false.
+    if (fast && !geom && !one_pass && (size_t)n * 96 <= ((size_t)2 << 30) && c->ncells >= 512u) {
+        const int bshift_f = lbits - 8;
+        // room per bucket: an even spread + 1/2.  The cuts are medians of a 1024-row sample: each is off by ~1.6 % of the rows
+        // (1 sigma), a bucket is the product of 8 such halves — 1 sigma 9 %, the fullest of 256 buckets ~27 % over the mean on
+        // uniform data (measured: + 1/8 overflowed at C3)
+        const unsigned cap_rows = (unsigned)((n / CELL_BUCKETS) + (n / CELL_BUCKETS) / 2 + CELL_BUILD_ROWS);
+        const size_t recs = (size_t)cap_rows * CELL_BUCKETS;
+        const long long tiles_ub = n / 32 + (long long)c->ncells;                         // every cell wastes less than a tile
+        const size_t items_ub = (size_t)c->ncells + (size_t)(tiles_ub / KNN_CELL_ITEM_TILES) + 1u;
+        unsigned *counts_f = nullptr;
+        hipError_t a = KNN_DEV_ALLOC((void **)&c->bounds, (bounds.size() + 1) * sizeof(float));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->tile_start, ((size_t)c->ncells + 1) * sizeof(unsigned));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&counts_f, (size_t)c->ncells * sizeof(unsigned));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->tmp_rows, recs * 16 * sizeof(float));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->tmp_meta, recs * sizeof(u64));
+        if (a == hipSuccess)   // [257] bucket starts | [256] fills | [4] results
+            a = KNN_DEV_ALLOC((void **)&c->bucket_start, (CELL_BUCKETS + 1 + CELL_BUCKETS + 4) * sizeof(unsigned));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->items, items_ub * sizeof(u64));
+        if (a == hipSuccess)
+            a = KNN_DEV_ALLOC((void **)&c->perm, (size_t)tiles_ub * 32 * sizeof(unsigned));
+        if (a == hipSuccess) {
+            c->bucket_fill = c->bucket_start + CELL_BUCKETS + 1;
+            c->build_res = c->bucket_fill + CELL_BUCKETS;
+            static_assert(sizeof c->h_bounds == 16 * (CELL_MAX_BINS - 1) * sizeof(float), "cuts");
+            for (int b = 0; b <= CELL_BUCKETS; ++b)
+                c->h_bucket_start[b] = (unsigned)b * cap_rows;
+            memcpy(c->h_bounds, bounds.data(), sizeof c->h_bounds);
+            a = hipMemcpyAsync(c->bounds, c->h_bounds, sizeof c->h_bounds, hipMemcpyHostToDevice, s);
+            if (a == hipSuccess)
+                a = hipMemcpyAsync(c->bucket_start, c->h_bucket_start, sizeof c->h_bucket_start, hipMemcpyHostToDevice, s);
+            if (a == hipSuccess)
+                a = hipMemsetAsync(c->bucket_fill, 0, (CELL_BUCKETS + 4) * sizeof(unsigned), s);
+            if (a == hipSuccess)
+                a = hipMemsetAsync(counts_f, 0, (size_t)c->ncells * sizeof(unsigned), s);
+            if (a == hipSuccess) {
+                hipLaunchKernelGGL(knn_cells_bucket_scatter_fixed_kernel, dim3((unsigned)((n + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS)),
+                                   dim3(256), 0, s, r, n, g, c->bounds, bshift_f, cap_rows, c->bucket_fill, c->tmp_rows, c->tmp_meta,
+                                   c->build_res + 3);
+                hipLaunchKernelGGL(knn_cells_bucket_cellcount_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, c->tmp_meta,
+                                   c->bucket_start, bshift_f, counts_f, c->bucket_fill);
+                hipLaunchKernelGGL(knn_cells_prefix_kernel, dim3((c->ncells + 1023u) / 1024u), dim3(1024), 0, s, counts_f, c->ncells,
+                                   c->tile_start, c->items, c->build_res);
+                a = hipGetLastError();
+            }
+            if (a == hipSuccess)   // the counts become the placement's fill counters
+                a = hipMemsetAsync(counts_f, 0, (size_t)c->ncells * sizeof(unsigned), s);
+        }
+        if (a == hipSuccess) {
+            c->lbits = lbits;
+            c->nitems = 0u;   // (the caller fills nitems / max_cell_rows in from build_res)
+            *code_out = nullptr;
+            *fill_out = counts_f;
+            *ntiles_out = tiles_ub;
+            *out = c;
+            return hipSuccess;
+        }
+        // no room (or a launch failed): the counted build below starts from scratch
+        (void)hipGetLastError();
+        (void)KNN_DEV_FREE(counts_f);
+        knn_cells_free(c);
+        c = new CellIndex();
+        c->bits = lbits;
+        c->ncells = 1u << lbits;
+        cell_grid_shape(k, lbits, c->nb, c->shift, &c->sa);
+        c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
+    }
     unsigned *code = nullptr, *counts = nullptr;
     std::vector<unsigned> hcounts((size_t)c->ncells), hstart((size_t)c->ncells + 1);
     std::vector<u64> hitems;
@@ -1916,7 +2183,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
             hipLaunchKernelGGL(knn_cells_bucket_scatter_kernel, dim3(bblocks), dim3(256), 0, s, r, n, k, bshift, code, c->bucket_start,
                                bucket_fill, c->tmp_rows, c->tmp_meta);
             hipLaunchKernelGGL(knn_cells_bucket_cellcount_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, c->tmp_meta,
-                               c->bucket_start, bshift, counts);
+                               c->bucket_start, bshift, counts, (const unsigned *)nullptr);
             e = hipGetLastError();
         }
         if (e == hipSuccess)
@@ -2006,7 +2273,8 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
     if (st.cells->tmp_rows)
         hipLaunchKernelGGL(knn_cells_place_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, st.cells->tmp_rows,
                            st.cells->tmp_meta, st.cells->bucket_start, st.k, st.cells->lbits - 8, st.cells->tile_start, fill, st.center, st.sigma,
-                           (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, out, st.outliers, ocap);
+                           (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, out, st.outliers, ocap,
+                           (const unsigned *)st.cells->bucket_fill);
     else
         hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
                            st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,

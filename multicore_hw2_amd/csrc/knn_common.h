@@ -181,6 +181,13 @@ struct CellIndex {
     float *tmp_rows = nullptr;
     unsigned long long *tmp_meta = nullptr;
     unsigned *bucket_start = nullptr;   // device [257]: first record of each bucket
+    // the FAST build (round 5; knn_cells_build with fast = true): buckets of fixed room, filled to bucket_fill[b]; the cells' tile
+    // ranges and the items come from a device prefix — build_res = {tiles, items, rows of the largest cell, bucket overflow}
+    // is read by the caller together with the placement's statistics, ONE synchronisation for the whole build
+    float h_bounds[16 * 15];            // (host sources of the fast build's asynchronous copies: they must outlive the call)
+    unsigned h_bucket_start[257];
+    unsigned *bucket_fill = nullptr;    // device [256] (inside the block `bucket_start` points to)
+    unsigned *build_res = nullptr;      // device [4]   (likewise)
     // cell-range shards (knn_index_create_sharded): global number of every local row, ascending (borrowed); null: base + row
     const unsigned *gids = nullptr;
     // cell-range shards: `bits`, `nb`, `shift`, `sa`, `bounds` are the GLOBAL grid's; this index holds cells
@@ -234,7 +241,7 @@ struct FilterState {
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r_dev, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
                            unsigned **fill_out, bool one_pass = false, const ShardGeom *geom = nullptr, int rank = 0,
-                           unsigned *bad_rows_out = nullptr);
+                           unsigned *bad_rows_out = nullptr, bool fast = false);
 #endif
 // Sizes of one scan launch of the cell-pruned path (knn_cells.hip; host arithmetic only).
 struct CellScanPlan {

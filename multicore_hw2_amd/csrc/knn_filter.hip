@@ -1613,6 +1613,8 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         fprintf(stderr, "[knn build] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    // want_cells: 1 = the fast two-pass build, counted build if a bucket overflows; 2 = one-pass placement; 3 = the counted two-pass build
+    bool fast_build = want_cells == 1, fast_overflow = false;
     // The cell-sorted layout from a GIVEN frame (centre, scale) and either a shard geometry's cuts or cuts taken from `samp`.
     // Returns with st.usable set when the layout stands; st.cells null (and st reset) when the shard does not suit the cells.
     // late_frame (nullable): called once the cells are counted; fills centre and scale then (false: no frame — give up)
@@ -1620,8 +1622,9 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
                              const std::function<bool(float *, float *)> &late_frame) -> hipError_t {
         long long ntiles = 0;
         unsigned *cell_code = nullptr, *cell_fill = nullptr;
-        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles, &cell_code, &cell_fill, want_cells == 2, geom, rank, bad_rows_out));
-        lap(st.cells ? "cell codes + counts" : "cell codes (not kept)");
+        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles, &cell_code, &cell_fill, want_cells == 2, geom, rank, bad_rows_out,
+                             fast_build));
+        lap(st.cells ? (st.cells->build_res ? "buckets + cell prefix (enqueued)" : "cell codes + counts") : "cell codes (not kept)");
         if (!st.cells)
             return hipSuccess;
         if (late_frame && !late_frame(center16, &sigma)) {
@@ -1653,14 +1656,28 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         if (e == hipSuccess)
             e = hipMemcpyAsync(st.center, center16, 16 * sizeof(float), hipMemcpyHostToDevice, s);
         lap("allocations");
-        unsigned hout[4] = {0, 0, 0, 0};
+        unsigned hout[4] = {0, 0, 0, 0}, hres[4] = {0, 0, 0, 0};
+        const bool fast_built = st.cells->build_res != nullptr;
         if (e == hipSuccess)
             e = knn_cells_place_rows(st, r, cell_code, cell_fill, dout, ocap, s);
         if (e == hipSuccess)
             e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && fast_built)
+            e = hipMemcpyAsync(hres, st.cells->build_res, sizeof hres, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess)
             e = hipStreamSynchronize(s);   // (also keeps `center16` alive until the copy is done)
-        lap("placement + sync");
+        lap(fast_built ? "build kernels + placement + sync" : "placement + sync");
+        if (e == hipSuccess && fast_built) {
+            // the fast build's verdict: tiles, items, the largest cell — or a bucket that outgrew its fixed room
+            st.ntiles = hres[0];
+            st.cells->nitems = hres[1];
+            st.cells->max_cell_rows = hres[2];
+            if (hres[3] != 0u || hres[1] == 0u)
+                fast_overflow = true;
+            if (trace)
+                fprintf(stderr, "[knn build] fast build: %u tiles (room for %lld), %u items, largest cell %u rows, overflow %u\n", hres[0], ntiles,
+                        hres[1], hres[2], hres[3]);
+        }
         (void)KNN_DEV_FREE(cell_code);
         (void)KNN_DEV_FREE(cell_fill);
         (void)KNN_DEV_FREE(st.cells->tmp_rows);
@@ -1670,7 +1687,9 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         st.cells->tmp_meta = nullptr;
         st.cells->bucket_start = nullptr;
         (void)KNN_DEV_FREE(dout);
-        if (e != hipSuccess || hout[2] != 0u || hout[3] > ocap) {   // (too many rows outside the box: no layouts from this frame)
+        st.cells->bucket_fill = nullptr;
+        st.cells->build_res = nullptr;
+        if (e != hipSuccess || fast_overflow || hout[2] != 0u || hout[3] > ocap) {   // (too many rows outside the box: no layouts from this frame)
             knn_filter_free(st);
             return e;
         }
@@ -1743,6 +1762,15 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
             FTRY(sorted_layout(center16, sigma, cut_samp, samples / 4, frame));
             if (st.usable)
                 return hipSuccess;
+            if (fast_overflow) {   // a bucket outgrew its fixed room (rows the cuts do not spread evenly): the counted build
+                lap("fast build: bucket overflow");
+                fast_overflow = false;
+                fast_build = false;
+                st = FilterState();
+                FTRY(sorted_layout(center16, sigma, cut_samp, samples / 4, frame));
+                if (st.usable)
+                    return hipSuccess;
+            }
             st = FilterState();   // (declined, or the sampled frame left too many rows out: the classic build decides)
         }
     }

@@ -419,14 +419,16 @@ def test_c3_full_shape_every_query_against_the_oracle(oracle):
 
 @pytest.mark.parametrize("k,dist,n", [(16, "uniform", (1 << 18) + 77), (5, "clustered", 1 << 17), (12, "queries_outside", (1 << 17) + 4097),
                                       (16, "tight_clusters", 1 << 19)])
-def test_one_pass_placement_still_builds_a_correct_layout(oracle, k, dist, n):
-    """`cells_build` 1: the build the two-pass one falls back to when its scratch (n x 72 bytes) does not fit."""
+@pytest.mark.parametrize("build", [1, 2], ids=["one_pass", "counted_two_pass"])
+def test_one_pass_placement_still_builds_a_correct_layout(oracle, k, dist, n, build):
+    """`cells_build` 1: the build the two-pass one falls back to when its scratch (n x 72 bytes) does not fit; 2: the counted
+    two-pass build the fast one (round 5: buckets of fixed room, device prefix) starts over with when a bucket overflows."""
     m = 500
     rng = np.random.default_rng(k + len(dist))
     Q, R = _off_the_cube(rng, dist, k, m, n) if dist == "tight_clusters" else _cases(rng, dist, k, m, n)
     want = oracle.v0(k, Q, R, threads=THREADS)
     pkg.set_option("cells", 1)
-    pkg.set_option("cells_build", 1)
+    pkg.set_option("cells_build", build)
     try:
         ix = pkg.KnnIndex(k, R)
         got, st = _query(ix, Q)
@@ -492,3 +494,29 @@ def test_c3_full_shape_with_either_list_maker(oracle, lists):
     assert st[0] == 4 and st[2] == 0, st
     want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
     np.testing.assert_array_equal(got, want)
+
+
+def test_fast_build_gives_the_layout_the_counted_build_gives(oracle):
+    """Round 5: the fast build (no counting pass, fixed bucket room, tile ranges and items from a device prefix, one
+    synchronisation) must describe the same index as the counted one: same cells, same largest cell, same answers — on data
+    the cuts spread evenly (uniform: the fast path stands) and on data they do not (64 tight clusters: a bucket overflows and
+    the build starts over in the counted form, invisibly to the caller)."""
+    k, m = 16, 512
+    for dist, n in (("uniform", (1 << 20) + 12345), ("tight_clusters", 1 << 20), ("uniform", 1 << 17)):
+        rng = np.random.default_rng(len(dist) + n % 97)
+        Q, R = _off_the_cube(rng, dist, k, m, n) if dist == "tight_clusters" else _cases(rng, dist, k, m, n)
+        want = oracle.v0(k, Q, R, threads=THREADS)
+        seen = {}
+        for build in (0, 2):
+            pkg.set_option("cells", 1)
+            pkg.set_option("cells_build", build)
+            try:
+                ix = pkg.KnnIndex(k, R)
+                got, st = _query(ix, Q)
+                seen[build] = (ix.debug_counters()[2], ix.debug_counters()[3], st[0])
+                ix.close()
+            finally:
+                pkg.set_option("cells", 0)
+                pkg.set_option("cells_build", 0)
+            np.testing.assert_array_equal(got, want, err_msg=f"{dist} n={n} cells_build={build}")
+        assert seen[0] == seen[2] and seen[0][2] == 4, (dist, n, seen)

@@ -77,7 +77,7 @@ def test_option_hooks_reject_unknown_names():
     with pytest.raises(pkg.KnnError):
         pkg.set_option("cells", 3)
     # round 3's switches: every legal value round-trips, the first illegal one is refused
-    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_build", (1, 0)), ("cells_lists", (1, 2, 0)), ("run_thresholds", (1, 2, 0))):
+    for name, legal in (("scan_deal", (1, 2, 0)), ("scan_blocks", (1, 2, 0)), ("cells_build", (1, 2, 0)), ("cells_lists", (1, 2, 0)), ("run_thresholds", (1, 2, 0))):
         for v in legal:
             pkg.set_option(name, v)
             assert pkg.get_option(name) == v, name
