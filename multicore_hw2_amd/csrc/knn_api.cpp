@@ -70,6 +70,7 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
+std::atomic<long long> g_opt_sample_stride{0};   // deep-K scans: stride of the sample pass in tiles, 0 = policy
 std::atomic<long long> g_opt_run_thresholds{0};  // deep-K scan: 0 / 1 running thresholds, 2 off (A/B)
 std::atomic<long long> g_opt_cells_lists{0};     // pruned scan, who lists a cell's queries: 0 auto, 1 the match launch, 2 the scan's own waves
 std::atomic<long long> g_opt_scan_deal{0};       // pruned scan, how waves get their items: 0 auto, 1 fixed deal, 2 block counter
@@ -355,6 +356,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_cells_build = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "sample_stride")) {
+        if (value < 0 || value > 1024)
+            return fail(KNN_EINVAL, "knn_set_option: sample_stride must be in [0, 1024]");
+        g_opt_sample_stride = value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "run_thresholds")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: run_thresholds must be 0 (auto), 1 (on) or 2 (off)");
@@ -428,6 +435,8 @@ long long knn_get_option(const char *name)
         return g_opt_cells_lists;
     if (name && !strcmp(name, "run_thresholds"))
         return g_opt_run_thresholds;
+    if (name && !strcmp(name, "sample_stride"))
+        return g_opt_sample_stride;
     if (name && !strcmp(name, "cells_build"))
         return g_opt_cells_build;
     if (name && !strcmp(name, "rccl_reductions"))   // read-only: cudaCallback merges done by RCCL so far
@@ -884,6 +893,7 @@ int knn_index_query(knn_index *idx, int slot, int m, const float *queries_dev, u
         idx->filter.scan_deal = (int)g_opt_scan_deal;
         idx->filter.cells_lists = (int)g_opt_cells_lists;
         idx->filter.run_thresholds = (int)g_opt_run_thresholds;
+        idx->filter.sample_stride = (int)g_opt_sample_stride;
         idx->last_slot = slot;
         HIP_TRY(knn_filter_query(idx->filter, slot, m, queries_dev, idx->refs, idx->base, (u64 *)keys_dev,
                                  idx->num_cu, s, ev ? ev->first : nullptr, ev ? ev->second : nullptr, init_keys, indices_dev));

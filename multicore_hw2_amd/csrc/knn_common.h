@@ -221,6 +221,7 @@ struct FilterState {
     bool several_slots = false;   // a query has used a workspace slot other than 0: batches are in flight side by side
     int scan_deal = 0;            // pruned scan: 0 auto (block counter unless several_slots), 1 fixed deal, 2 items from a block counter
     int scan_blocks = 0;          // pruned scan, blocks per CU: 0 auto (one for small shards when several_slots, else two), 1, 2
+    int sample_stride = 0;        // deep-K scans (k > 32): tiles the sample pass skips between two it scores; 0 = library policy
     int run_thresholds = 0;       // deep-K scan (64 < k <= 128): 0 / 1 thresholds tighten during the launch, 2 they stay as the sample pass left them
     int cells_lists = 0;          // pruned scan, who lists a cell's queries: 0 auto, 1 knn_cells_match_kernel, 2 the scan's own waves
     FilterWorkspace ws[KNN_SLOTS];

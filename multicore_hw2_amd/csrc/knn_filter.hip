@@ -2427,12 +2427,10 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     // to give it a start — every 32nd tile instead of every 8th at C5 (2048 tiles): the pass shrinks 4x, the candidates grow
     // from 210k to 355k of the 642k a fixed threshold left, ms per step 0.9155 (stride 8) / 0.8909 (16) / 0.8829 (32) / 0.9091
     // (64) / 0.9378 (128) on one box (profiles/r05_c5_running_thresholds.txt).  KNN_MI355X_SAMPLE_STRIDE: the sweep's knob.
-    if (KT == 8 && st.run_thresholds != 2) {
-        static const int stride_env = getenv("KNN_MI355X_SAMPLE_STRIDE") ? atoi(getenv("KNN_MI355X_SAMPLE_STRIDE")) : 0;
+    if (KT == 8 && st.run_thresholds != 2)
         stride = std::min<long long>(32, std::max<long long>(1, st.ntiles / 64));
-        if (stride_env > 0)
-            stride = std::min<long long>(stride_env, std::max<long long>(1, st.ntiles / 16));
-    }
+    if (st.sample_stride > 0)   // option `sample_stride` (the sweep's knob, and the tests' like-for-like comparison)
+        stride = std::min<long long>(st.sample_stride, std::max<long long>(1, st.ntiles / 16));
     const long long ns = (st.ntiles + stride - 1) / stride;
     unsigned sb = gx;
     if ((long long)sb > ns)

@@ -83,6 +83,11 @@ def test_option_hooks_reject_unknown_names():
             assert pkg.get_option(name) == v, name
         with pytest.raises(pkg.KnnError):
             pkg.set_option(name, max(legal) + 1)
+    for v in (8, 32, 1024, 0):                            # deep-K sample pass: tiles skipped (0 = policy)
+        pkg.set_option("sample_stride", v)
+        assert pkg.get_option("sample_stride") == v
+    with pytest.raises(pkg.KnnError):
+        pkg.set_option("sample_stride", 1025)
     # round 3's experiment arms left the product library in round 4 (tools/arms/): their switches are gone with them
     for name in ("cells_variant", "graphs", "deepk"):
         with pytest.raises(pkg.KnnError):

@@ -1191,6 +1191,7 @@ def test_thresholds_that_tighten_during_the_deep_k_launch_keep_every_answer(orac
         for mode in (0, 2):
             pkg.set_option("path", 2)
             pkg.set_option("run_thresholds", mode)
+            pkg.set_option("sample_stride", 8)                            # (like for like: the policy samples less with them on)
             ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
             keys = torch.empty(m, dtype=torch.int64, device=dev)
             out = torch.empty(m, dtype=torch.int32, device=dev)
@@ -1207,6 +1208,7 @@ def test_thresholds_that_tighten_during_the_deep_k_launch_keep_every_answer(orac
     finally:
         pkg.set_option("path", 0)
         pkg.set_option("run_thresholds", 0)
+        pkg.set_option("sample_stride", 0)
     assert records[0] <= records[2], records
     print("run_thresholds %s %s: %d candidates re-ranked with the running thresholds, %d without" % (dist, (k, m, n), records[0], records[2]))
     if dist in ("uniform", "gaussian") and m >= 4096:      # (few queries: every block sees a handful of tiles — nothing to tighten)
