@@ -539,6 +539,15 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
                 if (e == hipSuccess)
                     e = knn_filter_build_from_host(idx->filter, k, n_local, idx->owned_refs, refs, ds.copy, ds.compute);
                 layouts_done = e == hipSuccess;
+            } else if (want_layouts && !grid_planned && want_cells && g_opt_ingest != 1 && g_opt_cells_build == 0 &&
+                       streams_get(device, &ds) == hipSuccess) {
+                // ingest into a cell-sorted index: the fast build's bucket pass under the copy (round 5)
+                e = hipStreamSynchronize(s);   // work the caller queued ahead of this call
+                if (e == hipSuccess)
+                    e = knn_filter_build_cells_from_host(idx->filter, k, n_local, idx->owned_refs, refs, ds.copy, ds.compute);
+                layouts_done = e == hipSuccess && idx->filter.usable;   // (else: the rows are there, the build below sorts them)
+                if (e == hipSuccess && !layouts_done)
+                    knn_filter_free(idx->filter);
             } else {
                 e = hipMemcpyAsync(idx->owned_refs, refs, bytes, hipMemcpyHostToDevice, s);
                 if (e == hipSuccess)

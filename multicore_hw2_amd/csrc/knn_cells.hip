@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void knn_cells_bucket_scatter_kernel(const flo
 // codes worked out from the rows on the fly and parked in LDS, no `code` array — and copies them in bucket order four lanes
 // to a row: every load and store of the copy is a whole 64-byte line (one lane per row was four instructions touching 64
 // different lines each).  The second read of a row comes out of the L2 (the block's rows are 256 KiB).
-__global__ __launch_bounds__(256) void knn_cells_bucket_scatter_fixed_kernel(const float *__restrict__ R, long long n, CellGeom g,
+// R / n: the rows [row0, row0 + n) of the shard (a chunk of an ingest, or all of it): tmeta carries row0 + the row's number in R.
+__global__ __launch_bounds__(256) void knn_cells_bucket_scatter_fixed_kernel(const float *__restrict__ R, long long n, long long row0, CellGeom g,
                                                                              const float *__restrict__ bounds, int bshift, unsigned cap,
                                                                              unsigned *__restrict__ bucket_fill,
                                                                              float *__restrict__ trows, u64 *__restrict__ tmeta,
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void knn_cells_bucket_scatter_fixed_kernel(con
                 // this second read of them)
                 __builtin_nontemporal_store(((const f4v *)(R + (size_t)(i0 + src) * 16))[q], &((f4v *)(trows + pos * 16))[q]);
                 if (q == 0u)
-                    __builtin_nontemporal_store(((u64)c << 32) | (u64)(unsigned)(i0 + src), &tmeta[pos]);
+                    __builtin_nontemporal_store(((u64)c << 32) | (u64)(unsigned)(row0 + i0 + src), &tmeta[pos]);
             }
         }
     } else {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void knn_cells_bucket_scatter_fixed_kernel(con
                 float *__restrict__ t = trows + pos * 16;
                 for (int d = 0; d < g.k; ++d)
                     t[d] = x[d];
-                tmeta[pos] = ((u64)c << 32) | (u64)(unsigned)(i0 + src);
+                tmeta[pos] = ((u64)c << 32) | (u64)(unsigned)(row0 + i0 + src);
             }
         }
     }
@@ -1979,12 +1980,38 @@ void knn_cells_free(CellIndex *&c)
     c = nullptr;
 }
 
+// The fast build in stages (an ingest runs the scatter chunk by chunk under the copy): rows [row0, row1) of the shard, at `r`
+// = the shard's first row on the device.
+hipError_t knn_cells_fast_scatter(CellIndex &c, int k, const float *r, long long row0, long long row1, hipStream_t s)
+{
+    if (row1 <= row0)
+        return hipSuccess;
+    const CellGeom g = cell_geom_of(c, k);
+    const long long rows = row1 - row0;
+    hipLaunchKernelGGL(knn_cells_bucket_scatter_fixed_kernel, dim3((unsigned)((rows + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS)), dim3(256), 0,
+                       s, r + (size_t)row0 * k, rows, row0, g, c.bounds, c.lbits - 8, c.bucket_cap, c.bucket_fill, c.tmp_rows, c.tmp_meta,
+                       c.build_res + 3);
+    return hipGetLastError();
+}
+
+// rows per cell, tile ranges + items (device prefix), fill counters zeroed for the placement
+hipError_t knn_cells_fast_finish(CellIndex &c, unsigned *counts, hipStream_t s)
+{
+    hipLaunchKernelGGL(knn_cells_bucket_cellcount_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, c.tmp_meta, c.bucket_start,
+                       c.lbits - 8, counts, c.bucket_fill);
+    hipLaunchKernelGGL(knn_cells_prefix_kernel, dim3((c.ncells + 1023u) / 1024u), dim3(1024), 0, s, counts, c.ncells, c.tile_start, c.items,
+                       c.build_res);
+    FTRY(hipGetLastError());
+    return hipMemsetAsync(counts, 0, (size_t)c.ncells * sizeof(unsigned), s);   // the counts become the placement's fill counters
+}
+
 // Sorts the shard into cells (see the head of this file).  *out stays null when the shard is too small, the
 // dimension does not suit, or the cuts leave the cells badly unbalanced.  samp: the strided host sample
 // of the build (samples x k).  Synchronous.
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
-                           unsigned **fill_out, bool one_pass, const ShardGeom *geom, int rank, unsigned *bad_rows_out, bool fast)
+                           unsigned **fill_out, bool one_pass, const ShardGeom *geom, int rank, unsigned *bad_rows_out, bool fast,
+                           bool defer_scatter)
 {
     *out = nullptr;
     *code_out = nullptr;
@@ -2036,6 +2063,10 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     // indexes (no shard geometry: their rows' codes are local = global and fit 16 bits) whose scratch fits; everything it
     // launches is asynchronous — the caller reads c->build_res behind the placement and, if a bucket outgrew its fixed room
     // (data the quantile cuts do not spread evenly over the 256 buckets), builds again with fast = false.
+    if (defer_scatter && !(fast && !geom && !one_pass && (size_t)n * 96 <= ((size_t)2 << 30) && c->ncells >= 512u)) {
+        delete c;
+        return hipSuccess;
+    }
     if (fast && !geom && !one_pass && (size_t)n * 96 <= ((size_t)2 << 30) && c->ncells >= 512u) {
         const int bshift_f = lbits - 8;
         // room per bucket: an even spread + 1/2.  The cuts are medians of a 1024-row sample: each is off by ~1.6 % of the rows
@@ -2075,21 +2106,15 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
                 a = hipMemsetAsync(c->bucket_fill, 0, (CELL_BUCKETS + 4) * sizeof(unsigned), s);
             if (a == hipSuccess)
                 a = hipMemsetAsync(counts_f, 0, (size_t)c->ncells * sizeof(unsigned), s);
-            if (a == hipSuccess) {
-                hipLaunchKernelGGL(knn_cells_bucket_scatter_fixed_kernel, dim3((unsigned)((n + CELL_BUILD_ROWS - 1) / CELL_BUILD_ROWS)),
-                                   dim3(256), 0, s, r, n, g, c->bounds, bshift_f, cap_rows, c->bucket_fill, c->tmp_rows, c->tmp_meta,
-                                   c->build_res + 3);
-                hipLaunchKernelGGL(knn_cells_bucket_cellcount_kernel, dim3(CELL_BUCKETS * CELL_PLACE_PARTS), dim3(256), 0, s, c->tmp_meta,
-                                   c->bucket_start, bshift_f, counts_f, c->bucket_fill);
-                hipLaunchKernelGGL(knn_cells_prefix_kernel, dim3((c->ncells + 1023u) / 1024u), dim3(1024), 0, s, counts_f, c->ncells,
-                                   c->tile_start, c->items, c->build_res);
-                a = hipGetLastError();
+            c->lbits = lbits;
+            c->bucket_cap = cap_rows;
+            if (a == hipSuccess && !defer_scatter) {   // (an ingest scatters chunk by chunk as the rows land, then finishes)
+                a = knn_cells_fast_scatter(*c, k, r, 0, n, s);
+                if (a == hipSuccess)
+                    a = knn_cells_fast_finish(*c, counts_f, s);
             }
-            if (a == hipSuccess)   // the counts become the placement's fill counters
-                a = hipMemsetAsync(counts_f, 0, (size_t)c->ncells * sizeof(unsigned), s);
         }
         if (a == hipSuccess) {
-            c->lbits = lbits;
             c->nitems = 0u;   // (the caller fills nitems / max_cell_rows in from build_res)
             *code_out = nullptr;
             *fill_out = counts_f;
@@ -2101,6 +2126,8 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         (void)hipGetLastError();
         (void)KNN_DEV_FREE(counts_f);
         knn_cells_free(c);
+        if (defer_scatter)   // (an ingest has no rows on the device yet: nothing to count — the caller copies, then builds)
+            return hipSuccess;
         c = new CellIndex();
         c->bits = lbits;
         c->ncells = 1u << lbits;

@@ -186,6 +186,7 @@ struct CellIndex {
     // is read by the caller together with the placement's statistics, ONE synchronisation for the whole build
     float h_bounds[16 * 15];            // (host sources of the fast build's asynchronous copies: they must outlive the call)
     unsigned h_bucket_start[257];
+    unsigned bucket_cap = 0;            // records a bucket has room for
     unsigned *bucket_fill = nullptr;    // device [256] (inside the block `bucket_start` points to)
     unsigned *build_res = nullptr;      // device [4]   (likewise)
     // cell-range shards (knn_index_create_sharded): global number of every local row, ascending (borrowed); null: base + row
@@ -242,7 +243,10 @@ struct FilterState {
 hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r_dev, const std::vector<float> &samp,
                            long long samples, hipStream_t s, long long *ntiles_out, unsigned **code_out,
                            unsigned **fill_out, bool one_pass = false, const ShardGeom *geom = nullptr, int rank = 0,
-                           unsigned *bad_rows_out = nullptr, bool fast = false);
+                           unsigned *bad_rows_out = nullptr, bool fast = false, bool defer_scatter = false);
+// The fast build in stages (knn_cells_build with defer_scatter: everything allocated and uploaded, nothing scattered yet).
+hipError_t knn_cells_fast_scatter(CellIndex &c, int k, const float *r_dev, long long row0, long long row1, hipStream_t s);
+hipError_t knn_cells_fast_finish(CellIndex &c, unsigned *counts, hipStream_t s);
 #endif
 // Sizes of one scan launch of the cell-pruned path (knn_cells.hip; host arithmetic only).
 struct CellScanPlan {
@@ -310,6 +314,10 @@ hipError_t knn_gids_check(const unsigned *gids_dev, long long n, unsigned *bad_o
 // Host rows -> device rows (r_dev, n x k floats) + filter layouts, chunk by chunk under the copy.  Synchronous.
 hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
                                       hipStream_t copy, hipStream_t compute);
+// Host rows -> device rows + CELL-SORTED layouts, the fast build's bucket pass under the copy.  Always leaves the rows on the
+// device; st.usable says whether the layouts stand (else the caller builds from the resident rows).  Synchronous.
+hipError_t knn_filter_build_cells_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
+                                            hipStream_t copy, hipStream_t compute);
 void knn_filter_free(FilterState &st);
 // Asynchronous on `stream`: sample pre-pass + MFMA filter + exact re-rank + gated exact fallback.
 // init_keys: the keys are written from scratch ((+INF, 0) first) instead of min-folded into what they hold.

@@ -2136,6 +2136,160 @@ hipError_t knn_filter_build_from_host(FilterState &st, int k, long long n, float
     return knn_filter_build(st, k, n, r_dev, compute);
 }
 
+// ------------------------------------------------------------------------------------------
+// Ingest into a CELL-SORTED index (round 5; SURVEY §8 f1, VERDICT r04 missing 5): host rows -> device rows + the pruned scan's
+// layouts, the bucket pass of the fast build running chunk by chunk UNDER the copy.  Rounds 2-4 copied first and sorted
+// afterwards (the counted build needs every row before it can place one: +2.5 ms behind the last byte at C3, +13 % over the
+// bare copy).  The fast build's buckets have fixed room, so a chunk can be scattered the moment it has landed; what is left
+// behind the last byte is the tail chunk's scatter, the cell prefix and the placement (~0.8 ms).  Box and cuts come from a
+// strided HOST sample of 4096 rows taken before the first byte moves (as knn_filter_build_from_host).
+// Always leaves the rows on the device (r_dev) when it returns hipSuccess; st.usable says whether the layouts stand — if not
+// (a bucket overflowed, the sample was not finite or not representative, no room for the scratch) the caller builds from the
+// resident rows.  Synchronous.
+// ------------------------------------------------------------------------------------------
+hipError_t knn_filter_build_cells_from_host(FilterState &st, int k, long long n, float *r_dev, const float *r_host,
+                                            hipStream_t copy, hipStream_t compute)
+{
+    st = FilterState();
+    const bool trace = getenv("KNN_MI355X_TRACE_BUILD") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[knn ingest] %-36s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    const size_t row_bytes = (size_t)k * sizeof(float);
+    auto plain_copy = [&]() -> hipError_t {
+        FTRY(hipMemcpyAsync(r_dev, r_host, (size_t)n * row_bytes, hipMemcpyHostToDevice, copy));
+        return hipStreamSynchronize(copy);
+    };
+    if (k > 16 || n < (1ll << 17))
+        return plain_copy();
+    // 1. frame and cuts from a host sample
+    const long long samples = 4096, row_stride = n / samples;
+    std::vector<float> samp((size_t)samples * k);
+    for (long long i = 0; i < samples; ++i)
+        memcpy(&samp[(size_t)i * k], r_host + (size_t)(i * row_stride) * k, row_bytes);
+    std::vector<float> center;
+    float sigma = 1.0f;
+    if (!box_from_sample(samp.data(), samples, k, 16, center, &sigma))
+        return plain_copy();
+    std::vector<float> cut_samp((size_t)(samples / 4) * k);
+    for (long long i = 0; i < samples / 4; ++i)
+        memcpy(&cut_samp[(size_t)i * k], &samp[(size_t)(4 * i) * k], row_bytes);
+    lap("host sample, box, cuts");
+    // 2. the fast build, everything but its scatter
+    long long ntiles = 0;
+    unsigned *cell_code = nullptr, *cell_fill = nullptr;
+    FTRY(knn_cells_build(&st.cells, k, n, r_dev, cut_samp, samples / 4, compute, &ntiles, &cell_code, &cell_fill, false, nullptr, 0, nullptr,
+                         true, true));
+    if (!st.cells)
+        return plain_copy();
+    st.k = k;
+    st.kt = 1;
+    st.n = n;
+    st.ntiles = ntiles;   // (room; the build's own count replaces it below)
+    st.sigma = sigma;
+    float center16[16];
+    for (int d = 0; d < 16; ++d)
+        center16[d] = d < k ? center[(size_t)d] : 0.0f;
+    unsigned *dout = nullptr;
+    const unsigned ocap = (unsigned)(n / 32 > 4096 ? n / 32 : 4096);
+    hipError_t e = KNN_DEV_ALLOC((void **)&st.center, 16 * sizeof(float));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * 64 * 16);
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&st.ref_norms2, (size_t)ntiles * 32 * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&st.outliers, (size_t)ocap * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = KNN_DEV_ALLOC((void **)&dout, 4 * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), compute);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(st.center, center16, sizeof center16, hipMemcpyHostToDevice, compute);
+    if (e != hipSuccess) {   // no room for the layouts: rows only (the caller's build will find the same and say so)
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(compute);
+        (void)KNN_DEV_FREE(dout);
+        (void)KNN_DEV_FREE(cell_fill);
+        knn_filter_free(st);
+        return plain_copy();
+    }
+    lap("allocations");
+    // 3. two chunks (see knn_filter_build_from_host: a pageable copy runs at the link rate but every call costs ~0.25 ms of
+    // pipeline fill): everything but the last 64 MiB, then the tail; each is scattered into the buckets as soon as it is there
+    const long long tail_rows = ((long long)((64u << 20) / row_bytes) + 4095) / 4096 * 4096;
+    const long long head_rows = (size_t)n * row_bytes > ((size_t)128u << 20) ? (n - tail_rows) / 4096 * 4096 : n;
+    std::vector<hipEvent_t> events;
+    for (long long r0 = 0; r0 < n && e == hipSuccess;) {
+        const long long r1 = r0 == 0 ? head_rows : n;
+        e = hipMemcpyAsync(r_dev + (size_t)r0 * k, r_host + (size_t)r0 * k, (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice, copy);
+        lap("copy call returned");
+        hipEvent_t ev = nullptr;
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            events.push_back(ev);
+            e = hipEventRecord(ev, copy);
+        }
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(compute, ev, 0);
+        if (e == hipSuccess)
+            e = knn_cells_fast_scatter(*st.cells, k, r_dev, r0, r1, compute);
+        r0 = r1;
+    }
+    // 4. cell prefix, placement, padding — and ONE synchronisation
+    unsigned hout[4] = {0, 0, 0, 0}, hres[4] = {0, 0, 0, 0};
+    if (e == hipSuccess)
+        e = knn_cells_fast_finish(*st.cells, cell_fill, compute);
+    if (e == hipSuccess)
+        e = knn_cells_place_rows(st, r_dev, nullptr, cell_fill, dout, ocap, compute);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hout, dout, sizeof hout, hipMemcpyDeviceToHost, compute);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hres, st.cells->build_res, sizeof hres, hipMemcpyDeviceToHost, compute);
+    const hipError_t e1 = hipStreamSynchronize(copy), e2 = hipStreamSynchronize(compute);
+    lap("streams drained");
+    if (e == hipSuccess)
+        e = e1 != hipSuccess ? e1 : e2;
+    for (hipEvent_t ev : events)
+        (void)hipEventDestroy(ev);
+    (void)KNN_DEV_FREE(cell_fill);
+    (void)KNN_DEV_FREE(st.cells->tmp_rows);
+    (void)KNN_DEV_FREE(st.cells->tmp_meta);
+    (void)KNN_DEV_FREE(st.cells->bucket_start);
+    st.cells->tmp_rows = nullptr;
+    st.cells->tmp_meta = nullptr;
+    st.cells->bucket_start = nullptr;
+    st.cells->bucket_fill = nullptr;
+    st.cells->build_res = nullptr;
+    (void)KNN_DEV_FREE(dout);
+    if (trace)
+        fprintf(stderr, "[knn ingest] fast build under the copy: %u tiles (room for %lld), %u items, largest cell %u rows, overflow %u, outside the box %u\n",
+                hres[0], ntiles, hres[1], hres[2], hres[3], hout[3]);
+    if (e != hipSuccess) {
+        knn_filter_free(st);
+        return e;
+    }
+    if (hres[3] != 0u || hres[1] == 0u || hout[2] != 0u || hout[3] > ocap) {   // the caller builds from the resident rows
+        knn_filter_free(st);
+        return hipSuccess;
+    }
+    st.ntiles = hres[0];
+    st.cells->nitems = hres[1];
+    st.cells->max_cell_rows = hres[2];
+    st.n_outliers = hout[3];
+    memcpy(&st.bmax, &hout[0], 4);
+    memcpy(&st.nmax, &hout[1], 4);
+    st.usable = true;
+    return hipSuccess;
+}
+
 static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
 {
     if (!w.ctl) {
