@@ -70,6 +70,7 @@ std::atomic<long long> g_opt_filter_rounds{0};
 std::atomic<long long> g_opt_filter_chain{0};
 std::atomic<long long> g_opt_stream{0};
 std::atomic<long long> g_opt_scan_blocks{0};     // pruned scan, blocks per CU: 0 auto, 1, 2
+std::atomic<long long> g_last_cells{0};          // read-only: shards of the most recent cudaCallback that were served by the pruned scan
 std::atomic<long long> g_opt_sample_stride{0};   // deep-K scans: stride of the sample pass in tiles, 0 = policy
 std::atomic<long long> g_opt_run_thresholds{0};  // deep-K scan: 0 / 1 running thresholds, 2 off (A/B)
 std::atomic<long long> g_opt_cells_lists{0};     // pruned scan, who lists a cell's queries: 0 auto, 1 the match launch, 2 the scan's own waves
@@ -445,6 +446,8 @@ long long knn_get_option(const char *name)
         return knn_rccl_comm_sets();
     if (name && !strcmp(name, "last_shards"))       // read-only: GPUs / shards the most recent cudaCallback was split over
         return g_last_shards;
+    if (name && !strcmp(name, "last_cells"))        // read-only: how many of them the pruned scan served
+        return g_last_cells;
     if (name && !strcmp(name, "rccl_version"))      // read-only: NCCL_VERSION_CODE of the loaded RCCL, 0 if none
         return knn_rccl_version();
     return -1;
@@ -453,7 +456,7 @@ long long knn_get_option(const char *name)
 }  // extern "C"
 
 namespace {
-// build_filter: 1 build the MFMA filter layouts, 0 do not, -1 library policy
+// build_filter: 1 build the MFMA filter layouts, 2 build them cell-sorted (the pruned scan), 0 do not, -1 library policy
 // build_grid (k <= 4): 1 build the grid index, 0 do not, -1 library policy
 int index_create_impl(knn_index **out, int device, int k, long long n_local, const float *refs,
                       int refs_on_device, long long base_index, void *stream, int build_filter, int build_grid = -1);
@@ -510,7 +513,8 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     // hold most of the batch and the full scan's register-resident loop is the faster way to score them.
     const long long cells_from = k <= 12 ? (1ll << 19) : (1ll << 20);
     const bool want_cells = k <= 16 && n_local >= (1ll << 17) &&
-                            (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));
+                            (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter == 2) ||
+                             (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));
     if (build_filter < 0) {
         // library policy: shards of >= 65536 rows; for 32 < k <= 4096 (3k+3 exact lane-ops per pair,
         // one query per lane above k = 64, row-per-lane kernels above 128) the MFMA filter pays off from 4096 rows already
@@ -1272,6 +1276,16 @@ ShardPlan plan_shard(int k, int m, long long rows)
     const double t_filter_under_copy = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // host rows: layouts built under the copy
     p.want_filter = g_opt_path == 2 ||
                     (g_opt_path == 0 && m >= 5 && kt != 0 && (g_opt_ingest == 1 ? t_filter : t_filter_under_copy) < t_exact);
+    // The pruned scan for a one-shot call (round 5: the cell sort's bucket pass runs under the copy, knn_filter_build_cells_from_host):
+    // ~1.0 ms per 2^24 rows stay behind the last byte (cell prefix + placement) where the plain layouts leave 0.07, and a
+    // batch of 1024 queries then costs 0.04 ms + 6.5 ps per row instead of 3.4e-14 s per pair — it repays the sort from about
+    // 2500 queries on at C3's size (measured: one batch 0.145 ms against 0.58).  Where the library's own policy puts
+    // resident indexes on the cells (k <= 16, >= 2^19 / 2^20 rows), and only with the default build options.
+    // (same fixed costs as the plain layouts' line above, so that the two differ by what differs)
+    const double t_cells_query = 6e-4 + 1.0e-3 * (double)rows / 16777216.0 + ceil(m / 1024.0) * (4e-5 + 6.5e-12 * (double)rows) + 1e-4;
+    if (p.want_filter && g_opt_path == 0 && g_opt_cells == 0 && g_opt_ingest == 0 && g_opt_cells_build == 0 && k <= 16 &&
+        rows >= (k <= 12 ? (1ll << 19) : (1ll << 20)) && (double)rows * 96.0 <= 2147483648.0 && t_cells_query < t_filter_under_copy)
+        p.want_filter = 2;
     // Third option: the exact scan chunk by chunk under the copy: costs the longer of the two plus one chunk's scan.  The
     // staged alternatives pay the copy in one piece; the filter layouts are then built under the copy's tail
     // (knn_filter_build_from_host), leaving the query itself.
@@ -1283,7 +1297,7 @@ ShardPlan plan_shard(int k, int m, long long rows)
     p.nchunks = (int)nchunks;
     p.t_streamed = std::max(t_h2d, t_exact) + t_exact / nchunks + kCopyCall * nchunks + 1e-4;
     const double t_filter_query = 6e-4 + 3.4e-14 * kt * pairs + 1e-4;   // layouts under the copy + query
-    const double t_query = p.want_filter ? (g_opt_ingest == 1 ? t_filter : t_filter_query) : t_exact;
+    const double t_query = p.want_filter == 2 ? t_cells_query : p.want_filter ? (g_opt_ingest == 1 ? t_filter : t_filter_query) : t_exact;
     const double t_grid = k <= 4 ? 1.5e-4 + 1.5e-10 * (double)rows + 2e-8 * m : 1e30;
     p.want_grid = k <= 4 && (g_opt_path == 3 || (g_opt_path == 0 && rows >= 65536 && t_grid < t_query));
     p.t_staged = t_h2d + kCopyCall + (p.want_grid ? t_grid : t_query);
@@ -1354,6 +1368,7 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
     if (shards > n)
         shards = n;
     g_last_shards = shards;
+    g_last_cells = 0;
     static const bool trace = getenv("KNN_MI355X_TRACE_CALL") != nullptr;
     if (trace)
         fprintf(stderr, "[knn call] k %d m %d n %d: %d GPU(s) visible -> %lld shard(s)%s\n", k, m, n, ndev, shards,
@@ -1446,6 +1461,8 @@ extern "C" void cudaCallback(int k, int m, int n, float *searchPoints, float *re
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == KNN_OK)
             rc = query_keys_host(idx, m, searchPoints, keys.data(), keep_dev);
+        if (rc == KNN_OK && idx->stats[0] == 4)
+            ++g_last_cells;
         const auto t2 = std::chrono::steady_clock::now();
         knn_index_destroy(idx);
         if (trace) {
