@@ -929,6 +929,8 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 #define CELL_SCAN_WAVES 12
 #define CELL_SCAN_CHUNK 256   // slots of a block's share whose tile ranges and list lengths sit in LDS at a time (DYN)
 #define CELL_INLINE_RERANK_MAX 64u   // records a scan wave re-ranks itself; a longer list is left to the tail kernel
+#define CELL_PUBLISH_STEP 64u             // records between two publications of a wave's count to the batch's counter
+#define CELL_BATCH_RECORD_LIMIT (1u << 19)   // records of a batch beyond which it goes to the exact evaluation of its listed pairs
 #define CELL_SCAN_RUN 16      // DYN: consecutive items a block takes at a time; its next run lies gridDim.x runs further on
 
 // One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
@@ -1008,6 +1010,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         ctl_next[KNN_CTL_SCAN_DONE] = 0u;
         ctl_next[KNN_CTL_DEFERRED] = 0u;
         ctl_next[KNN_CTL_TAIL_DONE] = 0u;
+        ctl_next[KNN_CTL_TOTAL] = 0u;
     }
     const int half = lane >> 5;
     const size_t frag_at = (size_t)(qi >> 5) * 64 + (size_t)half * 32 + (size_t)(qi & 31);
@@ -1518,7 +1521,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             unsigned nq;
             if constexpr (SELF) {
                 __builtin_amdgcn_wave_barrier();   // the previous item's reads of the list room are done
-                nq = cell_self_list(self, cellj, m, s_dup, my_list, lane);
+                nq = cell_self_list(self.lo_t, self.hi, self.sa, m_padded, cellj, m, s_dup, my_list, lane);
                 wave_lds_sync();
                 if (nq == 0u)   // (wave-uniform) nobody wants this cell
                     continue;
@@ -1612,7 +1615,35 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                                     // instructions of exec bookkeeping.
                                     dead = obase + (total - first_over) > ovf_cap;
                                 }
+                                const unsigned steps_new = (total / CELL_PUBLISH_STEP - cnt / CELL_PUBLISH_STEP) * CELL_PUBLISH_STEP;
                                 cnt = total;
+                                // Is this a batch the fp16 scores cannot separate (rows of a cluster tighter than the fp16 step:
+                                // millions of candidates)?  Then it goes to the exact evaluation of its listed pairs, which costs
+                                // the same whatever was recorded, and every record and tile step from here on is wasted — round 4
+                                // noticed only when a wave's own slice AND the shared area were full, i.e. when all 6144 slices
+                                // were (64 tight clusters: 3.6 M records, scan 69 -> 183 us).  Now: every 64th wave publishes its
+                                // count in steps of CELL_PUBLISH_STEP records (a SAMPLE of the batch's total: a returning atomic on
+                                // one word costs ~26 ns and they queue — all waves publishing took the scan to 0.4 ms); when the
+                                // sample says CELL_BATCH_RECORD_LIMIT is passed, the publisher marks the shared area over-full, and
+                                // every wave looks at that word (an agent-scope load, no atomic) whenever its own count crosses a
+                                // step.  A clean batch — a few records per wave — never gets here.
+                                // (not in the self-listing variant: its registers are all taken — 8 bytes of scratch with this in —
+                                // and it serves shards of <= 2^13 cells one batch at a time, where the slices are large)
+                                if (!SELF && steps_new != 0u && ovf_cap != 0u) {   // wave-uniform
+                                    if ((wave & 63u) == 0u) {
+                                        unsigned seen = 0u;
+                                        if (lane == 0)
+                                            seen = atomicAdd(&ctl[KNN_CTL_TOTAL], steps_new) + steps_new;
+                                        seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+                                        if (seen > CELL_BATCH_RECORD_LIMIT / 64u) {
+                                            if (lane == 0)
+                                                atomicMax(&ctl[KNN_CTL_RECORDS], ovf_cap + 1u);   // what the tail kernel reads as "over-full"
+                                            dead = true;
+                                        }
+                                    } else if (__hip_atomic_load(&ctl[KNN_CTL_RECORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ovf_cap) {
+                                        dead = true;
+                                    }
+                                }
                             }
                         }
                     }

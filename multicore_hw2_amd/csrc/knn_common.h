@@ -67,7 +67,8 @@ enum {
     KNN_CTL_SCAN_DONE = 9,   // cell-pruned path: blocks of the scan that have finished (the last one finalises a clean batch)
     KNN_CTL_TAIL_DONE = 10,  // cell-pruned path: blocks of the tail kernel that have finished
     KNN_CTL_DEFERRED = 11,   // cell-pruned path, != 0: some wave of the scan left a long record list to the tail kernel
-    KNN_CTL_WORDS = 12
+    KNN_CTL_TOTAL = 12,      // cell-pruned path: records the scan's waves have published so far (steps of 64 per wave)
+    KNN_CTL_WORDS = 13
 };
 
 #define KNN_SLOTS 8  // independent query workspaces per index: up to eight batches may be in flight

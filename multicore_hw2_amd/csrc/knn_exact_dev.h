@@ -220,11 +220,12 @@ struct CellSelf {
 
 // -> the list's length; entries beyond CELL_SELF_CAP are counted, not stored.  `dupv`: the batch's Dup values (LDS in the
 // scan, global memory in the tail kernel).  The caller orders the LDS writes against its reads (wave_lds_sync in knn_cells.hip).
-__device__ __forceinline__ unsigned cell_self_list(const CellSelf &sf, unsigned cell, int m, const float *__restrict__ dupv,
+__device__ __forceinline__ unsigned cell_self_list(const float *__restrict__ lo_t, const float *__restrict__ hi_t, int sa, int m_padded,
+                                                   unsigned cell, int m, const float *__restrict__ dupv,
                                                    unsigned short *__restrict__ my_list, int lane)
 {
-    const float *__restrict__ lrow = sf.lo_t + (size_t)(cell & ((1u << sf.sa) - 1u)) * sf.m_padded;
-    const float *__restrict__ hrow = sf.hi + (size_t)(cell >> sf.sa) * sf.m_padded;
+    const float *__restrict__ lrow = lo_t + (size_t)(cell & ((1u << sa) - 1u)) * m_padded;
+    const float *__restrict__ hrow = hi_t + (size_t)(cell >> sa) * m_padded;
     unsigned nq = 0u;
     for (int q0 = 0; q0 < m; q0 += 64 * CELL_SELF_GROUP) {   // (wave-uniform)
         float lo[CELL_SELF_GROUP], hi[CELL_SELF_GROUP];
@@ -275,7 +276,7 @@ __device__ __forceinline__ void cells_exact_items(
         const unsigned short *__restrict__ list;
         if (self.lo_t) {   // (kernel-uniform)
             __builtin_amdgcn_wave_barrier();   // the previous item's reads of the list are done
-            nq = cell_self_list(self, cell, m, self.dup, my_list, lane);
+            nq = cell_self_list(self.lo_t, self.hi, self.sa, self.m_padded, cell, m, self.dup, my_list, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
