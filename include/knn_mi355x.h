@@ -220,14 +220,15 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             2 = host merge always.
  *             knn_get_option("rccl_reductions") counts the merges RCCL has done,
  *             knn_get_option("rccl_version") is the loaded library's NCCL_VERSION_CODE (0: none)
- *   "cells"   the MFMA filter's cell-pruned form (k <= 16): the index sorts the shard into 2^B cells (every
- *             dimension cut at sample quantiles), and a batch scores only the cells each query could not
- *             rule out by its distance to the cell's box.  0 = library policy: indexes created with
- *             knn_index_create of >= 2^19 rows (k <= 12) or >= 2^20 rows (k = 13 .. 16); for the one-shot
+ *   "cells"   the MFMA filter's cell-pruned form (k <= 32): the index sorts the shard into 2^B cells (every
+ *             dimension — the first 16 when k > 16 — cut at sample quantiles), and a batch scores only the cells each query
+ *             could not rule out by its distance to the cell's box.  0 = library policy: indexes created with
+ *             knn_index_create of >= 2^19 rows (k <= 12), >= 2^20 rows (k = 13 .. 16), >= 2^22 rows (k = 17 .. 20) or
+ *             >= 2^24 rows (k = 21, 22; beyond that too few cells are ruled out for the pruned scan to win); for the one-shot
  *             cudaCallback on shards of that size when the cost model says the batch repays the sort (the bucket pass of
  *             the sort runs under the host-to-device copy, ~1 ms per 2^24 rows stays behind the last byte: from about
  *             2500 queries on at n = 2^24; knn_get_option("last_cells") counts the shards of the most recent call
- *             that the pruned scan served).  1 = every index of >= 2^17 rows,
+ *             that the pruned scan served).  1 = every index of >= 2^17 rows (k <= 32),
  *             cudaCallback's shards included; 2 = never.  Read when an index is created; 2 also makes
  *             existing indexes use the full scan.  Any distribution keeps its cells: a cell of many rows
  *             (clustered, low-rank data) is cut into several work items, empty cells cost nothing.  A batch

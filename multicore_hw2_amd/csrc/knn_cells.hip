@@ -99,7 +99,7 @@ static void cell_quantile_cuts(int k, const unsigned char nb[16], const float *s
     std::vector<float> col((size_t)samples);
     for (int i = 0; i < 16 * (CELL_MAX_BINS - 1); ++i)
         bounds[i] = INFINITY;
-    for (int d = 0; d < k; ++d) {
+    for (int d = 0; d < std::min(k, 16); ++d) {   // (16 < k <= 32: the cells cut the first 16 dimensions only)
         if (!nb[d])
             continue;
         for (long long i = 0; i < samples; ++i)
@@ -208,12 +208,73 @@ __global__ __launch_bounds__(256) void knn_cells_code_kernel(const float *__rest
         return;
     const float *__restrict__ x = R + (size_t)i * g.k;
     unsigned c = 0u;
-    for (int d = 0; d < g.k; ++d)
+    for (int d = 0; d < min(g.k, 16); ++d)
         if (g.nb[d])
             c |= cell_bin(bounds + d * (CELL_MAX_BINS - 1), 1 << g.nb[d], x[d]) << g.shift[d];
     c = cell_local(c, g, bad);
     code[i] = c;
     atomicAdd(&counts[c], 1u);
+}
+
+// The one-pass placement for 16 < k <= 32 (two K-steps per tile: fragments [tile][2][64 lanes][8], round 5): what
+// knn_cells_scatter_frag_kernel does for k <= 16, with the row's 32 (padded) dimensions as four 8-wide halves.
+__global__ __launch_bounds__(256) void knn_cells_scatter_frag2_kernel(
+    const float *__restrict__ R, long long n, int k, const unsigned *__restrict__ code,
+    const unsigned *__restrict__ tile_start, unsigned *__restrict__ fill, const float *__restrict__ center, float sigma,
+    h8 *__restrict__ frag, float *__restrict__ norms, unsigned *__restrict__ norms2, unsigned *__restrict__ perm,
+    unsigned *__restrict__ out, unsigned *__restrict__ olist, unsigned ocap)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float vmax = 0.0f, nrm = 0.0f;
+    if (i < n) {
+        const float *__restrict__ x = R + (size_t)i * k;
+        bool real = true;
+        h8 v[4];
+#pragma unroll
+        for (int part = 0; part < 4; ++part)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = part * 8 + j;
+                const float sc = d < k ? (x[d] - center[d]) * sigma : 0.0f;  // fp32 subtract, exact power-of-two scale
+                const _Float16 hval = (_Float16)sc;                          // round to nearest even
+                const float back = (float)hval;
+                real = real && fabsf(back) <= 1.0f;                          // outside the robust box, NaN included
+                vmax = fmaxf(vmax, fabsf(back));
+                nrm = nrm + back * back;                                     // exact products, fp32 sum in dimension order
+                v[part][j] = hval;
+            }
+        if (!real) {   // out of the filter (zero fragment, +INF norm), into the exact list
+            const unsigned opos = atomicAdd(&out[3], 1u);
+            if (opos < ocap)
+                olist[opos] = (unsigned)i;
+#pragma unroll
+            for (int part = 0; part < 4; ++part)
+                v[part] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            vmax = 0.0f;
+            nrm = 0.0f;
+        }
+        const unsigned c = code[i];
+        const size_t pos = (size_t)tile_start[c] * 32 + atomicAdd(&fill[c], 1u);
+        h8 *__restrict__ tile = frag + (pos >> 5) * 128;   // two K-steps of 64 lanes
+#pragma unroll
+        for (int part = 0; part < 4; ++part)
+            tile[(part >> 1) * 64 + (part & 1) * 32 + (pos & 31)] = v[part];
+        norms[pos] = real ? nrm : INFINITY;
+        norms2[pos] = pack_norm22(real ? nrm : INFINITY);
+        perm[pos] = (unsigned)i;
+    }
+    vmax = wave_max_f(vmax);
+    nrm = wave_max_f(nrm);
+    __shared__ float s_v[4], s_n[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = vmax;
+        s_n[threadIdx.x >> 6] = nrm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        guarded_atomic_max(&out[0], __float_as_uint(fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]))));
+        guarded_atomic_max(&out[1], __float_as_uint(fmaxf(fmaxf(s_n[0], s_n[1]), fmaxf(s_n[2], s_n[3]))));
+    }
 }
 
 // Scatter + layout in one pass (k <= 16): row i, read in row order, goes to the next free position of its
@@ -753,15 +814,15 @@ __global__ __launch_bounds__(256) void knn_cells_place_kernel(
 // placed).  Rounds 2-3 memset the whole layout first: 0.76 GB of writes for 46 MB of padding at C3.
 __global__ __launch_bounds__(256) void knn_cells_pad_kernel(const unsigned *__restrict__ tile_start, const unsigned *__restrict__ fill,
                                                             unsigned ncells, h8 *__restrict__ frag, float *__restrict__ norms,
-                                                            unsigned *__restrict__ norms2, unsigned *__restrict__ perm)
+                                                            unsigned *__restrict__ norms2, unsigned *__restrict__ perm, int kt)
 {
     const unsigned c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, j = threadIdx.x & 31u;   // 32 threads per cell: at most 31 pads
     if (c >= ncells)
         return;
     const size_t pos = (size_t)tile_start[c] * 32 + fill[c] + j, end = (size_t)tile_start[c + 1u] * 32;
     if (pos < end) {
-        frag[(pos >> 5) * 64 + (pos & 31)] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-        frag[(pos >> 5) * 64 + 32 + (pos & 31)] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < 2 * kt; ++t)   // (kt K-steps x two halves of 32 lanes)
+            frag[(pos >> 5) * 64 * kt + t * 32 + (pos & 31)] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
         norms[pos] = INFINITY;
         norms2[pos] = 0x00007C00u;
         perm[pos] = 0xFFFFFFFFu;
@@ -934,18 +995,21 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 #define CELL_SCAN_RUN 16      // DYN: consecutive items a block takes at a time; its next run lies gridDim.x runs further on
 
 // One (tile, block of 32 listed queries) step: scores + min tree + threshold test -> hit mask.
-__device__ __forceinline__ u64 cell_tile_step(const h8 &a, const f4v *__restrict__ my_nrm, int p, int half, const h8 &b, float th)
+template <int KT>
+__device__ __forceinline__ u64 cell_tile_step(const h8 (&a)[KT], const f4v *__restrict__ my_nrm, int p, int half, const h8 (&b)[KT], float th)
 {
-    f16v c;
+    f16v d;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         const f4v v = my_nrm[p * 8 + 2 * gq + half];
-        c[4 * gq + 0] = v[0];
-        c[4 * gq + 1] = v[1];
-        c[4 * gq + 2] = v[2];
-        c[4 * gq + 3] = v[3];
+        d[4 * gq + 0] = v[0];
+        d[4 * gq + 1] = v[1];
+        d[4 * gq + 2] = v[2];
+        d[4 * gq + 3] = v[3];
     }
-    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], b[kk], d, 0, 0, 0);
     const float mn = min_tree16(d, th);
     return __ballot(mn < th);
 }
@@ -980,8 +1044,10 @@ struct SeedLayer {
 //     2 = 4 cells (what ships; a cell of this index WHOLE, a cell of another rank through the seed layer's few tiles).  The
 //     kernel is generic in SD: 4 = 16 cells leaves fewer survivors (profiles/r04_shard_sim.txt: 236 cells per query and
 //     rank at N = 8 against 399, 199 with the bound one GPU would have) but measured slower end to end (knn_cells_query).
-template <int PW, int SD>
-__global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
+// KT: K-steps of a tile, 1 (k <= 16) or 2 (16 < k <= 32, round 5: the cuts, the gaps and the tables cover the first 16
+//     dimensions; the fragments and the seed scores all of them)
+template <int PW, int SD, int KT = 1>
+__global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
     const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
     const float *__restrict__ center, float sigma, const unsigned *__restrict__ tile_start, long long ntiles,
     const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, SeedLayer layer, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
@@ -992,6 +1058,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
 {
 #pragma clang fp contract(off)
     constexpr int SEEDS = 1 << SD, NS = SEEDS / PW;   // seed cells in all, per wave
+    constexpr int PREP_TILES = KT == 1 ? CELL_PREP_TILES : 4;   // seed tiles a wave requests at once (KT KiB each)
     __shared__ float s_gap[16][CELL_MAX_BINS];
     __shared__ float s_red[PW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1013,10 +1080,13 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         ctl_next[KNN_CTL_TOTAL] = 0u;
     }
     const int half = lane >> 5;
-    const size_t frag_at = (size_t)(qi >> 5) * 64 + (size_t)half * 32 + (size_t)(qi & 31);
+    const size_t frag_at = (size_t)(qi >> 5) * 64 * KT + (size_t)half * 32 + (size_t)(qi & 31);   // (+ 64 per K-step)
     if (qi >= m) {   // padding query of the last tile (block-uniform): never listed, never passes
-        if (wib == 0 && (lane & 31) == 0)
-            qfg[frag_at] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (wib == 0 && (lane & 31) == 0) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+                qfg[frag_at + 64 * t] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
         if (tid == 0) {
             thr[qi] = -INFINITY;
             dup_out[qi] = -INFINITY;
@@ -1031,9 +1101,9 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
     const float *__restrict__ qrow = Q + (size_t)qi * g.k;
     float nrm = 0.0f, amax = 0.0f;
     bool qbad = false;
-    h8 bq;
+    h8 bq[KT];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) {
+    for (int d = 0; d < 16 * KT; ++d) {
         float sc = 0.0f;
         if (d < g.k)
             sc = (qrow[d] - center[d]) * sigma;   // fp32 subtract, exact power-of-two scale
@@ -1044,17 +1114,20 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         nrm = nrm + back * back;                  // exact products, fp32 sum in dimension order
         const _Float16 v = (_Float16)(back * -2.0f);
         qbad = qbad || !(fabsf((float)v) < INFINITY);
-        if ((d >> 3) == half)
-            bq[d & 7] = v;
+        if (((d >> 3) & 1) == half)
+            bq[d >> 4][d & 7] = v;
     }
-    if (wib == 0 && (lane & 31) == 0)
-        qfg[frag_at] = bq;   // for the scan (lanes 0 and 32 hold the two halves)
+    if (wib == 0 && (lane & 31) == 0) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+            qfg[frag_at + 64 * t] = bq[t];   // for the scan (lanes 0 and 32 hold the two halves of every K-step)
+    }
 
     // ---- squared gaps to every bin of every dimension (scaled units, rounded down): 256 entries over the block's threads
     for (int e = tid; e < 256; e += 64 * PW) {
         const int d = e >> 4, b = e & 15;
         float v = 0.0f;
-        if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {
+        if (d < g.k && g.nb[d] && b < (1 << g.nb[d])) {   // (d < 16: e < 256)
             const int nbins = 1 << g.nb[d];
             const float *__restrict__ bnd = bounds + d * (CELL_MAX_BINS - 1);
             const double q = (double)qrow[d];
@@ -1071,7 +1144,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
     // query's own bin and the neighbouring bin nearest to it
     unsigned bin = 0u, alt = 0xFFFFFFFFu, nbl = 0u, shl = 0u;
     float ag = INFINITY;
-    if (lane < g.k) {
+    if (lane < g.k && lane < 16) {   // (the cells cut the first 16 dimensions)
         nbl = g.nb[lane];
         shl = g.shift[lane];
     }
@@ -1139,9 +1212,9 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
             // against the 32 of everybody else's, and the launch lasted as long as those blocks: 36 us against 15)
             if (SD > 2 && lane >= 4)
                 v_nt = min(v_nt, (unsigned)CELL_OUTER_SEED_TILES);
-            v_fa = (unsigned long long)(rf + (size_t)tb * 64);
+            v_fa = (unsigned long long)(rf + (size_t)tb * 64 * KT);
             v_na = (unsigned long long)(rn2 + (size_t)tb * 32);
-        } else if (layer.base) {
+        } else if (KT == 1 && layer.base) {
             unsigned part = 0u;   // the rank whose range holds the cell (a table walk: no 64-bit divisions in here)
             for (unsigned r = 1u; r < layer.nranks; ++r)
                 part += code >= layer.first[r] ? 1u : 0u;
@@ -1192,11 +1265,11 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         for (int c = 0; c < NS; ++c)
             start[c + 1] = start[c] + cnt[c];
         const unsigned total = start[NS];
-        for (unsigned v0 = 0u; v0 < total; v0 += CELL_PREP_TILES) {
-            h8 ar[CELL_PREP_TILES];
-            unsigned nw[CELL_PREP_TILES];
+        for (unsigned v0 = 0u; v0 < total; v0 += PREP_TILES) {
+            h8 ar[PREP_TILES][KT];
+            unsigned nw[PREP_TILES];
 #pragma unroll
-            for (int p = 0; p < CELL_PREP_TILES; ++p) {
+            for (int p = 0; p < PREP_TILES; ++p) {
                 const unsigned v = v0 + (unsigned)p;   // position in the list -> (run, tile of the run)
                 nw[p] = 0u;
                 if (v < total) {
@@ -1211,16 +1284,20 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
                             vv = v - start[c];
                         }
                     const size_t t = (size_t)vv * st;
-                    ar[p] = ((const h8 *)f)[t * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk)
+                        ar[p][kk] = ((const h8 *)f)[(t * KT + kk) * 64 + lane];
                     if (lane < 32)
                         nw[p] = ((const unsigned *)nn)[t * 32 + lane];
                 }
             }
 #pragma unroll
-            for (int p = 0; p < CELL_PREP_TILES; ++p)
+            for (int p = 0; p < PREP_TILES; ++p)
                 if (v0 + (unsigned)p < total) {
-                    const f16v c = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw[p]), norm_b_operand(), zero_acc(), 0, 0, 0);
-                    const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p], bq, c, 0, 0, 0);
+                    f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw[p]), norm_b_operand(), zero_acc(), 0, 0, 0);
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk)
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p][kk], bq[kk], d, 0, 0, 0);
                     um = min_tree16(d, um);
                 }
         }
@@ -1268,7 +1345,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
                 cnt[c] = 0u;
                 stride[c] = 1u;
             }
-            fa[0] = (unsigned long long)(rf + (size_t)mine_first * wstride * 64);
+            fa[0] = (unsigned long long)(rf + (size_t)mine_first * wstride * 64 * KT);
             na[0] = (unsigned long long)(rn2 + (size_t)mine_first * wstride * 32);
             cnt[0] = min(64u / PW, total - mine_first);
             stride[0] = wstride;
@@ -1293,7 +1370,7 @@ __global__ __launch_bounds__(64 * PW, 4) void knn_cells_prep_kernel(   // (4 wav
         if (!bad && !(u < INFINITY))
             bad = true;        // no row of the filter seen: cannot bound
         if (!bad) {
-            const BoundConsts cst = knn_bound_consts(g.k, 1, sigma, amax, bmax, nmax);
+            const BoundConsts cst = knn_bound_consts(g.k, KT, sigma, amax, bmax, nmax);
             double dup = 0.0;
             t = knn_threshold(cst, u, nrm, &dup);
             if (!(t < INFINITY))
@@ -1360,8 +1437,11 @@ extern "C" int knn_debug_scan_stamps(unsigned long long *out)
 // K: 16 = compile-time dimension of the inline re-rank, 0 = run-time k <= 16
 // SELF: the waves make the lists of their own items (cell_self_list, knn_exact_dev.h) — no match launch in front of the scan;
 //       cell_counts / lists are unused and `cap` is CELL_SELF_CAP
-template <bool DYN, int K, bool SELF>
-__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel(
+// KT:   K-steps of a tile: 1 (k <= 16), 2 (16 < k <= 32, round 5: tiles of 2 KiB, four per pass instead of nine, two MFMAs per
+//       step, batches of 512 queries — their B operands are 64 bytes each —; K = 0 there: the inline re-rank walks k in chunks
+//       of 16 dimensions)
+template <bool DYN, int K, bool SELF, int KT = 1>
+__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cells_scan_kernel(   // (KT = 2: 96 registers — 80 left it 12 bytes of scratch)
     const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
@@ -1373,11 +1453,12 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
-    h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][64]
-    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32);            // [m_padded]
-    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * 36);                // [waves][CELL_TILES_PER_PASS * 8]
+    constexpr int TPP = KT == 1 ? CELL_TILES_PER_PASS : 4;              // reference tiles a wave holds in registers at a time
+    h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][KT][64]
+    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32 * KT);       // [m_padded]
+    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * (32 * KT + 4));     // [waves][TPP * 8]
     // SELF: the batch's Dup values and one list room per wave behind the norm windows (knn_cells_scan_plan sizes it)
-    float *s_dup = (float *)(s_dyn + (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v));   // [m_padded]
+    float *s_dup = (float *)(s_dyn + (size_t)m_padded * (32 * KT + 4) + (size_t)CELL_SCAN_WAVES * TPP * 8 * sizeof(f4v));   // [m_padded]
     unsigned short *s_lists = (unsigned short *)(s_dup + m_padded);     // [waves][CELL_SELF_CAP]
     __shared__ unsigned s_flag;
     SCAN_STAMP(0);
@@ -1439,7 +1520,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
     }
     // (LDS-DMA for this fill — no staging registers — measured: C3 -0.5 %, a rank of 8 +5 % per pipelined step.  Not taken.)
-    for (int i = threadIdx.x; i < m_padded * 2; i += 64 * CELL_SCAN_WAVES)
+    for (int i = threadIdx.x; i < m_padded * 2 * KT; i += 64 * CELL_SCAN_WAVES)
         s_qf[i] = qfg[i];
     for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
         s_thr[i] = thrg[i];
@@ -1450,7 +1531,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
     if (s_flag != 0u)
         return;
     SCAN_STAMP(1);
-    f4v *my_nrm = s_nrm + wib * (CELL_TILES_PER_PASS * 8);
+    f4v *my_nrm = s_nrm + wib * (TPP * 8);
     unsigned short *my_list = s_lists + (SELF ? wib * (int)CELL_SELF_CAP : 0);
 
     u64 *__restrict__ my_rec = rec + (size_t)wave * slice;
@@ -1544,21 +1625,28 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             // (round 3: blocks three and four of the list too — lists average 120 entries on the 2^21-row shards of an
             // 8-GPU run, and every block beyond the second was a dependent read from memory)
             const unsigned l1 = SELF ? 0u : dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
-            for (unsigned t0 = tb; t0 < te && !dead; t0 += CELL_TILES_PER_PASS) {
-                const int nt = (int)min((unsigned)CELL_TILES_PER_PASS, te - t0);   // wave-uniform
-                h8 ar[CELL_TILES_PER_PASS];
+            for (unsigned t0 = tb; t0 < te && !dead; t0 += TPP) {
+                const int nt = (int)min((unsigned)TPP, te - t0);   // wave-uniform
+                h8 ar[TPP][KT];
 #pragma unroll
-                for (int p = 0; p < CELL_TILES_PER_PASS; ++p)
-                    if (p < nt)
-                        ar[p] = __builtin_nontemporal_load(&rf[(size_t)(t0 + (unsigned)p) * 64 + lane]);
+                for (int p = 0; p < TPP; ++p)
+                    if (p < nt) {
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk)
+                            ar[p][kk] = __builtin_nontemporal_load(&rf[((size_t)(t0 + (unsigned)p) * KT + kk) * 64 + lane]);
+                    }
                 {
                     const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
                     const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
-                    const f4v n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
+                    f4v n1 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (TPP * 8 > 64)
+                        n1 = 64 + lane < nt * 8 ? __builtin_nontemporal_load(&rn4[64 + lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
                     __builtin_amdgcn_wave_barrier();   // the previous pass's reads of the window are done
-                    my_nrm[lane] = n0;
-                    if (lane < CELL_TILES_PER_PASS * 8 - 64)
-                        my_nrm[64 + lane] = n1;
+                    if (TPP * 8 >= 64 || lane < TPP * 8)
+                        my_nrm[lane] = n0;
+                    if constexpr (TPP * 8 > 64)
+                        if (lane < TPP * 8 - 64)
+                            my_nrm[64 + lane] = n1;
                     wave_lds_sync();
                 }
                 for (unsigned q0 = 0u; q0 < nq && !dead; q0 += 32u) {
@@ -1576,14 +1664,17 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
                     } else {
                         qid = dense ? (valid ? idx : 0u) : (unsigned)list[valid ? idx : 0u];
                     }
-                    const h8 b = s_qf[(qid >> 5) * 64u + (unsigned)half * 32u + (qid & 31u)];
+                    h8 b[KT];
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk)
+                        b[kk] = s_qf[((qid >> 5) * KT + (unsigned)kk) * 64u + (unsigned)half * 32u + (qid & 31u)];
                     const float th = valid ? s_thr[qid] : -INFINITY;
                     // (a hit is recorded right behind its tile: parking the nine masks of a pass until its end, as round 2
                     // did, kept 18 registers busy with them — the allocator put the mask pairs in VGPRs)
 #pragma unroll
-                    for (int p = 0; p < CELL_TILES_PER_PASS; ++p) {
+                    for (int p = 0; p < TPP; ++p) {
                         if (p < nt) {
-                            const u64 mask = cell_tile_step(ar[p], my_nrm, p, half, b, th);
+                            const u64 mask = cell_tile_step<KT>(ar[p], my_nrm, p, half, b, th);
                             if (__builtin_expect(mask != 0ull, 0)) {
                                 const bool hit = (mask >> lane) & 1ull;
                                 const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
@@ -1689,23 +1780,26 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
             const unsigned row = live && pos < npos ? perm[pos] : 0xFFFFFFFFu;   // ~0u: padding position
             const float *__restrict__ qp = Q + (size_t)qi * k;
             constexpr int KD = K > 0 ? K : 16;
-            float qv[KD], rv[KD];
-#pragma unroll
-            for (int d = 0; d < KD; ++d)
-                qv[d] = d < k ? qp[d] : 0.0f;
             const u64 cur = keys[qi];   // (may be stale: keys[] only ever decreases, a stale read costs a spare atomic)
             const float *__restrict__ rp = R + (size_t)(row != 0xFFFFFFFFu ? row : 0u) * k;
-#pragma unroll
-            for (int d = 0; d < KD; ++d)
-                rv[d] = d < k ? rp[d] : 0.0f;
             float acc = 0.0f;
 #pragma unroll
-            for (int d = 0; d < KD; ++d)
-                if (d < k) {   // v0's order and operations: diff, square, add (no contraction)
-                    const float diff = qv[d] - rv[d];
-                    const float sq = diff * diff;
-                    acc = acc + sq;
-                }
+            for (int ch = 0; ch < KT; ++ch) {   // (KT = 2: dimensions 16 .. 31 behind 0 .. 15, the same registers again)
+                float qv[KD], rv[KD];
+#pragma unroll
+                for (int d = 0; d < KD; ++d)
+                    qv[d] = 16 * ch + d < k ? qp[16 * ch + d] : 0.0f;
+#pragma unroll
+                for (int d = 0; d < KD; ++d)
+                    rv[d] = 16 * ch + d < k ? rp[16 * ch + d] : 0.0f;
+#pragma unroll
+                for (int d = 0; d < KD; ++d)
+                    if (16 * ch + d < k) {   // v0's order and operations: diff, square, add (no contraction)
+                        const float diff = qv[d] - rv[d];
+                        const float sq = diff * diff;
+                        acc = acc + sq;
+                    }
+            }
             u64 key = row != 0xFFFFFFFFu && acc < INFINITY ? pack_key(acc, (unsigned)(base + (long long)row)) : ~0ull;
             // (ds_swizzle's xor mode, not __shfl_xor: that one wants every lane's number in a register, computed at the top of
             // the kernel and kept across the item loop — 4 bytes of scratch under the 80-register cap)
@@ -1759,7 +1853,8 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, 6) void knn_cells_scan_kernel
 //                                                                                 here (exact_qreg_body); other k: the gated
 //                                                                                 exact launch in front of this one has run
 //   fin.defer                                                                  -> only the finalisation
-template <int K>
+// KT (with K = 0): run-time k <= 16 KT
+template <int K, int KT = 1>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
     const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long nrows, long long npos, long long base,
     const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
@@ -1788,7 +1883,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_cells_tail_kernel(
         if (have > ovf_cap) {
             if (blockIdx.x == 0 && threadIdx.x == 0)
                 ctl[KNN_CTL_EXACT_CELLS] = 1u;   // (statistics: knn_index_last_stats[2] = 2)
-            cells_exact_items<K>(Q, R, krt, m, base, items, nitems, cell_counts, lists, cap, perm, keys,
+            cells_exact_items<K, KT>(Q, R, krt, m, base, items, nitems, cell_counts, lists, cap, perm, keys,
                                  blockIdx.x * (unsigned)KNN_WAVES + (threadIdx.x >> 6), gridDim.x * (unsigned)KNN_WAVES, self,
                                  &s_tail_list[threadIdx.x >> 6][0]);
         } else {
@@ -2049,8 +2144,15 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     *fill_out = nullptr;
     if (bad_rows_out)
         *bad_rows_out = 0u;
-    if (k > 16 || n > 0x7FFFFFFFll || (!geom && (n < (1ll << 17) || samples < 64)))
+    // (16 < k <= 32, round 5: the cells cut the first 16 dimensions — a lower bound over some dimensions is one over all —
+    // and the layout has two K-steps per tile; one-pass placement, no shard geometry)
+    if (k > 32 || (k > 16 && geom) || n > 0x7FFFFFFFll || (!geom && (n < (1ll << 17) || samples < 64)))
         return hipSuccess;
+    const int kc = std::min(k, 16);   // dimensions the cells may cut
+    if (k > 16) {
+        one_pass = true;
+        fast = false;
+    }
     CellIndex *c = new CellIndex();
     std::vector<float> bounds((size_t)16 * (CELL_MAX_BINS - 1), INFINITY);
     if (geom) {
@@ -2068,14 +2170,14 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
             return hipSuccess;
         }
     } else {
-        const int bits = std::min(cell_bits_for_rows(n), std::min(16, 4 * k));
+        const int bits = std::min(cell_bits_for_rows(n), std::min(16, 4 * kc));
         if (bits < 9) {
             delete c;
             return hipSuccess;
         }
         c->bits = bits;
         c->ncells = 1u << bits;
-        cell_grid_shape(k, bits, c->nb, c->shift, &c->sa);
+        cell_grid_shape(kc, bits, c->nb, c->shift, &c->sa);
         if (c->sa < 6) {   // a wave of the match pass covers 64 consecutive low-table entries
             delete c;
             return hipSuccess;
@@ -2085,6 +2187,8 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
     // in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
     c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
+    if (k > 16)   // (more dimensions, fewer cells ruled out: lists of ~100-200 of 1024 queries at k = 20 — 128 entries made most cells dense)
+        c->cap = std::min(1024u, std::max(384u, (1u << 24) / c->ncells));
     const CellGeom g = cell_geom_of(*c, k);
     int lbits = 0;   // bits of a LOCAL cell number (= bits without a shard geometry)
     while ((1u << lbits) < c->ncells)
@@ -2099,7 +2203,6 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         return hipSuccess;
     }
     if (fast && !geom && !one_pass && (size_t)n * 96 <= ((size_t)2 << 30) && c->ncells >= 512u) {
-        const int bshift_f = lbits - 8;
         // room per bucket: an even spread + 1/2.  The cuts are medians of a 1024-row sample: each is off by ~1.6 % of the rows
         // (1 sigma), a bucket is the product of 8 such halves — 1 sigma 9 %, the fullest of 256 buckets ~27 % over the mean on
         // uniform data (measured: + 1/8 overflowed at C3)
@@ -2162,7 +2265,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         c = new CellIndex();
         c->bits = lbits;
         c->ncells = 1u << lbits;
-        cell_grid_shape(k, lbits, c->nb, c->shift, &c->sa);
+        cell_grid_shape(kc, lbits, c->nb, c->shift, &c->sa);
         c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
     }
     unsigned *code = nullptr, *counts = nullptr;
@@ -2333,13 +2436,17 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
                            st.cells->tmp_meta, st.cells->bucket_start, st.k, st.cells->lbits - 8, st.cells->tile_start, fill, st.center, st.sigma,
                            (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, out, st.outliers, ocap,
                            (const unsigned *)st.cells->bucket_fill);
+    else if (st.kt == 2)
+        hipLaunchKernelGGL(knn_cells_scatter_frag2_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
+                           st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,
+                           st.cells->perm, out, st.outliers, ocap);
     else
         hipLaunchKernelGGL(knn_cells_scatter_frag_kernel, dim3((unsigned)((st.n + 255) / 256)), dim3(256), 0, s, r, st.n, st.k, code,
                            st.cells->tile_start, fill, st.center, st.sigma, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2,
                            st.cells->perm, out, st.outliers, ocap);
     FTRY(hipGetLastError());
     hipLaunchKernelGGL(knn_cells_pad_kernel, dim3((st.cells->ncells + 7u) / 8u), dim3(256), 0, s, st.cells->tile_start, fill,
-                       st.cells->ncells, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm);
+                       st.cells->ncells, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, st.kt);
     return hipGetLastError();
 }
 
@@ -2387,7 +2494,7 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
 //   slice    records [w x slice, (w + 1) x slice) belong to wave w
 //   ovf      records [ovf_base, ovf_base + ovf_cap) are the area all waves share; nlists x slice <= ovf_base
 //   lds      dynamic LDS of the scan: m_padded x (32 B operand + 4 B threshold) + one norm window per wave
-CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded, bool self_lists)
+CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded, bool self_lists, int kt)
 {
     CellScanPlan p;
     p.blocks = (unsigned)num_cu * (unsigned)blocks_per_cu;
@@ -2401,7 +2508,9 @@ CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems,
     p.ovf_cap = std::min(rec_cap / 4u, 1u << 16);
     p.ovf_base = rec_cap - p.ovf_cap;
     p.slice = p.ovf_base / p.nlists;
-    p.lds_bytes = (size_t)m_padded * 36 + (size_t)CELL_SCAN_WAVES * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    // (16 < k <= 32: 64-byte B operands and windows of four tiles: 74 KiB for 1024 queries — two blocks still share a CU's
+    // 160 KiB; the launch raises the kernel's dynamic-LDS limit above the default 64 KiB)
+    p.lds_bytes = (size_t)m_padded * (32 * kt + 4) + (size_t)CELL_SCAN_WAVES * (kt == 1 ? CELL_TILES_PER_PASS : 4) * 8 * sizeof(f4v);
     if (self_lists)   // the self-listing scan: the batch's Dup values + one list room per wave
         p.lds_bytes += (size_t)m_padded * sizeof(float) + (size_t)CELL_SCAN_WAVES * CELL_SELF_CAP * sizeof(unsigned short);
     return p;
@@ -2442,8 +2551,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 32768u);
     // Who makes the cells' lists of queries: knn_cells_match_kernel in a launch of its own (rounds 2-4), or the scan's waves
     // for the items they take (round 5, cell_self_list).  Policy in knn_cells_lists_policy.
-    const bool self_lists = st.cells_lists == 2 || (st.cells_lists == 0 && knn_cells_lists_policy(c.ncells, st.several_slots));
-    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded, self_lists);
+    const bool self_lists = st.kt == 1 && (st.cells_lists == 2 || (st.cells_lists == 0 && knn_cells_lists_policy(c.ncells, st.several_slots)));
+    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded, self_lists, st.kt);
     const unsigned gx = plan.blocks;
     w.nlists = plan.nlists;
     w.ovf_cap = plan.ovf_cap;
@@ -2467,8 +2576,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
             layer.first[r_] = c.geom->first_cell(r_);
         layer.part_bytes = c.geom->part_bytes();
     }
-#define KNN_PREP_LAUNCH(PWV, SDV)                                                                                          \
-    hipLaunchKernelGGL((knn_cells_prep_kernel<PWV, SDV>), dim3((unsigned)m_padded), dim3(64 * PWV), 0, s, q, m, m_padded, g, \
+#define KNN_PREP_LAUNCH(PWV, SDV, KTV)                                                                                     \
+    hipLaunchKernelGGL((knn_cells_prep_kernel<PWV, SDV, KTV>), dim3((unsigned)m_padded), dim3(64 * PWV), 0, s, q, m, m_padded, g, \
                        c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,            \
                        st.ref_norms2, layer, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr,    \
                        w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init, self_lists ? 1 : 0)
@@ -2477,10 +2586,15 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     // of dependent round trips, and at a rank's size the step is made of those — emulated rank of N = 8, ms per step / one
     // batch at a time: 16 cells x 2 tiles 0.0302 / 0.0526, 8 x 2 0.0279 / 0.0493, 4 x 2 0.0275 / 0.0471, 4 x 4 0.0271 / 0.0473;
     // N = 4: 0.0432 / 0.0423 / 0.0414 / 0.0408.  profiles/r04_seed_sweep.txt)
-    if (st.several_slots)
-        KNN_PREP_LAUNCH(2, 2);
+    if (st.kt == 2) {
+        if (st.several_slots)
+            KNN_PREP_LAUNCH(2, 2, 2);
+        else
+            KNN_PREP_LAUNCH(4, 2, 2);
+    } else if (st.several_slots)
+        KNN_PREP_LAUNCH(2, 2, 1);
     else
-        KNN_PREP_LAUNCH(4, 2);
+        KNN_PREP_LAUNCH(4, 2, 1);
 #undef KNN_PREP_LAUNCH
     FTRY(hipGetLastError());
     if (self_lists) {
@@ -2545,8 +2659,8 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     fin.out_idx = out_idx;
     fin.defer = st.n_outliers != 0u ? 1 : 0;
     const long long npos = st.ntiles * 32;
-#define KNN_SCAN_LAUNCH(DYNV, KV, SELFV)                                                                                   \
-    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV, SELFV>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, \
+#define KNN_SCAN_LAUNCH(DYNV, KV, SELFV, ...)                                                                              \
+    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV, SELFV, ##__VA_ARGS__>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, \
                        st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded, w.cell_counts,        \
                        w.cell_lists, list_cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap, q, r, st.k, \
                        c.perm, npos, base, keys, fin, self)
@@ -2557,7 +2671,18 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         else                                                                                                               \
             KNN_SCAN_LAUNCH(DYNV, 0, SELFV);                                                                               \
     } while (0)
-    if (dyn) {
+    if (st.kt == 2) {   // 16 < k <= 32: run-time k, lists from the match launch
+        if (lds > (size_t)(64u << 10)) {   // (more than the default limit of dynamic LDS: say so, per launch — the attribute is per device)
+            if (dyn)
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<true, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            else
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<false, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (dyn)
+            KNN_SCAN_LAUNCH(true, 0, false, 2);
+        else
+            KNN_SCAN_LAUNCH(false, 0, false, 2);
+    } else if (dyn) {
         if (self_lists)
             KNN_SCAN_LAUNCH_K(true, true);
         else
@@ -2582,15 +2707,18 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         unsigned blocks = (unsigned)num_cu * 8u;
         if (blocks * KNN_WAVES > c.nitems)
             blocks = std::max(2u, (c.nitems + KNN_WAVES - 1u) / KNN_WAVES);
-#define KNN_TAIL_LAUNCH(KV)                                                                                                \
-    hipLaunchKernelGGL(knn_cells_tail_kernel<KV>, dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, st.n, npos, base, c.items,  \
+#define KNN_TAIL_LAUNCH(...)                                                                                               \
+    hipLaunchKernelGGL((knn_cells_tail_kernel<__VA_ARGS__>), dim3(blocks), dim3(KNN_BLOCK), 0, s, q, r, st.k, m, st.n, npos, base, c.items,  \
                        c.nitems, w.cell_counts, w.cell_lists, list_cap, c.perm, w.records, w.ovf_base, w.ovf_cap, w.ctl_cur, \
                        keys, fin, w.counts, w.nlists, w.slice, self)
-        switch (st.k) {
-        case 16: KNN_TAIL_LAUNCH(16); break;
-        case 8: KNN_TAIL_LAUNCH(8); break;
-        default: KNN_TAIL_LAUNCH(0); break;
-        }
+        if (st.kt == 2)
+            KNN_TAIL_LAUNCH(0, 2);
+        else
+            switch (st.k) {
+            case 16: KNN_TAIL_LAUNCH(16); break;
+            case 8: KNN_TAIL_LAUNCH(8); break;
+            default: KNN_TAIL_LAUNCH(0); break;
+            }
 #undef KNN_TAIL_LAUNCH
     }
     return hipGetLastError();

@@ -234,7 +234,8 @@ struct FilterState {
 };
 
 // ---- cell-pruned form of the filter (knn_cells.hip) -----------------------------------------
-#define KNN_CELL_BATCH 1024   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS
+#define KNN_CELLS_AUTO_MAX_K 22   // library policy: cell-sorted layouts for resident indexes up to this dimension (`cells` = 1: up to 32)
+#define KNN_CELL_BATCH 1024   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS (68 KiB for 16 < k <= 32)
 #ifdef __cplusplus
 #include <vector>
 // Cell codes + counts of the shard (cuts from the strided host sample of the build).  *out stays null when the
@@ -255,7 +256,7 @@ struct CellScanPlan {
     size_t lds_bytes = 0;
 };
 CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded,
-                                 bool self_lists = false);
+                                 bool self_lists = false, int kt = 1);
 bool knn_cells_lists_policy(unsigned ncells, bool several_slots);
 hipError_t knn_cells_place_rows(FilterState &st, const float *r_dev, const unsigned *code, unsigned *fill, unsigned *out,
                                 unsigned ocap, hipStream_t s);

@@ -256,7 +256,8 @@ __device__ __forceinline__ unsigned cell_self_list(const float *__restrict__ lo_
 
 // self.lo_t != null: the batch's lists are not in memory (the scan made its own) — this wave makes the list of every item it
 // takes the same way, in `my_list` (CELL_SELF_CAP entries of LDS per wave); cell_counts / lists are then unused.
-template <int K>
+// KT (with K = 0): run-time k <= 16 KT
+template <int K, int KT = 1>
 __device__ __forceinline__ void cells_exact_items(
     const float *__restrict__ Q, const float *__restrict__ R, int krt, int m, long long base,
     const u64 *__restrict__ items, unsigned nitems, const unsigned *__restrict__ cell_counts,
@@ -264,7 +265,7 @@ __device__ __forceinline__ void cells_exact_items(
     u64 *__restrict__ keys, unsigned wave, unsigned nwaves, const CellSelf &self, unsigned short *__restrict__ my_list)
 {
 #pragma clang fp contract(off)
-    constexpr int KD = K > 0 ? K : 16;
+    constexpr int KD = K > 0 ? K : 16 * KT;
     const int k = K > 0 ? K : krt;
     const int lane = threadIdx.x & (KNN_WAVE - 1);
     for (unsigned it = wave; it < nitems; it += nwaves) {

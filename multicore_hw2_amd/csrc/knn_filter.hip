@@ -1622,8 +1622,8 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
                              const std::function<bool(float *, float *)> &late_frame) -> hipError_t {
         long long ntiles = 0;
         unsigned *cell_code = nullptr, *cell_fill = nullptr;
-        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles, &cell_code, &cell_fill, want_cells == 2, geom, rank, bad_rows_out,
-                             fast_build));
+        FTRY(knn_cells_build(&st.cells, k, n, r, samp, samples, s, &ntiles, &cell_code, &cell_fill, want_cells == 2 || kt == 2, geom, rank,
+                             bad_rows_out, fast_build && kt == 1));
         lap(st.cells ? (st.cells->build_res ? "buckets + cell prefix (enqueued)" : "cell codes + counts") : "cell codes (not kept)");
         if (!st.cells)
             return hipSuccess;
@@ -1634,14 +1634,14 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
             return hipSuccess;
         }
         st.k = k;
-        st.kt = 1;
+        st.kt = kt;   // (1, or 2 for 16 < k <= 32)
         st.n = n;
         st.ntiles = ntiles;
         st.sigma = sigma;
         unsigned *dout = nullptr;
-        hipError_t e = KNN_DEV_ALLOC((void **)&st.center, 16 * sizeof(float));
+        hipError_t e = KNN_DEV_ALLOC((void **)&st.center, (size_t)16 * kt * sizeof(float));
         if (e == hipSuccess)
-            e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * 64 * 16);
+            e = KNN_DEV_ALLOC(&st.ref_frags, (size_t)ntiles * kt * 64 * 16);
         if (e == hipSuccess)
             e = KNN_DEV_ALLOC((void **)&st.ref_norms, (size_t)ntiles * 32 * sizeof(float));
         if (e == hipSuccess)
@@ -1654,7 +1654,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         if (e == hipSuccess)
             e = hipMemsetAsync(dout, 0, 4 * sizeof(unsigned), s);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(st.center, center16, 16 * sizeof(float), hipMemcpyHostToDevice, s);
+            e = hipMemcpyAsync(st.center, center16, (size_t)16 * kt * sizeof(float), hipMemcpyHostToDevice, s);
         lap("allocations");
         unsigned hout[4] = {0, 0, 0, 0}, hres[4] = {0, 0, 0, 0};
         const bool fast_built = st.cells->build_res != nullptr;
@@ -1709,7 +1709,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         memcpy(center16, geom->center, sizeof center16);
         return sorted_layout(center16, geom->sigma, none, 0, nullptr);
     }
-    if (want_cells && kt == 1 && n >= (1ll << 17)) {
+    if (want_cells && kt <= 2 && n >= (1ll << 17)) {
         // Round 4: the frame of a cell-sorted layout from a strided SAMPLE of the rows (4096 of them: range widened by 1 / 32,
         // median / MAD box inside it — what knn_filter_build_from_host does for host rows), not from a pass over the whole
         // shard: the full-range statistics kernel read 1 GiB for a box that any representative sample gives, and its round
@@ -1735,11 +1735,11 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         std::vector<float> center;
         float sigma = 1.0f;
         bool box_ok = false;
-        std::thread boxer([&] { box_ok = box_from_sample(samp.data(), samples, k, 16, center, &sigma); });
+        std::thread boxer([&] { box_ok = box_from_sample(samp.data(), samples, k, 16 * kt, center, &sigma); });
         std::vector<float> cut_samp((size_t)(samples / 4) * k);   // (the cuts from every fourth sample row, 1024 as before)
         for (long long i = 0; i < samples / 4; ++i)
             memcpy(&cut_samp[(size_t)i * k], &samp[(size_t)(4 * i) * k], (size_t)k * sizeof(float));
-        float center16[16] = {0};
+        float center16[32] = {0};   // (16 kt entries used)
         struct Joiner {   // (every way out of this block waits for the thread)
             std::thread &t;
             ~Joiner()
@@ -1753,7 +1753,7 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
                 boxer.join();
             if (!box_ok)
                 return false;
-            for (int d = 0; d < 16; ++d)
+            for (int d = 0; d < 16 * kt; ++d)
                 c16[d] = d < k ? center[(size_t)d] : 0.0f;
             *sg = sigma;
             return true;
@@ -2722,14 +2722,15 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     // raises its own FALLBACK flag on the device and is answered by the gated exact scan; the next batch is back on
     // the pruned path.  (Round 2 sent the whole index to full scans for 256 calls after such a batch, on a pinned
     // host word read here whenever the host happened to get to it.)
-    const bool cells = st.cells && st.cells_policy != 2 && st.kt == 1;
+    const bool cells = st.cells && st.cells_policy != 2 && st.kt <= 2;
     w.last_used_cells = cells;
     w.ev_begin = ev_begin;
     w.ev_end = ev_end;
     if (cells) {
-        FTRY(ensure_workspace(st, w, std::min(m, KNN_CELL_BATCH)));
-        for (int q0 = 0; q0 < m; q0 += KNN_CELL_BATCH) {
-            const int mb = std::min(KNN_CELL_BATCH, m - q0);
+        const int cell_batch = KNN_CELL_BATCH;   // (the scan's LDS holds a pass's B operands: 36 KiB, 68 KiB for 16 < k <= 32)
+        FTRY(ensure_workspace(st, w, std::min(m, cell_batch)));
+        for (int q0 = 0; q0 < m; q0 += cell_batch) {
+            const int mb = std::min(cell_batch, m - q0);
             const float *qb = q + (size_t)q0 * st.k;
             u64 *kb = keys + q0;
             FTRY(knn_cells_query(st, w, mb, qb, r, base, kb, num_cu, q0 == 0, s, init_keys, out_idx ? out_idx + q0 : nullptr));

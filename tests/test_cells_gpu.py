@@ -535,3 +535,49 @@ def test_drop_in_takes_the_pruned_path_when_the_batch_repays_the_sort(oracle):
         assert pkg.get_option("last_shards") == 1 and pkg.get_option("last_cells") == cells, (m, pkg.get_option("last_cells"))
         sel = np.random.default_rng(m).choice(m, min(m, 512), replace=False)
         np.testing.assert_array_equal(got[sel], oracle.v0(k, Q[sel], R, threads=THREADS), err_msg=f"m={m}")
+
+
+@pytest.mark.parametrize("k", [17, 18, 20, 24, 29, 32])
+@pytest.mark.parametrize("dist,n,m", [("uniform", (1 << 18) + 77, 700), ("uniform", 1 << 20, 1024), ("clustered", 1 << 17, 600),
+                                      ("copies", (1 << 17) + 7, 513), ("queries_outside", 1 << 18, 64), ("tight_clusters", 1 << 20, 1024)])
+def test_pruned_scan_for_17_to_32_dimensions_is_bit_exact(oracle, k, dist, n, m):
+    """Round 5 (VERDICT r04 missing 2): 16 < k <= 32 on the pruned path — the cells cut the first 16 dimensions (a lower bound
+    over some dimensions is one over all of them), tiles hold two K-steps, batches go through in passes of 512 queries.  Until
+    now k = 17 fell from the pruned scan's 0.12 ms to the full scan's 0.55 (n = 2^24).  Same bar: v0's indices, on ties (copies),
+    on queries outside the box, on a batch that ends in the exact evaluation of its listed pairs (tight clusters)."""
+    rng = np.random.default_rng(k * 13 + len(dist) + m)
+    Q, R = _off_the_cube(rng, dist, k, m, n) if dist == "tight_clusters" else _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("path", 2)
+    pkg.set_option("cells", 1)
+    try:
+        ix = pkg.KnnIndex(k, R, base_index=7)
+        got, st = _query(ix, Q)
+        again, _ = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("path", 0)
+        pkg.set_option("cells", 0)
+    np.testing.assert_array_equal(got - 7, want, err_msg=f"{dist} k={k} stats={st}")
+    np.testing.assert_array_equal(again, got)
+    assert st[0] == 4, st
+
+
+def test_c3_shape_with_20_dimensions_every_query_on_the_pruned_path(oracle):
+    """k = 20, m = 1024, n = 2^24 (C3's shape with four more dimensions): library policy puts it on the pruned scan since round
+    5 (two K-steps per tile, cuts on the first 16 dimensions); every answer against the oracle."""
+    k, m, n = 20, 1024, 1 << 24
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
+    pkg.synth_fill_device(r_d.data_ptr(), n * k, 1001, device=0, stream=stream)
+    torch.cuda.synchronize()
+    Q = oracle.synth(m * k, 1000).reshape(m, k)
+    ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True, stream=stream)
+    try:
+        got, st = _query(ix, Q)
+    finally:
+        ix.close()
+    assert st[0] == 4 and st[2] == 0, st
+    want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
+    np.testing.assert_array_equal(got, want)

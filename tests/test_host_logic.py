@@ -153,9 +153,10 @@ def test_hot_kernels_of_the_pruned_path_use_no_scratch_memory(tmp_path):
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert scratch == 0, (name, scratch)
         if "scan" in name:
-            assert vgprs <= 80, (name, vgprs)       # six waves per SIMD: 512 / 6 rounded down to the allocation granule
+            two_k_steps = re.search(r"scan_kernelILb[01]ELi\d+ELb[01]ELi2E", name) is not None      # 16 < k <= 32 (round 5)
+            assert vgprs <= (96 if two_k_steps else 80), (name, vgprs)   # six (five) waves per SIMD: 512 / 6 rounded down to the allocation granule
         seen += 1
-    assert seen >= 10, seen
+    assert seen >= 16, seen
     # a block counts itself done (ctl[SCAN_DONE] = word 9 in the scan, ctl[TAIL_DONE] = word 10 in the tail
     # kernel) only after every wave's own atomics on keys[] / ctl[] have been performed: the barrier in front of the counter's
     # add is preceded by `s_waitcnt vmcnt(0)` with no vector-memory instruction in between.  (The workgroup-scope release fence
