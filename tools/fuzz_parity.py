@@ -2,7 +2,7 @@
 """Randomised differential test of the drop-in entry against the CPU oracle: random shapes,
 distributions, paths, shard counts and one-shot strategies.  usage: fuzz_parity.py [cases] [seed]
 (FUZZ_BIG=1: large shapes, 48 sampled queries checked per case; FUZZ_CELLS=1: the cell-pruned scan — shards of
->= 2^17 rows, k <= 16, `cells` = 1, through the drop-in entry and through a resident index queried twice)
+>= 2^17 rows, k <= 32, `cells` = 1, through the drop-in entry and through a resident index queried twice)
 Exit status 1 on the first mismatch (prints the case so it can be replayed)."""
 import os
 import sys
@@ -111,7 +111,7 @@ def cells_case(o, rng, case):
     """The cell-pruned scan: cells forced on, every distribution (incl. ties, clusters, non-finite values), the
     drop-in entry and a resident index that answers two different batches (the second sees whatever the
     first left in the workspace: lists, flags, the pinned switch-off word)."""
-    k = int(rng.choice([3, 5, 8, 12, 15, 16]))
+    k = int(rng.choice([3, 5, 8, 12, 15, 16, 16, 17, 19, 20, 27, 32]))   # (round 5: 16 < k <= 32 — two K-steps per tile)
     m = int(rng.choice([1, 7, 33, 100, 257, 1000, 1024, 1300]))
     n = int(rng.choice([1 << 17, 150001, 262144, 400000, 600000, 1200000, 1 << 21]))
     kind = str(rng.choice(["uniform", "gauss", "offset", "grid", "clusters", "heavy", "tight", "lowrank", "mixture", "onepoint"]))
@@ -122,8 +122,11 @@ def cells_case(o, rng, case):
     else:
         Q = make_data(rng, kind, m, k)
     deal, blocks = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    lists, build = int(rng.integers(0, 3)), int(rng.integers(0, 3))   # round 5: who lists the cells' queries, how the layout is built
     pkg.set_option("scan_deal", deal)
     pkg.set_option("scan_blocks", blocks)
+    pkg.set_option("cells_lists", lists)
+    pkg.set_option("cells_build", build)
     Q2 = make_data(rng, "uniform" if kind in ("tight", "lowrank", "mixture", "onepoint") else str(rng.choice(["uniform", kind])), m, k)
     if rng.random() < 0.3:
         Q[: min(m, 8)] = R[rng.integers(0, n, min(m, 8))]
@@ -131,7 +134,7 @@ def cells_case(o, rng, case):
         R[rng.integers(0, n), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3e38]))
     if rng.random() < 0.1:
         Q2[rng.integers(0, m), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, 1e30]))
-    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, deal=deal, blocks=blocks)
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, deal=deal, blocks=blocks, lists=lists, build=build)
     if os.environ.get("FUZZ_VERBOSE") == "1":
         print("case", desc, "%.1f s" % time.time(), flush=True)
     pkg.set_option("cells", 1)
@@ -166,7 +169,7 @@ def main():
             if case % 25 == 24:
                 print("%d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
     finally:
-        for name in ("path", "shards", "stream", "cells", "scan_deal", "scan_blocks"):
+        for name in ("path", "shards", "stream", "cells", "scan_deal", "scan_blocks", "cells_lists", "cells_build"):
             pkg.set_option(name, 0)
     print("all %d cases bit-exact (seed %d)" % (cases, seed))
     return 0
