@@ -290,6 +290,10 @@ int knn_index_debug_counters(knn_index *idx, long long out[4]);
 /* Test hook (host arithmetic only, no GPU needed): the number of GPUs a cudaCallback(k, m, n, ...) is split over on a
  * node with ndev visible devices — the reference's rule (core.cu:865-872) plus the library's cost model. */
 int knn_debug_shard_policy(int k, int m, long long n, int ndev);
+/* Test hook (host arithmetic only): how ONE shard of `rows` rows of a one-shot cudaCallback(k, m, ...) would be served under the
+ * current options: out = {filter layouts (0 none: exact kernels, 1 plain, 2 cell-sorted: the pruned scan), 1 if the exact scan
+ * runs chunk by chunk under the copy, 1 if the grid index (k <= 4) serves it, copy calls of the streamed form}. */
+int knn_debug_plan_shard(int k, int m, long long rows, long long out[4]);
 
 /* Test hook (host arithmetic only, no GPU needed): every size one scan launch of the cell-pruned path and the re-rank behind
  * it index with, for an index of `nitems` work items on a device of num_cu CUs and a batch of m <= 1024 queries:

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "knn_index_query_host", "knn_set_option", "knn_get_option", "knn_index_last_stats",
     "knn_synth_fill_device", "knn_index_timing", "knn_index_timing_read",
     "knn_debug_filter_scores", "knn_index_query_keys_slot", "knn_trim", "knn_keys_allreduce_min",
-    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_scan_plan_ex", "knn_debug_shard_policy", "knn_index_query",
+    "knn_index_query_keys_ex", "knn_index_debug_counters", "knn_debug_scan_plan", "knn_debug_scan_plan_ex", "knn_debug_shard_policy", "knn_debug_plan_shard", "knn_index_query",
     "knn_geom_create", "knn_geom_destroy", "knn_geom_info", "knn_geom_assign", "knn_index_create_sharded",
     "knn_index_seed_export", "knn_index_seed_attach", "knn_geom_first_cell",
 ]
@@ -139,6 +139,15 @@ def debug_scan_plan(num_cu, blocks_per_cu, nitems, m, self_lists=False):
     f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
     _check(f(int(num_cu), int(blocks_per_cu), int(nitems), int(m), 1 if self_lists else 0, out))
     return dict(zip(("blocks", "nlists", "slice", "ovf_base", "ovf_cap", "lds_bytes", "rec_cap", "max_lists"), list(out)))
+
+
+def debug_plan_shard(k, m, rows):
+    """knn_debug_plan_shard: how one shard of a one-shot call would be served (host arithmetic; works without a GPU)."""
+    out = (ctypes.c_longlong * 4)()
+    f = lib().knn_debug_plan_shard
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    _check(f(int(k), int(m), int(rows), out))
+    return dict(zip(("filter", "streamed", "grid", "chunks"), list(out)))
 
 
 def shard_bounds(n, shards):

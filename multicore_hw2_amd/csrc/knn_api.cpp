@@ -1343,6 +1343,20 @@ int shard_policy(int k, int m, long long n, int ndev)
 
 }  // namespace
 
+// Test hook (host arithmetic): how ONE shard of a one-shot call would be served — out = {filter layouts: 0 none, 1 plain, 2 cell-sorted
+// (the pruned scan), exact scan streamed under the copy, grid index, copy calls of the streamed form}.
+extern "C" int knn_debug_plan_shard(int k, int m, long long rows, long long out[4])
+{
+    if (k < 1 || m < 1 || rows < 1 || !out)
+        return fail(KNN_EINVAL, "knn_debug_plan_shard: bad arguments");
+    const ShardPlan p = plan_shard(k, m, rows);
+    out[0] = p.want_filter;
+    out[1] = p.streamed ? 1 : 0;
+    out[2] = p.want_grid ? 1 : 0;
+    out[3] = p.nchunks;
+    return KNN_OK;
+}
+
 extern "C" int knn_debug_shard_policy(int k, int m, long long n, int ndev)
 {
     if (k < 1 || m < 1 || n < 1 || ndev < 1)
