@@ -691,7 +691,7 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
     const float *__restrict__ margg = nullptr, const float *__restrict__ floorg = nullptr, unsigned *__restrict__ rung = nullptr)
 {
     constexpr int WAVES = BLOCK / 64;   // waves that share every staged reference tile
-    constexpr bool RUN = X16 && !SAMPLE && TPB > 1;   // thresholds tighten during the launch
+    constexpr bool RUN = X16 && !SAMPLE;   // thresholds tighten during the launch (k > 64: the 16 x 16 x 32 scans)
     constexpr int CHUNKS = KT * 64;                 // 16-byte chunks of A per tile
     constexpr int CPT = (CHUNKS + BLOCK - 1) / BLOCK;
     // TPB > 1 (round 3): TPB reference tiles per barrier, staged by LDS-DMA (global_load_lds, no staging registers) — the
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
                 // what the other blocks that scan these queries (other tile ranges) have found meanwhile: requested in front of
                 // the barrier — it waits for the next tiles anyway, and the scoring registers are dead here — and folded into this
                 // wave's thresholds behind it.  Agent scope: the words are changed by other XCDs' atomics.
-                static_assert(!RUN || QT * 32 == 128, "two words per lane");
+                static_assert(!RUN || QT * 32 <= 128, "at most two words per lane");
                 unsigned o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
                 if (run && nq > 0) {
                     const size_t qb = (size_t)qt0 * 32;
@@ -1016,6 +1016,19 @@ __global__ __launch_bounds__(BLOCK, 2) void knn_filter_tiled_kernel(
             score_tile(&s_a[buf][0], &s_n[buf][0], i);
             if (i + 1 < i1)
                 park(buf ^ 1);  // the other buffer was last read one iteration ago
+            if constexpr (RUN) {
+                // (running thresholds, as in the four-tiles-per-barrier form above: what the other blocks have found, every
+                // fourth tile, requested in front of the barrier and folded in behind it; QT x 32 <= 64 queries: one word per lane)
+                static_assert(!RUN || TPB > 1 || QT * 32 <= 64, "one word per lane");
+                const bool reload = run && nq > 0 && ((i - i0) & 3) == 3;   // (block-uniform but for nq: no barrier inside)
+                unsigned o0 = 0xFFFFFFFFu;
+                if (reload)
+                    o0 = __hip_atomic_load(&rung[min((size_t)qt0 * 32 + (size_t)lane, (size_t)(qt0 + nq) * 32 - 1)], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (reload && lane < nq * 32)
+                    s_th16[wib][lane] = fminf(s_th16[wib][lane], ord2f(o0));
+            } else
             __syncthreads();
         }
     }
@@ -2581,7 +2594,7 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
     // to give it a start — every 32nd tile instead of every 8th at C5 (2048 tiles): the pass shrinks 4x, the candidates grow
     // from 210k to 355k of the 642k a fixed threshold left, ms per step 0.9155 (stride 8) / 0.8909 (16) / 0.8829 (32) / 0.9091
     // (64) / 0.9378 (128) on one box (profiles/r05_c5_running_thresholds.txt).  KNN_MI355X_SAMPLE_STRIDE: the sweep's knob.
-    if (KT == 8 && st.run_thresholds != 2)
+    if (KT >= 8 && st.run_thresholds != 2)   // (KT = 16, 32: k 129 .. 512, the same scheme since the end of round 5)
         stride = std::min<long long>(32, std::max<long long>(1, st.ntiles / 64));
     if (st.sample_stride > 0)   // option `sample_stride` (the sweep's knob, and the tests' like-for-like comparison)
         stride = std::min<long long>(st.sample_stride, std::max<long long>(1, st.ntiles / 16));
@@ -2637,7 +2650,9 @@ static hipError_t launch_filter_tiled(FilterState &st, FilterWorkspace &w, int m
         hipLaunchKernelGGL((knn_filter_tiled_kernel<KT, QT, false, FILTER_BLOCK, 1, (KT > 4)>), dim3(gx, gy), dim3(FILTER_BLOCK), 0, s,
                            (const h8 *)st.ref_frags, st.ref_norms, (const h8 *)w.qry_frags, w.thr, qtiles, st.ntiles,
                            1ll, w.umin, m_padded, w.records, w.counts, w.ctl, w.slice,
-                           (unsigned short *)(w.records + w.rec_cap));
+                           (unsigned short *)(w.records + w.rec_cap),
+                           st.run_thresholds != 2 ? w.thr + (size_t)w.m_cap : nullptr, w.thr + 2 * (size_t)w.m_cap,
+                           st.run_thresholds != 2 ? (unsigned *)(w.thr + 3 * (size_t)w.m_cap) : nullptr);
     w.has_rows = true;
     w.pieces = RerankPieces();
     FTRY(hipGetLastError());

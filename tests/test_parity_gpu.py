@@ -1161,9 +1161,9 @@ def test_rccl_always_refuses_a_call_whose_shards_are_not_the_visible_devices():
 
 
 @pytest.mark.parametrize("dist", ["uniform", "gaussian", "near_copies", "far_queries"])
-@pytest.mark.parametrize("k,m,n", [(128, 4096, 65536), (100, 1000, 70001), (72, 2500, 40000)])
+@pytest.mark.parametrize("k,m,n", [(128, 4096, 65536), (100, 1000, 70001), (72, 2500, 40000), (256, 4096, 65536), (400, 2048, 33000)])
 def test_thresholds_that_tighten_during_the_deep_k_launch_keep_every_answer(oracle, dist, k, m, n):
-    """Round 5: for 64 < k <= 128 every score below a query's threshold is also a new bound for that
+    """Round 5: for 64 < k <= 512 every score below a query's threshold is also a new bound for that
     query — threshold' = max(floor, score + margin), shared between the blocks that scan other tile ranges for the same
     queries through atomic minima on one word per query (knn_thr_kernel has the derivation).  Same answers as v0 with the
     running thresholds on (default) and off (option run_thresholds = 2), FEWER re-ranked candidates with them on; near
