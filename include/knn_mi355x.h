@@ -240,9 +240,9 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "scan_blocks" the pruned scan's blocks per CU: 0 = auto (two; one for shards of up to 2^15 cells while the index's last
  *             eight calls named more than one workspace slot — batches in flight side by side: the scan alone gets 10-20 %
  *             longer and the next batch's preparation kernels find room beside it, 5-7 % per step), 1, 2
- *   "run_thresholds" the deep-K scan (64 < k <= 128): 0 / 1 = every score below a query's threshold lowers that threshold for the
- *             rest of the launch (threshold' = max(floor, score + margin), shared between blocks through an atomic minimum per
- *             query; the sample pass then only visits every 32nd tile), 2 = thresholds stay what the sample pass made them
+ *   "run_thresholds" the deep-K scans (64 < k <= 512): 0 / 1 = every score below a query's threshold lowers that threshold for
+ *             the rest of the launch (threshold' = max(floor, score + margin), shared between blocks through an atomic minimum
+ *             per query; the sample pass then only visits every 32nd tile), 2 = thresholds stay what the sample pass made them
  *   "sample_stride" deep-K scans: tiles the sample pass skips between two it scores (0 = library policy)
  *   "cells_lists" who makes a cell's list of queries (those of the batch that cannot rule the cell out) on the pruned path:
  *             1 = knn_cells_match_kernel in a launch of its own between the preparation and the scan (lists in memory),
