@@ -4,6 +4,9 @@
 #   gpurun -- 'bash tools/collect_profiles_r05.sh a'    bench lines, kernel traces, PMC passes keyed by workload (C3, rank 0 of 8, C4)
 #   gpurun -- 'bash tools/collect_profiles_r05.sh b'    emulated ranks, pipeline gaps, list makers, deep K, k 17-20
 #   gpurun -- 'bash tools/collect_profiles_r05.sh c'    distributions, build / ingest / drop-in records, per-wave timeline
+#   gpurun -- 'bash tools/collect_profiles_r05.sh d'    (after tools/publish_profiles_r05.py has made the PMC files of part a) the bench
+#                                                       lines of the three workloads with a PMC file again, so that their roofline
+#                                                       blocks quote the counter bytes — what a later `python bench.py` prints
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05_final
@@ -108,4 +111,11 @@ step "fuzz (bounded)"
 { echo "== drop-in, random shapes / paths / shards"; timeout -k 10 200 python3 tools/fuzz_parity.py 500 50505 2>&1 | tail -3;
   echo "== cell-pruned scan (k <= 32, both list makers, three builds)"; FUZZ_CELLS=1 timeout -k 10 420 python3 tools/fuzz_parity.py 400 27182 2>&1 | tail -3; } > $O/fuzz.txt 2>&1 || true
 echo done c
+fi
+if [ "$1" = d ]; then
+step "bench lines that quote the PMC files of this collection"
+B c3
+B c4_1gpu --workload c4 --cpu-queries 0
+B c3_rank_0_of_8 --emulate 8:0 --cpu-queries 0
+echo done d
 fi
