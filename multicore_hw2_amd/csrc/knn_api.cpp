@@ -511,11 +511,12 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     // Pruning needs enough cells for the dimension: measured on uniform data at m = 1024 (profiles/r02_cells_policy.txt)
     // the pruned scan wins from 2^19 rows for k <= 12 and from 2^20 rows for k = 13..16; below that the lists
     // hold most of the batch and the full scan's register-resident loop is the faster way to score them.
-    // (16 < k <= 32, round 5: the cells cut the first 16 dimensions; policy from the measurements in profiles/r05_cells_k17_32.txt)
-    // k 17 .. 22, uniform data, m = 1024, ms per step pruned / full scan: n = 2^24: k 17 0.285 / 0.924, 18 0.303 / 0.934, 20 0.432 / 0.948,
-    // 22 0.646 / 0.96, 24 1.42 / 0.979 (loses); n = 2^22: k 17 0.101 / 0.228, 18 0.138 / 0.232, 20 0.193 / 0.233, 22 0.282 / 0.24 (loses)
-    const long long cells_from = k <= 12 ? (1ll << 19) : k <= 16 ? (1ll << 20) : k <= 20 ? (1ll << 22) : k <= KNN_CELLS_AUTO_MAX_K ? (1ll << 24)
-                                                                                                       : (1ll << 62);
+    // (16 < k <= 32, round 5: the cells cut the first 16 dimensions; policy from the measurements in profiles/r05_cells_k17_32.txt:
+    // uniform data, m = 1024, ms per step pruned / full scan on one box — n = 2^24: k 17 0.222 / 0.992, 20 0.304 / 1.023, 22 0.485 / 1.039,
+    // 24 0.709 / 1.050, 26 1.36 / 1.07 (loses); n = 2^23: k 20 0.223 / 0.493, 22 0.363 / 0.505, 23 0.461 / 0.510, 24 0.578 / 0.514 (loses);
+    // n = 2^22: k 17 0.087 / 0.242, 20 0.163 / 0.253, 21 0.202 / 0.256, 22 0.252 / 0.260, 23 0.268 / 0.262 (loses))
+    const long long cells_from = k <= 12 ? (1ll << 19) : k <= 16 ? (1ll << 20) : k <= 20 ? (1ll << 22) : k <= 22 ? (1ll << 23)
+                                 : k <= KNN_CELLS_AUTO_MAX_K ? (1ll << 24) : (1ll << 62);
     const bool want_cells = k <= 32 && n_local >= (1ll << 17) &&
                             (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter == 2) ||
                              (g_opt_cells == 0 && build_filter < 0 && n_local >= cells_from));

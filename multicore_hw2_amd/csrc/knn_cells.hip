@@ -848,6 +848,7 @@ __device__ __forceinline__ float min_tree16(const f16v &x, float seed)
 // flight per wave; survivors go to the cell's list at offsets prefix-summed over the waves.  cell_counts[c] = queries
 // that could not rule cell c out, lists[c][0..) = their numbers.  No global atomics: per-cell
 // appends with returning atomics ran at 22 per ns, 0.13 ms for this batch (tools/atomic_probe).
+#define CELL_MATCH_STAGED_CAP 640u
 template <int CELL_MATCH_WAVES>   // 8, or 16 for shards of few cells (one block per 64 cells: 128 blocks at 2^13 cells)
 __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
@@ -857,10 +858,12 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     __shared__ unsigned short s_q[1024];
     __shared__ float s_hv[1024], s_dq[1024];
     __shared__ unsigned s_npass, s_flag, s_wcnt[CELL_MATCH_WAVES][64];
-    // lists of up to 128 entries are put together in LDS (row stride 65 dwords: lanes appending at the same
-    // depth hit different banks) and written out as whole 256-byte rows; longer ones (few, large cells) go
-    // straight to memory
-    __shared__ unsigned short s_list[64][130];
+    // lists of up to 640 entries are put together in LDS (dynamic: 64 rows of cap + 2 entries — a row stride of an odd number
+    // of dwords, 65 at cap 128: lanes appending at the same depth hit different banks) and written out as whole rows;
+    // longer ones (few, large cells) go straight to memory.  (16 < k <= 32, lists of 384 / 640: written straight to memory —
+    // ten million two-byte stores 768 bytes apart at k = 20 — the launch took 75 us at C3's shape; staged in LDS 0.326 -> 0.304 ms per step at k = 20, 0.810 -> 0.709 at k = 24)
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_list[];
+    const unsigned lstride = cap + 2u;
     // (the flag is read ONCE per block: other blocks of this launch may raise it, and threads of one block must not
     // disagree about leaving before the barriers below)
     if (threadIdx.x == 0)
@@ -909,8 +912,8 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     }
     __syncthreads();
     const unsigned npass = s_npass;
-    const bool staged = cap <= 128u;
-    unsigned short *__restrict__ my = staged ? &s_list[lane][0] : lists + (size_t)cell * cap;
+    const bool staged = cap <= CELL_MATCH_STAGED_CAP;
+    unsigned short *__restrict__ my = staged ? s_list + (size_t)lane * lstride : lists + (size_t)cell * cap;
     // pass 2: the queue in contiguous runs, one per wave (<= 1024 / WAVES entries); a lane keeps "my cell could not
     // rule entry j out" as bit j of a mask, the waves' counts are prefix-summed through LDS, and the second sweep
     // writes every survivor to its final place — no LDS atomics (16 waves adding to the same 64 counters cost
@@ -976,8 +979,8 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
             for (int w = 0; w < CELL_MATCH_WAVES; ++w)
                 cj += s_wcnt[w][j];
             cj = min(cj, cap);
-            if ((unsigned)lane * 2u < cj)
-                ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[lane] = ((const unsigned *)&s_list[j][0])[lane];
+            for (unsigned d = (unsigned)lane; d * 2u < cj; d += 64u)
+                ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[d] = ((const unsigned *)(s_list + (size_t)j * lstride))[d];
         }
     }
 }
@@ -988,6 +991,7 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
 // broadcast ds_read_b128 per tile and block of queries.  (Round 3 measured the C tile out of one extra MFMA on split norms
 // instead: 115-138 VGPRs, slower at every size — tools/arms/README.md.)
 #define CELL_SCAN_WAVES 12
+#define CELL_SCAN_WAVES_KT2 16   // 16 < k <= 32: one block per CU (74 KiB of operands), 4 waves per SIMD, 128 registers each
 #define CELL_SCAN_CHUNK 256   // slots of a block's share whose tile ranges and list lengths sit in LDS at a time (DYN)
 #define CELL_INLINE_RERANK_MAX 64u   // records a scan wave re-ranks itself; a longer list is left to the tail kernel
 #define CELL_PUBLISH_STEP 64u             // records between two publications of a wave's count to the batch's counter
@@ -1424,8 +1428,8 @@ __device__ __forceinline__ void cells_finalize(u64 *__restrict__ keys, int m, co
 __device__ unsigned long long g_scan_stamps[8192 * 5];
 #define SCAN_STAMP(i)                                                                                  \
     do {                                                                                               \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x * CELL_SCAN_WAVES + (threadIdx.x >> 6) < 8192u)      \
-            g_scan_stamps[(blockIdx.x * CELL_SCAN_WAVES + (threadIdx.x >> 6)) * 5 + (i)] = wall_clock64(); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 8192u)      \
+            g_scan_stamps[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 5 + (i)] = wall_clock64(); \
     } while (0)
 extern "C" int knn_debug_scan_stamps(unsigned long long *out)
 {
@@ -1437,11 +1441,11 @@ extern "C" int knn_debug_scan_stamps(unsigned long long *out)
 // K: 16 = compile-time dimension of the inline re-rank, 0 = run-time k <= 16
 // SELF: the waves make the lists of their own items (cell_self_list, knn_exact_dev.h) — no match launch in front of the scan;
 //       cell_counts / lists are unused and `cap` is CELL_SELF_CAP
-// KT:   K-steps of a tile: 1 (k <= 16), 2 (16 < k <= 32, round 5: tiles of 2 KiB, four per pass instead of nine, two MFMAs per
-//       step, batches of 512 queries — their B operands are 64 bytes each —; K = 0 there: the inline re-rank walks k in chunks
-//       of 16 dimensions)
+// KT:   K-steps of a tile: 1 (k <= 16), 2 (16 < k <= 32, round 5: tiles of 2 KiB, two MFMAs per step, 64-byte B operands — 74 KiB
+//       of LDS for a batch, so a CU holds ONE block: it has 16 waves of up to 128 registers, windows of nine tiles like KT = 1;
+//       K = 0 there: the inline re-rank walks k in chunks of 16 dimensions)
 template <bool DYN, int K, bool SELF, int KT = 1>
-__global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cells_scan_kernel(   // (KT = 2: 96 registers — 80 left it 12 bytes of scratch)
+__global__ __launch_bounds__(64 * (KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2), KT == 1 ? 6 : 4) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
@@ -1453,12 +1457,13 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
-    constexpr int TPP = KT == 1 ? CELL_TILES_PER_PASS : 4;              // reference tiles a wave holds in registers at a time
+    constexpr int TPP = CELL_TILES_PER_PASS;                         // reference tiles a wave holds in registers at a time
+    constexpr int SW = KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2;   // waves of a block
     h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][KT][64]
     float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32 * KT);       // [m_padded]
     f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * (32 * KT + 4));     // [waves][TPP * 8]
     // SELF: the batch's Dup values and one list room per wave behind the norm windows (knn_cells_scan_plan sizes it)
-    float *s_dup = (float *)(s_dyn + (size_t)m_padded * (32 * KT + 4) + (size_t)CELL_SCAN_WAVES * TPP * 8 * sizeof(f4v));   // [m_padded]
+    float *s_dup = (float *)(s_dyn + (size_t)m_padded * (32 * KT + 4) + (size_t)SW * TPP * 8 * sizeof(f4v));   // [m_padded]
     unsigned short *s_lists = (unsigned short *)(s_dup + m_padded);     // [waves][CELL_SELF_CAP]
     __shared__ unsigned s_flag;
     SCAN_STAMP(0);
@@ -1466,7 +1471,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
         s_flag = ctl[KNN_CTL_FALLBACK];   // read once per block: see knn_cells_match_kernel
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned wave = blockIdx.x * (unsigned)CELL_SCAN_WAVES + (unsigned)wib, nwaves = gridDim.x * (unsigned)CELL_SCAN_WAVES;
+    const unsigned wave = blockIdx.x * (unsigned)SW + (unsigned)wib, nwaves = gridDim.x * (unsigned)SW;
     __shared__ unsigned s_next, s_imeta[DYN ? CELL_SCAN_CHUNK : 1], s_itb[DYN ? CELL_SCAN_CHUNK : 1], s_inq[DYN ? CELL_SCAN_CHUNK : 1];
     const unsigned per_wave = (nitems + nwaves - 1u) / nwaves;
     // DYN: a block's share is one RUN of CELL_SCAN_RUN consecutive items out of every stripe of gridDim.x runs, not one
@@ -1506,7 +1511,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
     // cap, and a kernel that uses scratch at all ran 7 % slower — 0.1197 -> 0.1283 ms on one box.  Left as it was.)
     if constexpr (DYN) {
         const unsigned nc0 = min((unsigned)CELL_SCAN_CHUNK, i1 - i0);
-        for (unsigned i = threadIdx.x; i < nc0; i += 64 * CELL_SCAN_WAVES) {
+        for (unsigned i = threadIdx.x; i < nc0; i += 64 * SW) {
             const unsigned it = slot_item(i0 + i);
             const u64 item = it != 0xFFFFFFFFu ? items[it] : 0ull;
             s_imeta[i] = (unsigned)(item >> 40);
@@ -1517,15 +1522,15 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
                 s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;   // (a hole: nobody lists it)
         }
         if (threadIdx.x == 0)
-            s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
+            s_next = (unsigned)SW;   // the first item of every wave is its own number
     }
     // (LDS-DMA for this fill — no staging registers — measured: C3 -0.5 %, a rank of 8 +5 % per pipelined step.  Not taken.)
-    for (int i = threadIdx.x; i < m_padded * 2 * KT; i += 64 * CELL_SCAN_WAVES)
+    for (int i = threadIdx.x; i < m_padded * 2 * KT; i += 64 * SW)
         s_qf[i] = qfg[i];
-    for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
+    for (int i = threadIdx.x; i < m_padded; i += 64 * SW)
         s_thr[i] = thrg[i];
     if constexpr (SELF)
-        for (int i = threadIdx.x; i < m_padded; i += 64 * CELL_SCAN_WAVES)
+        for (int i = threadIdx.x; i < m_padded; i += 64 * SW)
             s_dup[i] = self.dup[i];
     __syncthreads();
     if (s_flag != 0u)
@@ -1556,7 +1561,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
                     break;
                 nc = min((unsigned)CELL_SCAN_CHUNK, i1 - c0);
                 __syncthreads();   // everybody is done with the previous chunk's tables
-                for (unsigned i = threadIdx.x; i < nc; i += 64 * CELL_SCAN_WAVES) {
+                for (unsigned i = threadIdx.x; i < nc; i += 64 * SW) {
                     const unsigned it = slot_item(c0 + i);
                     const u64 item = it != 0xFFFFFFFFu ? items[it] : 0ull;
                     s_imeta[i] = (unsigned)(item >> 40);
@@ -1567,7 +1572,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
                         s_inq[i] = it != 0xFFFFFFFFu ? cell_counts[(unsigned)(item >> 48)] : 0u;
                 }
                 if (threadIdx.x == 0)
-                    s_next = (unsigned)CELL_SCAN_WAVES;   // the first item of every wave is its own number
+                    s_next = (unsigned)SW;   // the first item of every wave is its own number
                 __syncthreads();
                 mine_dyn = (unsigned)wib;
             }
@@ -1838,7 +1843,7 @@ __global__ __launch_bounds__(64 * CELL_SCAN_WAVES, KT == 1 ? 6 : 5) void knn_cel
         const unsigned have = __hip_atomic_load(&ctl[KNN_CTL_RECORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
                               __hip_atomic_load(&ctl[KNN_CTL_DEFERRED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (have == 0u)
-            cells_finalize(keys, m, fin, threadIdx.x, 64u * CELL_SCAN_WAVES);
+            cells_finalize(keys, m, fin, threadIdx.x, 64u * SW);
     }
     SCAN_STAMP(4);
 }
@@ -2188,7 +2193,8 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     // in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
     c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
     if (k > 16)   // (more dimensions, fewer cells ruled out: lists of ~100-200 of 1024 queries at k = 20 — 128 entries made most cells dense)
-        c->cap = std::min(1024u, std::max(384u, (1u << 24) / c->ncells));
+        c->cap = std::min(1024u, std::max(k > 20 ? 640u : 384u, (1u << 24) / c->ncells));
+    // (k = 24, n 2^24: lists of 384 left most cells dense, 1.19 ms per step; 640 or 1024 entries 0.75 — the full scan takes 0.97)
     const CellGeom g = cell_geom_of(*c, k);
     int lbits = 0;   // bits of a LOCAL cell number (= bits without a shard geometry)
     while ((1u << lbits) < c->ncells)
@@ -2497,10 +2503,12 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
 CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded, bool self_lists, int kt)
 {
     CellScanPlan p;
-    p.blocks = (unsigned)num_cu * (unsigned)blocks_per_cu;
-    if (p.blocks * CELL_SCAN_WAVES > nitems)
-        p.blocks = std::max(1u, nitems / CELL_SCAN_WAVES);
-    p.nlists = p.blocks * CELL_SCAN_WAVES;
+    const unsigned sw = kt == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2;
+    p.waves = sw;
+    p.blocks = (unsigned)num_cu * (unsigned)(kt == 1 ? blocks_per_cu : 1);
+    if (p.blocks * sw > nitems)
+        p.blocks = std::max(1u, nitems / sw);
+    p.nlists = p.blocks * sw;
     // the tail of the record buffer is shared by all waves: what a wave's own slice cannot hold goes there.  2^16 records:
     // room for a batch whose queries crowd into a few cells (1024 copies of one query leave ~2000 records there), and small
     // enough that a batch the fp16 scores cannot separate at all (a cluster tighter than the fp16 step: millions of
@@ -2508,11 +2516,13 @@ CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems,
     p.ovf_cap = std::min(rec_cap / 4u, 1u << 16);
     p.ovf_base = rec_cap - p.ovf_cap;
     p.slice = p.ovf_base / p.nlists;
-    // (16 < k <= 32: 64-byte B operands and windows of four tiles: 74 KiB for 1024 queries — two blocks still share a CU's
-    // 160 KiB; the launch raises the kernel's dynamic-LDS limit above the default 64 KiB)
-    p.lds_bytes = (size_t)m_padded * (32 * kt + 4) + (size_t)CELL_SCAN_WAVES * (kt == 1 ? CELL_TILES_PER_PASS : 4) * 8 * sizeof(f4v);
+    // (16 < k <= 32: 64-byte B operands, 74 KiB for 1024 queries: with windows of nine 2-KiB tiles in registers (126 VGPRs) a CU
+    // holds ONE block, so that block has sixteen waves — four per SIMD; the launch raises the kernel's dynamic-LDS limit above
+    // the default 64 KiB.  Round 5, one box, ms per step at k 17 / 18 / 20, n 2^24: four tiles per pass, 12 waves, 96
+    // registers 0.282 / 0.315 / 0.428; five 0.269 / 0.303 / 0.399; nine, 12 waves (3 per SIMD) 0.237 / 0.242 / 0.352)
+    p.lds_bytes = (size_t)m_padded * (32 * kt + 4) + (size_t)sw * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
     if (self_lists)   // the self-listing scan: the batch's Dup values + one list room per wave
-        p.lds_bytes += (size_t)m_padded * sizeof(float) + (size_t)CELL_SCAN_WAVES * CELL_SELF_CAP * sizeof(unsigned short);
+        p.lds_bytes += (size_t)m_padded * sizeof(float) + (size_t)sw * CELL_SELF_CAP * sizeof(unsigned short);
     return p;
 }
 
@@ -2599,12 +2609,20 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     FTRY(hipGetLastError());
     if (self_lists) {
         // no match launch: the scan's waves list their own items
-    } else if (c.ncells <= 16384u)
-        hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
-                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
-    else
-        hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), 0, s, w.lo_tab, w.hi_tab, w.dup, m,
-                           m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
+    } else {
+        const size_t mlds = c.cap <= CELL_MATCH_STAGED_CAP ? (size_t)64 * (c.cap + 2u) * sizeof(unsigned short) : 0;   // the lists of a block's 64 cells
+        if (c.ncells <= 16384u) {
+            if (mlds > (size_t)(48u << 10))   // (12-20 KiB of static LDS in front of it; the attribute is per device, so per launch)
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_match_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), mlds, s, w.lo_tab, w.hi_tab, w.dup, m,
+                               m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
+        } else {
+            if (mlds > (size_t)(48u << 10))
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_match_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), mlds, s, w.lo_tab, w.hi_tab, w.dup, m,
+                               m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
+        }
+    }
     FTRY(hipGetLastError());
     CellSelf self;
     memset(&self, 0, sizeof self);
@@ -2660,7 +2678,7 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     fin.defer = st.n_outliers != 0u ? 1 : 0;
     const long long npos = st.ntiles * 32;
 #define KNN_SCAN_LAUNCH(DYNV, KV, SELFV, ...)                                                                              \
-    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV, SELFV, ##__VA_ARGS__>), dim3(gx), dim3(64 * CELL_SCAN_WAVES), lds, s, (const h8 *)st.ref_frags, \
+    hipLaunchKernelGGL((knn_cells_scan_kernel<DYNV, KV, SELFV, ##__VA_ARGS__>), dim3(gx), dim3(64 * plan.waves), lds, s, (const h8 *)st.ref_frags, \
                        st.ref_norms, c.items, c.nitems, (const h8 *)w.qry_frags, w.thr, m, m_padded, w.cell_counts,        \
                        w.cell_lists, list_cap, w.records, w.counts, w.ctl_cur, w.slice, w.ovf_base, w.ovf_cap, q, r, st.k, \
                        c.perm, npos, base, keys, fin, self)

@@ -234,7 +234,7 @@ struct FilterState {
 };
 
 // ---- cell-pruned form of the filter (knn_cells.hip) -----------------------------------------
-#define KNN_CELLS_AUTO_MAX_K 22   // library policy: cell-sorted layouts for resident indexes up to this dimension (`cells` = 1: up to 32)
+#define KNN_CELLS_AUTO_MAX_K 24   // library policy: cell-sorted layouts for resident indexes up to this dimension (`cells` = 1: up to 32)
 #define KNN_CELL_BATCH 1024   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS (68 KiB for 16 < k <= 32)
 #ifdef __cplusplus
 #include <vector>
@@ -252,7 +252,7 @@ hipError_t knn_cells_fast_finish(CellIndex &c, unsigned *counts, hipStream_t s);
 #endif
 // Sizes of one scan launch of the cell-pruned path (knn_cells.hip; host arithmetic only).
 struct CellScanPlan {
-    unsigned blocks = 0, nlists = 0, slice = 0, ovf_base = 0, ovf_cap = 0;
+    unsigned blocks = 0, waves = 0, nlists = 0, slice = 0, ovf_base = 0, ovf_cap = 0;
     size_t lds_bytes = 0;
 };
 CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded,
