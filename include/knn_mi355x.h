@@ -244,6 +244,14 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *             the rest of the launch (threshold' = max(floor, score + margin), shared between blocks through an atomic minimum
  *             per query; the sample pass then only visits every 32nd tile), 2 = thresholds stay what the sample pass made them
  *   "sample_stride" deep-K scans: tiles the sample pass skips between two it scores (0 = library policy)
+ *   "cells_centre" per-cell frames of the cell-sorted layout (k <= 16, not for cell-range shards): the fp16 fragments of a cell are
+ *             taken about the middle of the cell's own box and scaled (by up to 2^8 more) to fill the fp16 range the rows of the
+ *             whole shard share otherwise — the filter's rounding error shrinks from 2^-12 of the shard's box to 2^-12 of the
+ *             cell's, what a set of tight clusters needs for its thresholds to separate anything.  0 = library policy: when the
+ *             build's sample of the rows looks clustered (median nearest-neighbour distance inside the sample below 1/16 of the
+ *             box); 1 = every cell-sorted layout; 2 = never.  Read when an index is built.  Costs one more pass over the rows at
+ *             build time and ~100 instructions per (cell, 32 queries) at query time; results are identical either way.
+ *             knn_get_option("cells_centred_builds") counts the layouts built so (read-only).
  *   "cells_lists" who makes a cell's list of queries (those of the batch that cannot rule the cell out) on the pruned path:
  *             1 = knn_cells_match_kernel in a launch of its own between the preparation and the scan (lists in memory),
  *             2 = the scan's waves for the items they take (same test, same arithmetic, lists in LDS: one launch and one

@@ -369,6 +369,12 @@ int knn_set_option(const char *name, long long value)
         g_opt_run_thresholds = value;
         return KNN_OK;
     }
+    if (!strcmp(name, "cells_centre")) {
+        if (value < 0 || value > 2)
+            return fail(KNN_EINVAL, "knn_set_option: cells_centre must be 0 (auto: per-cell frames for clustered data), 1 (always) or 2 (never)");
+        g_knn_cells_centre = (int)value;
+        return KNN_OK;
+    }
     if (!strcmp(name, "cells_lists")) {
         if (value < 0 || value > 2)
             return fail(KNN_EINVAL, "knn_set_option: cells_lists must be 0 (auto), 1 (match launch) or 2 (the scan lists its own items)");
@@ -434,6 +440,10 @@ long long knn_get_option(const char *name)
         return g_opt_scan_deal;
     if (name && !strcmp(name, "cells_lists"))
         return g_opt_cells_lists;
+    if (name && !strcmp(name, "cells_centre"))
+        return (long long)g_knn_cells_centre.load();
+    if (name && !strcmp(name, "cells_centred_builds"))   // read-only: cell-sorted layouts moved into per-cell frames so far
+        return g_knn_cells_centred_builds.load();
     if (name && !strcmp(name, "run_thresholds"))
         return g_opt_run_thresholds;
     if (name && !strcmp(name, "sample_stride"))

@@ -1018,6 +1018,61 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 (&a)[KT], const f4v *__re
     return __ballot(mn < th);
 }
 
+// |coordinate| a query may have in a cell's frame: twice that must stay an fp16 number (the B operand is -2 x the query); the
+// bounds do not mind the size — every error term is relative to the pair's own amax (64 box half-widths at the largest scale).
+#define CELL_FRAME_AMAX 16384.0f
+
+// The centred scan's B operand and threshold for one (query, cell) pair (per-cell frames, knn_cells_recentre): lane = (query
+// of the block, half of the dimensions).  The query is rounded in the CELL's frame exactly as knn_cells_prep_kernel rounds it
+// in the shard's — fp32 subtract, exact power-of-two scale, fp16 to nearest even, times -2 —; amax and the computed norm mq
+// are the pair's own.  The threshold is knn_threshold's last line with the constants of knn_bound_consts(k, 1, scale_c, amax,
+// bmax_c, nmax_c), evaluated in fp32 with everything rounded towards "pass":
+//     thr = Dup + 2 eta sqrt(Dup) + eta^2 + rho - mq (1 - gamma)          (Dup in the cell's units: Dup_q x ratio^2)
+// P = the positive terms: eight fp32 operations on positive numbers, constants rounded up — within 2^-20 of exact, taken
+// 10^-5 larger; mq x 0.999998 <= mq (1 - gamma)(1 - 2^-22) (gamma = 18 x 2^-24 = 1.07 x 10^-6); the last subtraction rounds by
+// at most 2^-24 (P + mq), 2.4 x 10^-7 (P + mq) is added.  A pair whose query does not fit the cell's frame: see the end.
+__device__ __forceinline__ void cell_centred_operand(const float *__restrict__ s_q32, int k, unsigned qid, int half, bool valid,
+                                                     const float (&cc)[8], float scale, float ratio, float bmaxc, float nmaxc,
+                                                     float dupq, float sqdq, h8 &b, float &th)
+{
+#pragma clang fp contract(off)
+    // the query's fp32 row, padded to 16 dimensions with zeros, from LDS (the centre is zero there too: no masks)
+    const f4v x0 = *(const f4v *)(s_q32 + (size_t)qid * 16 + 8 * half), x1 = *(const f4v *)(s_q32 + (size_t)qid * 16 + 8 * half + 4);
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    float a = 0.0f, a32 = 0.0f, mq = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float sc = (x[j] - cc[j]) * scale;
+        const _Float16 hval = (_Float16)sc;
+        const float back = (float)hval;
+        bad = bad || !(fabsf(back) < INFINITY);
+        a = fmaxf(a, fabsf(back));
+        a32 = fmaxf(a32, fabsf(sc));
+        mq = mq + back * back;
+        b[j] = (_Float16)(back * -2.0f);
+    }
+    a = fmaxf(a, __shfl_xor(a, 32, KNN_WAVE));
+    a32 = fmaxf(a32, __shfl_xor(a32, 32, KNN_WAVE));
+    mq = mq + __shfl_xor(mq, 32, KNN_WAVE);
+    bad = bad || __shfl_xor((int)bad, 32, KNN_WAVE) != 0;
+    const float kf = (float)k;
+    const float emax = 4.8865e-4f * (a + bmaxc) + 1.2220e-4f;          // theta' (amax + bmax) + 2 nu0
+    const float sqk = k <= 1 ? 1.0f : k <= 4 ? 2.0f : k <= 9 ? 3.0f : 4.0f;   // >= sqrt(k), k <= 16 (no square root here: the exact kernels' ISA is checked for FMAs)
+    const float eta = sqk * emax, eta2 = kf * emax * emax;
+    const float rho = 1.1921e-5f * (nmaxc + 16.0f * a * a) + 1.79e-7f + 4.77e-7f * nmaxc;
+    const float dupc = dupq * ratio * ratio, sqdc = sqdq * ratio;
+    const float P = dupc + 2.0f * eta * sqdc + eta2 + rho;
+    const float T = (P * 1.00001f + (P + mq) * 2.4e-7f + 1e-30f) - mq * 0.999998f;
+    // A query that does not fit the cell's frame (a coordinate beyond CELL_FRAME_AMAX cell units, or not finite): along that coordinate it
+    // is at least a32 (1 - 2^-22) - bmax_c - (rounding of the rows: 2^-11 bmax_c) away from every row of the cell, in exact
+    // arithmetic.  Further than sqrt(Dup): no row of this cell can be its answer (a `dense` cell is scored against the whole
+    // batch, queries that never listed it included).  Else everything passes — its rows are re-ranked exactly, as any candidate is.
+    const float lb = a32 * 0.999f - bmaxc * 1.001f - 0.001f;
+    const bool beyond = lb > 0.0f && lb * lb > dupc * 1.001f;   // (a32 = +INF: beyond any finite Dup; NaN: not beyond)
+    th = !valid ? -INFINITY : (bad || !(a <= CELL_FRAME_AMAX)) ? (dupq > -INFINITY && !beyond ? INFINITY : -INFINITY) : T;
+}
+
 // ------------------------------------------------------------------------------------------
 // Round 3: everything a batch needs before its cells can be matched, in ONE kernel — one block of 4 waves per query.
 // Replaces knn_frag_kernel (queries) + knn_cells_seed_kernel + the keys-fill launch of round 2 (three launches, 26 us
@@ -1050,15 +1105,19 @@ struct SeedLayer {
 //     rank at N = 8 against 399, 199 with the bound one GPU would have) but measured slower end to end (knn_cells_query).
 // KT: K-steps of a tile, 1 (k <= 16) or 2 (16 < k <= 32, round 5: the cuts, the gaps and the tables cover the first 16
 //     dimensions; the fragments and the seed scores all of them)
-template <int PW, int SD, int KT = 1>
-__global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
+// CTR: per-cell frames (knn_cells_recentre; KT = 1, no seed layer): every seed cell is scored with the query rounded in THAT
+//     cell's frame, each gives its own bound Dup (frame-free: a squared distance) and the smallest stands; thr[q] = an upper
+//     bound of sqrt(Dup_q) — what the centred scan's per-pair thresholds start from — instead of a score threshold
+template <int PW, int SD, int KT = 1, bool CTR = false>
+__global__ __launch_bounds__(64 * PW, KT == 1 && !CTR ? 4 : 3) void knn_cells_prep_kernel(   // (4 waves per SIMD: a batch of 1024 queries is resident at once)
     const float *__restrict__ Q, int m, int m_padded, CellGeom g, const float *__restrict__ bounds, double sigma2,
     const float *__restrict__ center, float sigma, const unsigned *__restrict__ tile_start, long long ntiles,
     const h8 *__restrict__ rf, const unsigned *__restrict__ rn2, SeedLayer layer, h8 *__restrict__ qfg, float *__restrict__ lo_tab,
     float *__restrict__ hi_tab, float bmax, float nmax, float amax_limit, float *__restrict__ thr,
     float *__restrict__ dup_out, unsigned *__restrict__ ctl, unsigned *__restrict__ ctl_next,
     unsigned *__restrict__ counts, unsigned nlists, u64 *__restrict__ keys_init,
-    int lo_by_entry)   // != 0: the low table as [entry][query] (what the self-listing scan reads: a cell's row is contiguous)
+    int lo_by_entry,   // != 0: the low table as [entry][query] (what the self-listing scan reads: a cell's row is contiguous)
+    const float *__restrict__ frame, const unsigned *__restrict__ tile_cell)   // CTR only
 {
 #pragma clang fp contract(off)
     constexpr int SEEDS = 1 << SD, NS = SEEDS / PW;   // seed cells in all, per wave
@@ -1205,11 +1264,12 @@ __global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kerne
     // A cell of this index: all its tiles, out of the layout; a cell of another rank (cell-range shards): the few tiles of
     // the replicated seed layer.
     unsigned long long v_fa = 0ull, v_na = 0ull;
-    unsigned v_nt = 0u;
+    unsigned v_nt = 0u, v_cell = 0u;
     if (ok) {
         const unsigned l = code - g.cell_base;
         if (code >= g.cell_base && l < g.ncells) {
             const unsigned tb = tile_start[l];
+            v_cell = l;
             v_nt = tile_start[l + 1u] - tb;
             // (a shard's OUTER seeds — beyond the own cell and the cells across the two nearest cuts — give what the layer
             // would: their first tiles.  Whole, the 16 local seed cells of a query that lives on this rank were 136 tiles
@@ -1227,6 +1287,16 @@ __global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kerne
             v_nt = layer.tiles;
             v_fa = (unsigned long long)(pb + (size_t)cl * layer.tiles * 1024u);
             v_na = (unsigned long long)(pb + (size_t)layer.cpr * layer.tiles * 1024u + (size_t)cl * layer.tiles * 128u);
+        }
+    }
+    float fv_seed[NS];   // CTR: the frames of this wave's seed cells, word w on lane w (in flight while the tables are made)
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        fv_seed[c] = 0.0f;
+        if constexpr (CTR) {
+            const unsigned cell = (unsigned)__builtin_amdgcn_readlane((int)v_cell, wib + PW * c);
+            if (lane < KNN_CELL_FRAME_WORDS)
+                fv_seed[c] = frame[(size_t)cell * KNN_CELL_FRAME_WORDS + lane];
         }
     }
     __syncthreads();   // s_gap is complete
@@ -1262,7 +1332,7 @@ __global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kerne
     float um = INFINITY;
     // (all wave-uniform) run c: `cnt[c]` tiles fa[c] + v stride[c] KiB, norm words na[c] + v stride[c] 128 B
     auto score_runs = [&](const unsigned long long (&fa)[NS], const unsigned long long (&na)[NS], const unsigned (&cnt)[NS],
-                          const unsigned (&stride)[NS]) __attribute__((always_inline)) {
+                          const unsigned (&stride)[NS], const h8 (&bqx)[KT]) __attribute__((always_inline)) {
         unsigned start[NS + 1];   // run c holds positions [start[c], start[c + 1]) of the list (constant indices only: these
         start[0] = 0u;            // arrays must stay in registers — indexed by a run-time c they went to scratch memory)
 #pragma unroll
@@ -1301,11 +1371,137 @@ __global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kerne
                     f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(norm_a_operand(nw[p]), norm_b_operand(), zero_acc(), 0, 0, 0);
 #pragma unroll
                     for (int kk = 0; kk < KT; ++kk)
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p][kk], bq[kk], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[p][kk], bqx[kk], d, 0, 0, 0);
                     um = min_tree16(d, um);
                 }
         }
     };
+    if constexpr (CTR) {
+        // One seed cell (or sampled tile) at a time: the query rounded in the cell's frame — what knn_frag_kernel would write
+        // for it with (centre_c, scale_c) —, the cell's tiles scored against it, the bound on the answer's distance they give
+        // in the SHARD's scaled units (the two frames differ by the power of two frame[17]).  All lanes do all of it.
+        // fv: the cell's frame, word w on lane w (requested early — before the tables — for the seed cells)
+        auto cell_bound = [&](float fv, unsigned long long f0, unsigned long long n0, unsigned cnt0,
+                              unsigned stride0) __attribute__((always_inline)) -> float {
+            float fr[KNN_CELL_FRAME_WORDS];
+#pragma unroll
+            for (int w_ = 0; w_ < KNN_CELL_FRAME_WORDS; ++w_)
+                fr[w_] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fv), w_));
+            const float scale = fr[16], ratio = fr[17];
+            float nrmc = 0.0f, amaxc = 0.0f, n32 = 0.0f;
+            bool badc = false;
+            h8 bqc[KT];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                float sc = 0.0f;
+                if (d < g.k)
+                    sc = (qrow[d] - fr[d]) * scale;
+                n32 = n32 + sc * sc;
+                const _Float16 hval = (_Float16)sc;
+                const float back = (float)hval;
+                badc = badc || !(fabsf(back) < INFINITY);
+                amaxc = fmaxf(amaxc, fabsf(back));
+                nrmc = nrmc + back * back;
+                const _Float16 v = (_Float16)(back * -2.0f);
+                badc = badc || !(fabsf((float)v) < INFINITY);
+                if (((d >> 3) & 1) == half)
+                    bqc[0][d & 7] = v;
+            }
+            // A query that does not fit this cell's frame (beyond CELL_FRAME_AMAX cell units: far from a tight cell): no fp16 scores — a
+            // zero B operand leaves the rows' norms, finite iff the tiles hold a real row — and the bound is the triangle
+            // inequality's: every row of the cell is within sqrt(k) bmax_c (1 + 2^-10) of its centre.
+            const bool far = badc || !(amaxc <= CELL_FRAME_AMAX);
+            if (far)
+                bqc[0] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long fa[NS], na[NS];
+            unsigned cnt[NS], stride[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                fa[c] = na[c] = 0ull;
+                cnt[c] = 0u;
+                stride[c] = 1u;
+            }
+            fa[0] = f0;
+            na[0] = n0;
+            cnt[0] = cnt0;
+            stride[0] = stride0;
+            um = INFINITY;
+            score_runs(fa, na, cnt, stride, bqc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                um = fminf(um, __shfl_xor(um, off, KNN_WAVE));
+            if (!(um < INFINITY))
+                return INFINITY;
+            const BoundConsts cst = knn_bound_consts(g.k, 1, scale, far ? 0.0f : amaxc, fr[18], fr[19]);
+            double dup = 0.0;
+            if (far) {
+                const double reach = sqrt((double)n32) * (1.0 + 1e-6) + sqrt((double)g.k) * (double)fr[18] * 1.001 + 0.001;
+                dup = reach * reach * (1.0 + 1e-5) * (1.0 + cst.g2) * (1.0 + cst.g2) + cst.sigma2 * cst.tau;
+                if (!(dup < 1e300))
+                    return INFINITY;
+            } else {
+                const float t = knn_threshold(cst, um, nrmc, &dup);
+                if (!(t < INFINITY))
+                    return INFINITY;
+            }
+            dup = dup / ((double)ratio * (double)ratio) * (1.0 + 1e-6);
+            float df = (float)dup;
+            if ((double)df < dup)
+                df = nextafterf(df, INFINITY);
+            return df;
+        };
+        float best = INFINITY;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {   // this wave's seed cells
+            const int sl = wib + PW * c;
+            const unsigned nt = (unsigned)__builtin_amdgcn_readlane((int)v_nt, sl);
+            if (nt != 0u) {   // wave-uniform
+                const unsigned long long f0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v_fa >> 32), sl) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v_fa, sl);
+                const unsigned long long n0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v_na >> 32), sl) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v_na, sl);
+                const unsigned st0 = (nt + CELL_SEED_MAX_TILES - 1u) / CELL_SEED_MAX_TILES;
+                best = fminf(best, cell_bound(fv_seed[c], f0, n0, (nt + st0 - 1u) / st0, st0));
+            }
+        }
+        if (lane == 0)
+            s_red[wib] = best;
+        __syncthreads();
+        float u = s_red[0];
+#pragma unroll
+        for (int i = 1; i < PW; ++i)
+            u = fminf(u, s_red[i]);
+        if (!(u < INFINITY) && ntiles > 0) {   // block-uniform: nothing in the seed cells — 64 tiles spread over the layout, each in its cell's frame
+            __syncthreads();
+            const unsigned total = (unsigned)(ntiles > 64 ? 64 : ntiles);
+            const unsigned wstride = (unsigned)(ntiles > 64 ? ntiles / 64 : 1);
+            best = INFINITY;
+            for (unsigned i = (unsigned)wib * (64u / PW); i < min(((unsigned)wib + 1u) * (64u / PW), total); ++i) {
+                const size_t t = (size_t)i * wstride;
+                const float fv = lane < KNN_CELL_FRAME_WORDS ? frame[(size_t)tile_cell[t] * KNN_CELL_FRAME_WORDS + lane] : 0.0f;
+                best = fminf(best, cell_bound(fv, (unsigned long long)(rf + t * 64), (unsigned long long)(rn2 + t * 32), 1u, 1u));
+            }
+            if (lane == 0)
+                s_red[wib] = best;
+            __syncthreads();
+            u = s_red[0];
+#pragma unroll
+            for (int i = 1; i < PW; ++i)
+                u = fminf(u, s_red[i]);
+            if (tid == 0)
+                atomicAdd(&ctl[KNN_CTL_WIDE_SEEDS], 1u);   // rare; statistics only
+        }
+        if (tid == 0) {
+            const bool bad = qbad || !(amax <= amax_limit) || !(u < INFINITY);
+            float sq = sqrtf(u);
+            sq = nextafterf(nextafterf(sq, INFINITY), INFINITY);
+            thr[qi] = bad ? -INFINITY : sq;
+            dup_out[qi] = bad ? -INFINITY : u;
+            if (bad)
+                ctl[KNN_CTL_FALLBACK] = 1u;  // benign race: every writer stores 1
+        }
+        return;
+    }
     {
         unsigned long long fa[NS], na[NS];
         unsigned cnt[NS], stride[NS];
@@ -1320,7 +1516,7 @@ __global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kerne
             stride[c] = (nt + CELL_SEED_MAX_TILES - 1u) / CELL_SEED_MAX_TILES;   // 1 up to the cap
             cnt[c] = nt == 0u ? 0u : (nt + stride[c] - 1u) / stride[c];
         }
-        score_runs(fa, na, cnt, stride);
+        score_runs(fa, na, cnt, stride, bq);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)   // (every column is this query; the halves hold different rows)
@@ -1353,7 +1549,7 @@ __global__ __launch_bounds__(64 * PW, KT == 1 ? 4 : 3) void knn_cells_prep_kerne
             na[0] = (unsigned long long)(rn2 + (size_t)mine_first * wstride * 32);
             cnt[0] = min(64u / PW, total - mine_first);
             stride[0] = wstride;
-            score_runs(fa, na, cnt, stride);
+            score_runs(fa, na, cnt, stride, bq);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
@@ -1444,8 +1640,11 @@ extern "C" int knn_debug_scan_stamps(unsigned long long *out)
 // KT:   K-steps of a tile: 1 (k <= 16), 2 (16 < k <= 32, round 5: tiles of 2 KiB, two MFMAs per step, 64-byte B operands — 74 KiB
 //       of LDS for a batch, so a CU holds ONE block: it has 16 waves of up to 128 registers, windows of nine tiles like KT = 1;
 //       K = 0 there: the inline re-rank walks k in chunks of 16 dimensions)
-template <bool DYN, int K, bool SELF, int KT = 1>
-__global__ __launch_bounds__(64 * (KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2), KT == 1 ? 6 : 4) void knn_cells_scan_kernel(
+// CTR:  per-cell frames (knn_cells_recentre; KT = 1, lists from the match launch): the B operand and the threshold of a (query,
+//       cell) pair are made here, from the fp32 query, the cell's frame and Dup_q (cell_centred_operand) — s_thr holds the
+//       batch's sqrt(Dup) bounds, s_dup the Dup values, the B operands' room in LDS stays unused
+template <bool DYN, int K, bool SELF, int KT = 1, bool CTR = false>
+__global__ __launch_bounds__(64 * (KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2), CTR ? 4 : KT == 1 ? 6 : 4) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
     const unsigned *__restrict__ cell_counts, const unsigned short *__restrict__ lists, unsigned cap,
@@ -1458,12 +1657,13 @@ __global__ __launch_bounds__(64 * (KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_K
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(128))) unsigned char s_dyn[];   // (aligned: static LDS of the kernel sits in front of it, and the b128 reads below want 16-byte addresses)
     constexpr int TPP = CELL_TILES_PER_PASS;                         // reference tiles a wave holds in registers at a time
-    constexpr int SW = KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2;   // waves of a block
-    h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][KT][64]
-    float *s_thr = (float *)(s_dyn + (size_t)m_padded * 32 * KT);       // [m_padded]
-    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * (32 * KT + 4));     // [waves][TPP * 8]
+    constexpr int SW = KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2;   // waves of a block
+    constexpr int QB = CTR ? 64 : 32 * KT;                              // bytes of a query in LDS (CTR: its fp32 row, 16 dimensions)
+    h8 *s_qf = (h8 *)s_dyn;                                             // [m_padded / 32][KT][64]; CTR: float s_q32[m_padded][16]
+    float *s_thr = (float *)(s_dyn + (size_t)m_padded * QB);            // [m_padded]
+    f4v *s_nrm = (f4v *)(s_dyn + (size_t)m_padded * (QB + 4));          // [waves][TPP * 8]
     // SELF: the batch's Dup values and one list room per wave behind the norm windows (knn_cells_scan_plan sizes it)
-    float *s_dup = (float *)(s_dyn + (size_t)m_padded * (32 * KT + 4) + (size_t)SW * TPP * 8 * sizeof(f4v));   // [m_padded]
+    float *s_dup = (float *)(s_dyn + (size_t)m_padded * (QB + 4) + (size_t)SW * TPP * 8 * sizeof(f4v));   // [m_padded]
     unsigned short *s_lists = (unsigned short *)(s_dup + m_padded);     // [waves][CELL_SELF_CAP]
     __shared__ unsigned s_flag;
     SCAN_STAMP(0);
@@ -1525,11 +1725,17 @@ __global__ __launch_bounds__(64 * (KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_K
             s_next = (unsigned)SW;   // the first item of every wave is its own number
     }
     // (LDS-DMA for this fill — no staging registers — measured: C3 -0.5 %, a rank of 8 +5 % per pipelined step.  Not taken.)
-    for (int i = threadIdx.x; i < m_padded * 2 * KT; i += 64 * SW)
-        s_qf[i] = qfg[i];
+    if constexpr (CTR) {   // the batch's fp32 rows, padded to 16 dimensions (and to m_padded queries) with zeros
+        const int kq = K > 0 ? K : krt;
+        for (int i = threadIdx.x; i < m_padded * 16; i += 64 * SW)
+            ((float *)s_dyn)[i] = (i >> 4) < m && (i & 15) < kq ? Q[(size_t)(i >> 4) * kq + (i & 15)] : 0.0f;
+    } else {
+        for (int i = threadIdx.x; i < m_padded * 2 * KT; i += 64 * SW)
+            s_qf[i] = qfg[i];
+    }
     for (int i = threadIdx.x; i < m_padded; i += 64 * SW)
         s_thr[i] = thrg[i];
-    if constexpr (SELF)
+    if constexpr (SELF || CTR)
         for (int i = threadIdx.x; i < m_padded; i += 64 * SW)
             s_dup[i] = self.dup[i];
     __syncthreads();
@@ -1630,6 +1836,17 @@ __global__ __launch_bounds__(64 * (KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_K
             // (round 3: blocks three and four of the list too — lists average 120 entries on the 2^21-row shards of an
             // 8-GPU run, and every block beyond the second was a dependent read from memory)
             const unsigned l1 = SELF ? 0u : dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
+            float ccv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c_scale = 0.f, c_ratio = 0.f, c_bmax = 0.f, c_nmax = 0.f;
+            if constexpr (CTR) {   // the cell's frame: this lane's half of the centre, the scale, the cell's bounds
+                const float *__restrict__ fr = self.frame + (size_t)cellj * KNN_CELL_FRAME_WORDS;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    ccv[j] = fr[8 * half + j];
+                c_scale = fr[16];
+                c_ratio = fr[17];
+                c_bmax = fr[18];
+                c_nmax = fr[19];
+            }
             for (unsigned t0 = tb; t0 < te && !dead; t0 += TPP) {
                 const int nt = (int)min((unsigned)TPP, te - t0);   // wave-uniform
                 h8 ar[TPP][KT];
@@ -1670,10 +1887,16 @@ __global__ __launch_bounds__(64 * (KT == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_K
                         qid = dense ? (valid ? idx : 0u) : (unsigned)list[valid ? idx : 0u];
                     }
                     h8 b[KT];
+                    float th;
+                    if constexpr (CTR) {
+                        cell_centred_operand((const float *)s_dyn, K > 0 ? K : krt, qid, half, valid, ccv, c_scale, c_ratio, c_bmax, c_nmax, s_dup[qid],
+                                             s_thr[qid], b[0], th);
+                    } else {
 #pragma unroll
-                    for (int kk = 0; kk < KT; ++kk)
-                        b[kk] = s_qf[((qid >> 5) * KT + (unsigned)kk) * 64u + (unsigned)half * 32u + (qid & 31u)];
-                    const float th = valid ? s_thr[qid] : -INFINITY;
+                        for (int kk = 0; kk < KT; ++kk)
+                            b[kk] = s_qf[((qid >> 5) * KT + (unsigned)kk) * 64u + (unsigned)half * 32u + (qid & 31u)];
+                        th = valid ? s_thr[qid] : -INFINITY;
+                    }
                     // (a hit is recorded right behind its tile: parking the nine masks of a pass until its end, as round 2
                     // did, kept 18 registers busy with them — the allocator put the mask pairs in VGPRs)
 #pragma unroll
@@ -2093,6 +2316,145 @@ bool knn_geom_cells(ShardGeom &g, int k, long long n_global, int nranks, const f
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Per-cell frames (round 5; VERDICT r03 / r04: "centre fragments on their cell's box").  The shard's ONE frame rounds a
+// coordinate to fp16 with an error of 2^-12 of the box; where the rows of a cell sit in a thousandth of the box (clustered
+// data: 64 clusters of width 10^-3 — tools/distribution_check.py) that error is a quarter of the cluster's width, the
+// thresholds admit most of the cluster (2 200 candidates per query) and the batch ends in the exact evaluation of its listed
+// pairs.  In a frame of the CELL — fragment = fp16((row - centre_c) x scale_c), scale_c = sigma 2^e <= 2^8 sigma so that the
+// cell's rows fill [-1, 1] — the same rounding is 2^-12 of the cell, and everything knn_filter_dev.h derives for (centre,
+// sigma) holds for (centre_c, scale_c) word for word: the B operand of a (query, cell) pair is the query in THAT frame
+// (built by the scan's lanes from the fp32 query, which the block keeps in LDS: knn_cells_scan_kernel<CTR>), its threshold comes from Dup_q — a squared
+// DISTANCE, frame-free up to the power-of-two ratio — and the pair's own amax, the cell's bmax and nmax.
+// Built as a pass over the finished cell-sorted layout (rows gathered through perm: ~3 ms per 2^24 rows — taken only when the
+// build's sample says the data is clustered, or on request: knn_cells_recentre).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_cells_tile_cell_kernel(const unsigned *__restrict__ tile_start, unsigned ncells,
+                                                                  unsigned *__restrict__ tile_cell)
+{
+    // 32 threads per cell (a cell of a clustered set can hold thousands of tiles)
+    const unsigned c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, j = threadIdx.x & 31u;
+    if (c >= ncells)
+        return;
+    for (unsigned t = tile_start[c] + j; t < tile_start[c + 1u]; t += 32u)
+        tile_cell[t] = c;
+}
+
+// box[c][0..15] = min, box[c][16..31] = max of the cell's rows (ordered-uint images; rows outside the robust box — +INF norm —
+// and padding positions do not count).  One wave per tile: lane = (row, half of the dimensions).
+__global__ __launch_bounds__(256) void knn_cells_box_kernel(const float *__restrict__ R, int k, const unsigned *__restrict__ perm,
+                                                            const float *__restrict__ norms, unsigned ntiles,
+                                                            const unsigned *__restrict__ tile_cell, unsigned *__restrict__ box)
+{
+    const unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    if (t >= ntiles)
+        return;
+    const size_t pos = (size_t)t * 32 + (lane & 31);
+    const unsigned row = perm[pos];
+    const bool real = row != 0xFFFFFFFFu && norms[pos] < INFINITY;
+    float lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = 8 * half + j;
+        const float x = real && d < k ? R[(size_t)row * k + d] : 0.0f;
+        lo[j] = real && d < k ? x : INFINITY;
+        hi[j] = real && d < k ? x : -INFINITY;
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, KNN_WAVE));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, KNN_WAVE));
+        }
+    if ((lane & 31) == 0) {
+        unsigned *__restrict__ b = box + (size_t)tile_cell[t] * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (lo[j] < INFINITY)
+                guarded_atomic_min(&b[8 * half + j], f2ord(lo[j]));
+            if (hi[j] > -INFINITY)
+                guarded_atomic_max(&b[16 + 8 * half + j], f2ord(hi[j]));
+        }
+    }
+}
+
+// frame[c] = { centre[16], scale, 2^e, 0 (bmax), 0 (nmax) }: the centre is the middle of the cell's box, e the largest
+// exponent <= 8 for which the box, scaled, stays inside [-1, 1]
+__global__ __launch_bounds__(256) void knn_cells_frame_kernel(const unsigned *__restrict__ box, unsigned ncells, int k, float sigma,
+                                                              float *__restrict__ frame)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells)
+        return;
+    float *__restrict__ f = frame + (size_t)c * KNN_CELL_FRAME_WORDS;
+    float hw = 0.0f;
+    for (int d = 0; d < 16; ++d) {
+        float ctr = 0.0f;
+        if (d < k && box[(size_t)c * 32 + d] <= box[(size_t)c * 32 + 16 + d]) {   // (min <= max: the cell has a row)
+            const float lo = ord2f(box[(size_t)c * 32 + d]), hi = ord2f(box[(size_t)c * 32 + 16 + d]);
+            ctr = 0.5f * lo + 0.5f * hi;
+            hw = fmaxf(hw, fmaxf(hi - ctr, ctr - lo));
+        }
+        f[d] = ctr;
+    }
+    float ratio = 1.0f;
+    for (int e = 0; e < 8 && hw * sigma * (2.0f * ratio) <= 0.999f; ++e)
+        ratio *= 2.0f;
+    f[16] = sigma * ratio;
+    f[17] = ratio;
+    f[18] = 0.0f;
+    f[19] = 0.0f;
+}
+
+// The fragments, norms and norm halves of every tile again, in its cell's frame; frame[c][18] / [19] = the cell's largest
+// |coordinate| and norm.  Same arithmetic as the placement (fp32 subtract, exact power-of-two scale, round to nearest even,
+// exact products summed in fp32), same rule for rows outside the shard's robust box (they stay out: zero fragment, +INF norm).
+__global__ __launch_bounds__(256) void knn_cells_recentre_kernel(const float *__restrict__ R, int k, const unsigned *__restrict__ perm,
+                                                                 unsigned ntiles, const unsigned *__restrict__ tile_cell,
+                                                                 float *__restrict__ frame, h8 *__restrict__ frag,
+                                                                 float *__restrict__ norms, unsigned *__restrict__ norms2)
+{
+    const unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    if (t >= ntiles)
+        return;
+    const size_t pos = (size_t)t * 32 + (lane & 31);
+    const unsigned row = perm[pos];
+    const bool real = row != 0xFFFFFFFFu && norms[pos] < INFINITY;
+    float *__restrict__ f = frame + (size_t)tile_cell[t] * KNN_CELL_FRAME_WORDS;
+    const float scale = f[16];
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    float vmax = 0.0f, part = 0.0f;
+    if (real) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 8 * half + j;
+            const float sc = d < k ? (R[(size_t)row * k + d] - f[d]) * scale : 0.0f;
+            const _Float16 hval = (_Float16)sc;
+            const float back = (float)hval;
+            vmax = fmaxf(vmax, fabsf(back));
+            part = part + back * back;
+            v[j] = hval;
+        }
+    }
+    const float other = __shfl_xor(part, 32, KNN_WAVE);
+    const float nrm = half == 0 ? part + other : other + part;   // (dimensions 0..7) + (dimensions 8..15) on both lanes of a row
+    frag[(size_t)t * 64 + lane] = v;
+    if (half == 0) {
+        norms[pos] = real ? nrm : INFINITY;
+        norms2[pos] = pack_norm22(real ? nrm : INFINITY);
+    }
+    vmax = wave_max_f(vmax);
+    const float nmaxv = wave_max_f(real ? nrm : 0.0f);
+    if (lane == 0) {
+        guarded_atomic_max((unsigned *)&f[18], __float_as_uint(vmax));
+        guarded_atomic_max((unsigned *)&f[19], __float_as_uint(nmaxv));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side.
 // ------------------------------------------------------------------------------------------
@@ -2107,8 +2469,82 @@ void knn_cells_free(CellIndex *&c)
     (void)KNN_DEV_FREE(c->tmp_rows);
     (void)KNN_DEV_FREE(c->tmp_meta);
     (void)KNN_DEV_FREE(c->bucket_start);
+    (void)KNN_DEV_FREE(c->cell_frame);
+    (void)KNN_DEV_FREE(c->tile_cell);
     delete c;
     c = nullptr;
+}
+
+std::atomic<int> g_knn_cells_centre{0};                 // option `cells_centre`
+std::atomic<long long> g_knn_cells_centred_builds{0};   // read-only option `cells_centred_builds`
+
+// Moves a finished cell-sorted layout (k <= 16, no shard geometry) into per-cell frames — see the kernels.  Enqueues on `s`;
+// the caller's next synchronisation covers it.
+hipError_t knn_cells_recentre(FilterState &st, const float *r, hipStream_t s)
+{
+    if (!st.cells || st.kt != 1 || st.cells->geom || st.cells->centred)
+        return hipSuccess;
+    CellIndex &c = *st.cells;
+    const unsigned ntiles = (unsigned)st.ntiles;
+    unsigned *box = nullptr;
+    FTRY(KNN_DEV_ALLOC((void **)&c.cell_frame, (size_t)c.ncells * KNN_CELL_FRAME_WORDS * sizeof(float)));
+    FTRY(KNN_DEV_ALLOC((void **)&c.tile_cell, (size_t)std::max(1u, ntiles) * sizeof(unsigned)));
+    FTRY(KNN_DEV_ALLOC((void **)&box, (size_t)c.ncells * 32 * sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(box, 0xFF, (size_t)c.ncells * 32 * sizeof(unsigned), s);   // min = ~0; max: cleared below
+    if (e == hipSuccess)
+        e = hipMemset2DAsync(box + 16, 32 * sizeof(unsigned), 0, 16 * sizeof(unsigned), c.ncells, s);
+    if (e == hipSuccess && ntiles != 0u) {
+        hipLaunchKernelGGL(knn_cells_tile_cell_kernel, dim3((c.ncells * 32u + 255u) / 256u), dim3(256), 0, s, c.tile_start, c.ncells, c.tile_cell);
+        hipLaunchKernelGGL(knn_cells_box_kernel, dim3((ntiles + 3u) / 4u), dim3(256), 0, s, r, st.k, c.perm, st.ref_norms, ntiles, c.tile_cell, box);
+        hipLaunchKernelGGL(knn_cells_frame_kernel, dim3((c.ncells + 255u) / 256u), dim3(256), 0, s, box, c.ncells, st.k, st.sigma, c.cell_frame);
+        hipLaunchKernelGGL(knn_cells_recentre_kernel, dim3((ntiles + 3u) / 4u), dim3(256), 0, s, r, st.k, c.perm, ntiles, c.tile_cell,
+                           c.cell_frame, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);   // (box is scratch)
+    (void)KNN_DEV_FREE(box);
+    FTRY(e);
+    c.centred = true;
+    ++g_knn_cells_centred_builds;
+    return hipSuccess;
+}
+
+// What the builds call once a cell-sorted layout stands: per-cell frames when option `cells_centre` asks for them (1), or
+// (0) when the build's host sample looks clustered.  samp may be null (no sample at hand: only on request).
+hipError_t knn_cells_maybe_recentre(FilterState &st, const float *r, const float *samp, long long samples, hipStream_t s)
+{
+    if (!st.usable || !st.cells || st.kt != 1 || st.cells->geom)
+        return hipSuccess;
+    const int opt = g_knn_cells_centre;
+    if (opt == 2 || (opt == 0 && !(samp && knn_cells_sample_is_clustered(samp, samples, st.k, st.sigma))))
+        return hipSuccess;
+    return knn_cells_recentre(st, r, s);
+}
+
+// Does the build's host sample look clustered?  Median, over up to 256 sample rows, of the distance (largest coordinate
+// difference) to the nearest other sample row, in units of the frame's box (scaled: the box is [-1, 1]): uniform or gaussian
+// data in 16 dimensions ~0.5-1, 1000 blobs of 0.05 of the box likewise (the sample's neighbours are in other blobs), 64
+// clusters of 10^-3 of the box 0.007.  Below 1/16 the per-cell frames pay for their pass over the rows.
+bool knn_cells_sample_is_clustered(const float *samp, long long samples, int k, float sigma)
+{
+    const long long take = std::min<long long>(samples, 256), step = take > 0 ? samples / take : 1;
+    if (take < 32)
+        return false;
+    std::vector<float> nn((size_t)take, INFINITY);
+    for (long long i = 0; i < take; ++i)
+        for (long long j = i + 1; j < take; ++j) {
+            float dmax = 0.0f;
+            const float *a = samp + (size_t)(i * step) * k, *b = samp + (size_t)(j * step) * k;
+            for (int d = 0; d < k; ++d)
+                dmax = std::max(dmax, fabsf(a[d] - b[d]));
+            if (!(dmax == dmax))
+                return false;
+            nn[(size_t)i] = std::min(nn[(size_t)i], dmax);
+            nn[(size_t)j] = std::min(nn[(size_t)j], dmax);
+        }
+    std::nth_element(nn.begin(), nn.begin() + take / 2, nn.end());
+    return nn[(size_t)(take / 2)] * sigma < 1.0f / 16.0f;
 }
 
 // The fast build in stages (an ingest runs the scatter chunk by chunk under the copy): rows [row0, row1) of the shard, at `r`
@@ -2500,12 +2936,13 @@ static hipError_t ensure_cells_workspace(FilterState &st, FilterWorkspace &w, in
 //   slice    records [w x slice, (w + 1) x slice) belong to wave w
 //   ovf      records [ovf_base, ovf_base + ovf_cap) are the area all waves share; nlists x slice <= ovf_base
 //   lds      dynamic LDS of the scan: m_padded x (32 B operand + 4 B threshold) + one norm window per wave
-CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded, bool self_lists, int kt)
+CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded, bool self_lists, int kt,
+                                 bool centred)
 {
     CellScanPlan p;
-    const unsigned sw = kt == 1 ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2;
+    const unsigned sw = kt == 1 && !centred ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2;
     p.waves = sw;
-    p.blocks = (unsigned)num_cu * (unsigned)(kt == 1 ? blocks_per_cu : 1);
+    p.blocks = (unsigned)num_cu * (unsigned)(kt == 1 && !centred ? blocks_per_cu : 1);
     if (p.blocks * sw > nitems)
         p.blocks = std::max(1u, nitems / sw);
     p.nlists = p.blocks * sw;
@@ -2520,9 +2957,11 @@ CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems,
     // holds ONE block, so that block has sixteen waves — four per SIMD; the launch raises the kernel's dynamic-LDS limit above
     // the default 64 KiB.  Round 5, one box, ms per step at k 17 / 18 / 20, n 2^24: four tiles per pass, 12 waves, 96
     // registers 0.282 / 0.315 / 0.428; five 0.269 / 0.303 / 0.399; nine, 12 waves (3 per SIMD) 0.237 / 0.242 / 0.352)
-    p.lds_bytes = (size_t)m_padded * (32 * kt + 4) + (size_t)sw * CELL_TILES_PER_PASS * 8 * sizeof(f4v);
+    p.lds_bytes = (size_t)m_padded * ((centred ? 64 : 32 * kt) + 4) + (size_t)sw * CELL_TILES_PER_PASS * 8 * sizeof(f4v);   // (per-cell frames: the queries' fp32 rows)
     if (self_lists)   // the self-listing scan: the batch's Dup values + one list room per wave
         p.lds_bytes += (size_t)m_padded * sizeof(float) + (size_t)sw * CELL_SELF_CAP * sizeof(unsigned short);
+    else if (centred)   // per-cell frames: the batch's Dup values
+        p.lds_bytes += (size_t)m_padded * sizeof(float);
     return p;
 }
 
@@ -2561,8 +3000,9 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     const bool one_block = st.scan_blocks == 1 || (st.scan_blocks == 0 && st.several_slots && c.ncells <= 32768u);
     // Who makes the cells' lists of queries: knn_cells_match_kernel in a launch of its own (rounds 2-4), or the scan's waves
     // for the items they take (round 5, cell_self_list).  Policy in knn_cells_lists_policy.
-    const bool self_lists = st.kt == 1 && (st.cells_lists == 2 || (st.cells_lists == 0 && knn_cells_lists_policy(c.ncells, st.several_slots)));
-    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded, self_lists, st.kt);
+    const bool centred = c.centred;   // per-cell frames (knn_cells_recentre): the centred prep and scan, lists from the match launch
+    const bool self_lists = st.kt == 1 && !centred && (st.cells_lists == 2 || (st.cells_lists == 0 && knn_cells_lists_policy(c.ncells, st.several_slots)));
+    const CellScanPlan plan = knn_cells_scan_plan(num_cu, one_block ? 1 : 2, c.nitems, w.rec_cap, m_padded, self_lists, st.kt, centred);
     const unsigned gx = plan.blocks;
     w.nlists = plan.nlists;
     w.ovf_cap = plan.ovf_cap;
@@ -2586,17 +3026,22 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
             layer.first[r_] = c.geom->first_cell(r_);
         layer.part_bytes = c.geom->part_bytes();
     }
-#define KNN_PREP_LAUNCH(PWV, SDV, KTV)                                                                                     \
-    hipLaunchKernelGGL((knn_cells_prep_kernel<PWV, SDV, KTV>), dim3((unsigned)m_padded), dim3(64 * PWV), 0, s, q, m, m_padded, g, \
+#define KNN_PREP_LAUNCH(PWV, SDV, ...)                                                                                     \
+    hipLaunchKernelGGL((knn_cells_prep_kernel<PWV, SDV, ##__VA_ARGS__>), dim3((unsigned)m_padded), dim3(64 * PWV), 0, s, q, m, m_padded, g, \
                        c.bounds, sigma2, st.center, st.sigma, c.tile_start, st.ntiles, (const h8 *)st.ref_frags,            \
                        st.ref_norms2, layer, (h8 *)w.qry_frags, w.lo_tab, w.hi_tab, st.bmax, st.nmax, kAmaxLimit, w.thr,    \
-                       w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init, self_lists ? 1 : 0)
+                       w.dup, w.ctl_cur, ctl_next, w.counts, w.nlists, keys_init, self_lists ? 1 : 0, c.cell_frame, c.tile_cell)
     // (cell-range shards take the same four seed cells — those of another rank through the seed layer.  Sixteen seed cells
     // (SD = 4) leave 20 % fewer candidates, as the simulation said, and cost more than they save: the prep kernel is a chain
     // of dependent round trips, and at a rank's size the step is made of those — emulated rank of N = 8, ms per step / one
     // batch at a time: 16 cells x 2 tiles 0.0302 / 0.0526, 8 x 2 0.0279 / 0.0493, 4 x 2 0.0275 / 0.0471, 4 x 4 0.0271 / 0.0473;
     // N = 4: 0.0432 / 0.0423 / 0.0414 / 0.0408.  profiles/r04_seed_sweep.txt)
-    if (st.kt == 2) {
+    if (centred) {
+        if (st.several_slots)
+            KNN_PREP_LAUNCH(2, 2, 1, true);
+        else
+            KNN_PREP_LAUNCH(4, 2, 1, true);
+    } else if (st.kt == 2) {
         if (st.several_slots)
             KNN_PREP_LAUNCH(2, 2, 2);
         else
@@ -2632,6 +3077,10 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         self.dup = w.dup;
         self.sa = c.sa;
         self.m_padded = m_padded;
+    }
+    if (centred) {
+        self.dup = w.dup;
+        self.frame = c.cell_frame;
     }
     const unsigned list_cap = self_lists ? CELL_SELF_CAP : c.cap;
     static const bool trace_cells = getenv("KNN_MI355X_TRACE_CELLS") != nullptr;   // (read once: a query may run beside a thread that changes the environment)
@@ -2689,7 +3138,26 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         else                                                                                                               \
             KNN_SCAN_LAUNCH(DYNV, 0, SELFV);                                                                               \
     } while (0)
-    if (st.kt == 2) {   // 16 < k <= 32: run-time k, lists from the match launch
+#define KNN_SCAN_LAUNCH_K5(DYNV)   /* per-cell frames: 92 KiB of dynamic LDS for 1024 queries (their fp32 rows) */                  \
+    do {                                                                                                                   \
+        if (st.k == 16) {                                                                                                  \
+            if (lds > (size_t)(64u << 10))                                                                                 \
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<DYNV, 16, false, 1, true>,                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+            KNN_SCAN_LAUNCH(DYNV, 16, false, 1, true);                                                                     \
+        } else {                                                                                                           \
+            if (lds > (size_t)(64u << 10))                                                                                 \
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<DYNV, 0, false, 1, true>,                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+            KNN_SCAN_LAUNCH(DYNV, 0, false, 1, true);                                                                      \
+        }                                                                                                                  \
+    } while (0)
+    if (centred) {   // per-cell frames: lists from the match launch
+        if (dyn)
+            KNN_SCAN_LAUNCH_K5(true);
+        else
+            KNN_SCAN_LAUNCH_K5(false);
+    } else if (st.kt == 2) {   // 16 < k <= 32: run-time k, lists from the match launch
         if (lds > (size_t)(64u << 10)) {   // (more than the default limit of dynamic LDS: say so, per launch — the attribute is per device)
             if (dyn)
                 FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<true, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2711,6 +3179,7 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
         else
             KNN_SCAN_LAUNCH_K(false, false);
     }
+#undef KNN_SCAN_LAUNCH_K5
 #undef KNN_SCAN_LAUNCH_K
 #undef KNN_SCAN_LAUNCH
     FTRY(hipGetLastError());

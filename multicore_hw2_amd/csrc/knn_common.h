@@ -1,5 +1,6 @@
 // knn_common.h — shared declarations of the knn_mi355x library internals (gfx950 only).
 #pragma once
+#include <atomic>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -197,7 +198,14 @@ struct CellIndex {
     unsigned cell_base = 0;
     const ShardGeom *geom = nullptr;      // (borrowed: outlives the index)
     const unsigned char *seed_layer = nullptr;   // device: every rank's part, nranks x geom->part_bytes() (borrowed)
+    // per-cell frames (round 5, clustered data; knn_cells_recentre): the fragments of cell c are fp16((row - centre_c) x scale_c)
+    // instead of the shard's one frame — cell_frame[c] = { centre[16] (the rows' own units), scale_c = sigma 2^e, 2^e,
+    // max |fragment coordinate| of the cell, max fragment norm of the cell }; tile_cell[t] = the cell tile t belongs to
+    bool centred = false;
+    float *cell_frame = nullptr;          // device [ncells][KNN_CELL_FRAME_WORDS]
+    unsigned *tile_cell = nullptr;        // device [ntiles]
 };
+#define KNN_CELL_FRAME_WORDS 20
 
 struct FilterState {
     bool usable = false;       // references finite and in a sane range: filter layouts exist
@@ -256,11 +264,16 @@ struct CellScanPlan {
     size_t lds_bytes = 0;
 };
 CellScanPlan knn_cells_scan_plan(int num_cu, int blocks_per_cu, unsigned nitems, unsigned rec_cap, int m_padded,
-                                 bool self_lists = false, int kt = 1);
+                                 bool self_lists = false, int kt = 1, bool centred = false);
 bool knn_cells_lists_policy(unsigned ncells, bool several_slots);
 hipError_t knn_cells_place_rows(FilterState &st, const float *r_dev, const unsigned *code, unsigned *fill, unsigned *out,
                                 unsigned ocap, hipStream_t s);
 void knn_cells_free(CellIndex *&c);
+hipError_t knn_cells_recentre(FilterState &st, const float *r, hipStream_t s);
+bool knn_cells_sample_is_clustered(const float *samp, long long samples, int k, float sigma);
+hipError_t knn_cells_maybe_recentre(FilterState &st, const float *r, const float *samp, long long samples, hipStream_t s);
+extern std::atomic<int> g_knn_cells_centre;
+extern std::atomic<long long> g_knn_cells_centred_builds;
 void knn_cells_workspace_free(FilterWorkspace &w);
 // One batch of <= KNN_CELL_BATCH queries already prepared by the filter's query-fragment kernel: seed, thresholds,
 // match, scan (records in w, as the full scan leaves them).  Asynchronous.

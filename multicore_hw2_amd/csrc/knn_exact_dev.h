@@ -216,6 +216,7 @@ struct CellSelf {
     const float *hi;     // device [high entries][m_padded]
     const float *dup;    // device [m_padded]
     int sa, m_padded;
+    const float *frame;  // per-cell frames (the centred scan): device [cells][KNN_CELL_FRAME_WORDS]; null otherwise
 };
 
 // -> the list's length; entries beyond CELL_SELF_CAP are counted, not stored.  `dupv`: the batch's Dup values (LDS in the

@@ -1710,7 +1710,13 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
         memcpy(&st.bmax, &hout[0], 4);
         memcpy(&st.nmax, &hout[1], 4);
         st.usable = true;
-        return hipSuccess;
+        if (!geom) {   // clustered data (or on request): the fragments again, each cell in its own frame
+            e = knn_cells_maybe_recentre(st, r, samples > 0 ? samp.data() : nullptr, samples, s);
+            lap("per-cell frames (if any)");
+            if (e != hipSuccess)
+                knn_filter_free(st);
+        }
+        return e;
     };
     if (geom) {
         // Cell-range shard of a global grid: centre, scale and cuts are the grid's (identical on every rank: the ranks' fp16
@@ -1956,7 +1962,12 @@ hipError_t knn_filter_build(FilterState &st, int k, long long n, const float *r,
     memcpy(&st.bmax, &hout[0], 4);
     memcpy(&st.nmax, &hout[1], 4);
     st.usable = true;
-    return hipSuccess;
+    if (st.cells) {
+        e = knn_cells_maybe_recentre(st, r, samp.data(), samples_used, s);
+        if (e != hipSuccess)
+            knn_filter_free(st);
+    }
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2300,7 +2311,10 @@ hipError_t knn_filter_build_cells_from_host(FilterState &st, int k, long long n,
     memcpy(&st.bmax, &hout[0], 4);
     memcpy(&st.nmax, &hout[1], 4);
     st.usable = true;
-    return hipSuccess;
+    e = knn_cells_maybe_recentre(st, r_dev, cut_samp.data(), samples / 4, compute);
+    if (e != hipSuccess)
+        knn_filter_free(st);
+    return e;
 }
 
 static hipError_t ensure_workspace(FilterState &st, FilterWorkspace &w, int m)
@@ -2737,7 +2751,7 @@ hipError_t knn_filter_query(FilterState &st, int slot, int m, const float *q, co
     // raises its own FALLBACK flag on the device and is answered by the gated exact scan; the next batch is back on
     // the pruned path.  (Round 2 sent the whole index to full scans for 256 calls after such a batch, on a pinned
     // host word read here whenever the host happened to get to it.)
-    const bool cells = st.cells && st.cells_policy != 2 && st.kt <= 2;
+    const bool cells = st.cells && (st.cells_policy != 2 || st.cells->centred) && st.kt <= 2;   // (per-cell frames: the full scan cannot read them)
     w.last_used_cells = cells;
     w.ev_begin = ev_begin;
     w.ev_end = ev_end;

@@ -19,7 +19,7 @@ def _need_gpu():
     assert os.path.exists(pkg.lib_path), "libknn_mi355x.so not built (no CPU fallback exists)"
     assert pkg.device_count() >= 1, "no GPU visible to libknn_mi355x.so"
     yield
-    for name in ("path", "shards", "cells", "scan_deal", "cells_build", "cells_lists"):
+    for name in ("path", "shards", "cells", "scan_deal", "cells_build", "cells_lists", "cells_centre"):
         pkg.set_option(name, 0)
 
 
@@ -150,12 +150,14 @@ def test_long_record_lists_left_to_the_tail_kernel(oracle, k, n):
     R = (rng.normal(0, 1, (n, k)) / np.sqrt(rng.random((n, 1)))).astype(np.float32)
     Q = (rng.normal(0, 1, (m, k)) / np.sqrt(rng.random((m, 1)))).astype(np.float32)
     want = oracle.v0(k, Q, R, threads=THREADS)
-    ix = pkg.KnnIndex(k, R)
+    pkg.set_option("cells_centre", 2)   # (the shard's one frame: with per-cell frames — what the library's policy picks for these rows since round 5 — a fifth of the records are left)
     try:
+        ix = pkg.KnnIndex(k, R)
         got, st = _query(ix, Q)
         again, _ = _query(ix, Q)
-    finally:
         ix.close()
+    finally:
+        pkg.set_option("cells_centre", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
     np.testing.assert_array_equal(again, got)
     assert st[0] == 4 and st[2] == 0, st
@@ -232,12 +234,15 @@ def test_both_ways_of_dealing_items_to_the_scan_waves_are_bit_exact(oracle, deal
     assert st[0] == 4 and st[2] in (0, 2), st
 
 
-def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle):
+@pytest.mark.parametrize("centre", [0, 1])
+def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle, centre):
     """1024 copies of one query want the same ~4 % of the cells, with all 1024 on each of their lists: far beyond a
     list's on-chip room (256 entries at 2^16 cells).  Round 2 answered such a batch with the exact scan and sent the
     index to full scans for its next 256 calls; now the crowded cells are scored `dense` — against the whole batch,
-    which is what their lists asked for — the batch stays on the pruned path with no fallback, and so does the next."""
+    which is what their lists asked for — the batch stays on the pruned path with no fallback, and so does the next.
+    (centre = 1: the same with per-cell frames — a dense cell there meets queries that never listed it.)"""
     k, n, m = 16, 1 << 24, 1024
+    pkg.set_option("cells_centre", centre)
     dev = torch.device("cuda:0")
     r_d = torch.empty(n * k, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -266,6 +271,7 @@ def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle):
         np.testing.assert_array_equal(got[sel], want_var)
     finally:
         ix.close()
+        pkg.set_option("cells_centre", 0)
 
 
 def test_queries_whose_seed_cells_are_empty_are_bounded_by_a_strided_sample(oracle):
@@ -457,6 +463,7 @@ def test_both_makers_of_the_cells_query_lists_are_bit_exact(oracle, lists, deal,
     pkg.set_option("cells", 1)
     pkg.set_option("scan_deal", deal)
     pkg.set_option("cells_lists", lists)
+    pkg.set_option("cells_centre", 2)   # (the shard's one frame: per-cell frames take their lists from the match launch only, and keep tight clusters on the filter)
     try:
         ix = pkg.KnnIndex(k, R)
         got, st = _query(ix, Q)
@@ -466,6 +473,7 @@ def test_both_makers_of_the_cells_query_lists_are_bit_exact(oracle, lists, deal,
         pkg.set_option("cells", 0)
         pkg.set_option("scan_deal", 0)
         pkg.set_option("cells_lists", 0)
+        pkg.set_option("cells_centre", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"lists {lists} deal {deal} {dist} k={k} stats={st}")
     np.testing.assert_array_equal(again, got)
     assert st[0] == 4 and st[2] in (0, 2), st
@@ -583,3 +591,127 @@ def test_c3_shape_with_20_dimensions_every_query_on_the_pruned_path(oracle, k):
     assert st[0] == 4 and st[2] == 0, st
     want = oracle.v0(k, Q, oracle.synth(n * k, 1001), threads=THREADS)
     np.testing.assert_array_equal(got, want)
+
+
+def _clusters(rng, k, m, n, nclusters, width):
+    """`nclusters` blobs of standard deviation `width` (of a unit box): what tools/distribution_check.py calls clusters64."""
+    c = rng.random((nclusters, k), dtype=np.float32)
+    R = (c[rng.integers(0, nclusters, n)] + rng.normal(0, width, (n, k))).astype(np.float32)
+    Q = (c[rng.integers(0, nclusters, m)] + rng.normal(0, width, (m, k))).astype(np.float32)
+    return np.ascontiguousarray(Q), np.ascontiguousarray(R)
+
+
+@pytest.mark.parametrize("k", [16, 13, 8, 5])
+@pytest.mark.parametrize("dist", ["uniform", "offset", "lattice", "clustered", "skewed", "queries_outside", "copies"])
+def test_per_cell_frames_are_bit_exact_on_every_distribution(oracle, k, dist):
+    """Round 5 (per-cell centring): `cells_centre` = 1 moves every cell's fragments into the cell's own frame
+    (centre of its box, up to 2^8 more scale); the prep kernel bounds every seed cell in that cell's frame, the scan makes the B
+    operand and the threshold of each (query, cell) pair itself.  Same bar as the shard-wide frame: v0's indices, on ties, on
+    the cuts, far outside the box."""
+    m, n = 777, (1 << 18) + 4099
+    rng = np.random.default_rng(k * 7 + len(dist))
+    Q, R = _cases(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    before = pkg.get_option("cells_centred_builds")
+    pkg.set_option("cells", 1)
+    pkg.set_option("cells_centre", 1)
+    try:
+        ix = pkg.KnnIndex(k, R, base_index=3)
+        got, st = _query(ix, Q)
+        again, _ = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("cells_centre", 0)
+    assert pkg.get_option("cells_centred_builds") == before + 1
+    np.testing.assert_array_equal(got - 3, want, err_msg=f"{dist} k={k} stats={st}")
+    np.testing.assert_array_equal(again, got)
+    assert st[0] == 4, st
+
+
+@pytest.mark.parametrize("deal,build", [(1, 0), (2, 1), (2, 2)])
+@pytest.mark.parametrize("dist", ["tight_clusters", "low_rank", "mixture", "one_point"])
+def test_per_cell_frames_on_clustered_and_degenerate_data(oracle, dist, deal, build):
+    """The same off the cube (fat cells in several work items, one cell holding the shard, rows that all tie), with both ways of
+    dealing items to the scan's waves and all three builds in front of the re-centring pass."""
+    k, m, n = 16, 1024, (1 << 19) + 33
+    rng = np.random.default_rng(len(dist) * 131 + deal)
+    Q, R = _off_the_cube(rng, dist, k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("cells_centre", 1)
+    pkg.set_option("scan_deal", deal)
+    pkg.set_option("cells_build", build)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        for name in ("cells", "cells_centre", "scan_deal", "cells_build"):
+            pkg.set_option(name, 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"{dist} stats={st}")
+    assert st[0] == 4 and st[2] in (0, 2), st
+
+
+def test_library_policy_gives_tight_clusters_their_own_frames_and_the_filter_separates_them(oracle):
+    """64 clusters of 10^-3 of the box, k 16, n 2^22, m 1024 (tools/distribution_check.py's `clusters64`): in the shard's one
+    frame the fp16 step is a quarter of a cluster's width — 2.2 M candidates, the batch ends in the exact evaluation of its
+    listed pairs (stats[2] == 2; 0.34 ms per step).  The build's sample sees the clustering (library policy, no option set),
+    the layout gets per-cell frames, and the batch stays on the filter with a few candidates per query; switched off
+    (`cells_centre` = 2) it is what it was.  Uniform rows keep the shard's frame.  Every answer against the oracle."""
+    k, m, n = 16, 1024, 1 << 22
+    rng = np.random.default_rng(64)
+    Q, R = _clusters(rng, k, m, n, 64, 1e-3)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    before = pkg.get_option("cells_centred_builds")
+    ix = pkg.KnnIndex(k, R)
+    try:
+        got, st = _query(ix, Q)
+    finally:
+        ix.close()
+    assert pkg.get_option("cells_centred_builds") == before + 1
+    np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
+    assert st[0] == 4 and st[2] == 0 and st[1] < 64 * m, st
+    pkg.set_option("cells_centre", 2)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got2, st2 = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells_centre", 0)
+    assert pkg.get_option("cells_centred_builds") == before + 1
+    np.testing.assert_array_equal(got2, want)
+    assert st2[2] == 2 or st2[1] > 8 * st[1], (st, st2)
+    U = rng.random((1 << 20, k), dtype=np.float32)
+    ix = pkg.KnnIndex(k, U)
+    ix.close()
+    assert pkg.get_option("cells_centred_builds") == before + 1
+
+
+def test_per_cell_frames_with_dense_cells_and_queries_that_do_not_fit_a_cells_frame(oracle):
+    """Tight clusters (frames scaled by the full 2^8) and a batch that crowds one cell's list beyond its room — 700 near-copies of
+    one row — beside queries elsewhere in the box, far outside it, and not finite: the crowded cell is scored against the whole
+    batch, and the queries that do not fit its frame (|coordinate| > 1024 cell units) are ruled out by their distance along that
+    coordinate or pass everything; the non-finite query sends the batch to the exact scan.  Every answer against the oracle."""
+    k, m, n = 16, 1024, 1 << 22      # (2^14 cells: a list holds 512 queries)
+    rng = np.random.default_rng(5)
+    Q, R = _clusters(rng, k, m, n, 16, 2e-4)
+    Q[:700] = R[12345] + rng.normal(0, 1e-5, (700, k)).astype(np.float32)
+    Q[700:716] = rng.random((16, k), dtype=np.float32) * 40.0 - 20.0      # far outside the box
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells_centre", 1)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        assert st[0] == 4 and st[2] == 0, st      # (the far queries are bounded through the triangle inequality: no exact scan)
+        dense = ix.debug_counters()[1]
+        Qn = Q.copy()
+        Qn[5, 3] = np.float32("nan")
+        got_n, st_n = _query(ix, Qn)
+        ix.close()
+    finally:
+        pkg.set_option("cells_centre", 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
+    assert dense > 0, "the crowded cell did not overflow its list: the test does not reach the dense path"
+    keep = np.arange(m) != 5
+    np.testing.assert_array_equal(got_n[keep], want[keep])

@@ -56,6 +56,10 @@ def make(name):
     raise ValueError(name)
 
 
+for opt in os.environ.get("KNN_DC_OPTS", "").split(","):   # e.g. KNN_DC_OPTS=cells_centre=1 (per-cell frames always), =2 (never)
+    if opt:
+        pkg.set_option(opt.split("=")[0], int(opt.split("=")[1]))
+before_centred = pkg.get_option("cells_centred_builds")
 for name in sys.argv[1:] or ["uniform", "gaussian", "heavy_tail", "clusters64", "low_rank", "offset_1e4", "mixture1000", "unit_sphere",
                              "bytes_0_255"]:
     q_d, r_d = make(name)
@@ -85,5 +89,7 @@ for name in sys.argv[1:] or ["uniform", "gaussian", "heavy_tail", "clusters64", 
     ok = (out.cpu().numpy()[sel] == o.v0(k, Q[sel], R)).all()
     print(f"{name:12s} {dt * 1e3:8.3f} ms/step  path={ {1: 'exact', 2: 'filter', 3: 'grid', 4: 'cell-pruned filter'}.get(st[0], st[0])}  records={st[1]:9d}  "
           f"fallback={ {0: 'none', 1: 'exact scan of the shard', 2: 'exact over the listed cells'}[st[2]]}  bit-exact on 16 sampled queries: {ok}"
-          f"  (runs: {' '.join('%.3f' % (v * 1e3) for v in reps)})", flush=True)
+          f"  (runs: {' '.join('%.3f' % (v * 1e3) for v in reps)})"
+          f"{'  per-cell frames' if pkg.get_option('cells_centred_builds') != before_centred else ''}", flush=True)
+    before_centred = pkg.get_option("cells_centred_builds")
     ix.close()
