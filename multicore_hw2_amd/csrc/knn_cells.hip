@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(64 * PW, KT == 1 && !CTR ? 4 : 3) void knn_cells_pr
 {
 #pragma clang fp contract(off)
     constexpr int SEEDS = 1 << SD, NS = SEEDS / PW;   // seed cells in all, per wave
-    constexpr int PREP_TILES = KT == 1 ? CELL_PREP_TILES : 4;   // seed tiles a wave requests at once (KT KiB each)
+    constexpr int PREP_TILES = KT == 1 ? CELL_PREP_TILES : 6;   // seed tiles a wave requests at once (KT KiB each)
     __shared__ float s_gap[16][CELL_MAX_BINS];
     __shared__ float s_red[PW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2522,29 +2522,33 @@ hipError_t knn_cells_maybe_recentre(FilterState &st, const float *r, const float
     return knn_cells_recentre(st, r, s);
 }
 
-// Does the build's host sample look clustered?  Median, over up to 256 sample rows, of the distance (largest coordinate
-// difference) to the nearest other sample row, in units of the frame's box (scaled: the box is [-1, 1]): uniform or gaussian
+// Does the build's host sample look clustered?  Median, over 64 sample rows, of the distance (largest coordinate difference)
+// to the nearest of up to 256 other sample rows, in units of the frame's box (scaled: the box is [-1, 1]): uniform or gaussian
 // data in 16 dimensions ~0.5-1, 1000 blobs of 0.05 of the box likewise (the sample's neighbours are in other blobs), 64
-// clusters of 10^-3 of the box 0.007.  Below 1/16 the per-cell frames pay for their pass over the rows.
+// clusters of 10^-3 of the box 0.007.  Below 1/16 the per-cell frames pay for their pass over the rows.  (0.05 ms of host
+// arithmetic in every build of a cell-sorted layout.)
 bool knn_cells_sample_is_clustered(const float *samp, long long samples, int k, float sigma)
 {
-    const long long take = std::min<long long>(samples, 256), step = take > 0 ? samples / take : 1;
-    if (take < 32)
+    const long long cand = std::min<long long>(samples, 256), step = cand > 0 ? samples / cand : 1, probes = std::min<long long>(cand, 64);
+    if (cand < 32)
         return false;
-    std::vector<float> nn((size_t)take, INFINITY);
-    for (long long i = 0; i < take; ++i)
-        for (long long j = i + 1; j < take; ++j) {
+    std::vector<float> nn((size_t)probes, INFINITY);
+    for (long long i = 0; i < probes; ++i) {
+        const float *a = samp + (size_t)(i * (cand / probes) * step) * k;
+        for (long long j = 0; j < cand; ++j) {
+            const float *b = samp + (size_t)(j * step) * k;
+            if (a == b)
+                continue;
             float dmax = 0.0f;
-            const float *a = samp + (size_t)(i * step) * k, *b = samp + (size_t)(j * step) * k;
             for (int d = 0; d < k; ++d)
                 dmax = std::max(dmax, fabsf(a[d] - b[d]));
             if (!(dmax == dmax))
                 return false;
             nn[(size_t)i] = std::min(nn[(size_t)i], dmax);
-            nn[(size_t)j] = std::min(nn[(size_t)j], dmax);
         }
-    std::nth_element(nn.begin(), nn.begin() + take / 2, nn.end());
-    return nn[(size_t)(take / 2)] * sigma < 1.0f / 16.0f;
+    }
+    std::nth_element(nn.begin(), nn.begin() + probes / 2, nn.end());
+    return nn[(size_t)(probes / 2)] * sigma < 1.0f / 16.0f;
 }
 
 // The fast build in stages (an ingest runs the scatter chunk by chunk under the copy): rows [row0, row1) of the shard, at `r`

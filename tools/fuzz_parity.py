@@ -127,6 +127,8 @@ def cells_case(o, rng, case):
     pkg.set_option("scan_blocks", blocks)
     pkg.set_option("cells_lists", lists)
     pkg.set_option("cells_build", build)
+    centre = int(rng.choice([0, 1, 1, 2]))                            # round 5: per-cell frames by policy / always / never
+    pkg.set_option("cells_centre", centre)
     Q2 = make_data(rng, "uniform" if kind in ("tight", "lowrank", "mixture", "onepoint") else str(rng.choice(["uniform", kind])), m, k)
     if rng.random() < 0.3:
         Q[: min(m, 8)] = R[rng.integers(0, n, min(m, 8))]
@@ -134,7 +136,7 @@ def cells_case(o, rng, case):
         R[rng.integers(0, n), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3e38]))
     if rng.random() < 0.1:
         Q2[rng.integers(0, m), rng.integers(0, k)] = np.float32(rng.choice([np.nan, np.inf, 1e30]))
-    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, deal=deal, blocks=blocks, lists=lists, build=build)
+    desc = dict(case=case, k=k, m=m, n=n, kind=kind, shards=shards, deal=deal, blocks=blocks, lists=lists, build=build, centre=centre)
     if os.environ.get("FUZZ_VERBOSE") == "1":
         print("case", desc, "%.1f s" % time.time(), flush=True)
     pkg.set_option("cells", 1)
