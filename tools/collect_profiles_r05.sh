@@ -81,9 +81,12 @@ B 640_16384_65536 --workload 640,16384,65536 --cpu-queries 0 --steps 20 --warmup
 B 1024_65536_65536 --workload 1024,65536,65536 --cpu-queries 0 --steps 10 --warmup 2
 B 2048_8192_32768 --workload 2048,8192,32768 --cpu-queries 0 --steps 20 --warmup 3
 step "16 < k <= 32 on the pruned scan against the full scan"
-for k in 17 18 20 22; do B ${k}_1024_16777216 --workload $k,1024,16777216 --cpu-queries 0 --steps 60; B ${k}_1024_16777216_fullscan --workload $k,1024,16777216 --cpu-queries 0 --steps 60 --cells 2; done
+for k in 17 18 20 22 24; do B ${k}_1024_16777216 --workload $k,1024,16777216 --cpu-queries 0 --steps 60; B ${k}_1024_16777216_fullscan --workload $k,1024,16777216 --cpu-queries 0 --steps 60 --cells 2; done
+B 26_1024_16777216_pruned --workload 26,1024,16777216 --cpu-queries 0 --steps 60 --cells 1
 B 17_1024_4194304 --workload 17,1024,4194304 --cpu-queries 64 --steps 60
 B 20_1024_4194304 --workload 20,1024,4194304 --cpu-queries 64 --steps 60
+B 22_1024_8388608 --workload 22,1024,8388608 --cpu-queries 0 --steps 60
+KT 20_1024_16777216_serial --workload 20,1024,16777216 --serial --steps 40
 step "SQ counters of the deep-K scans"
 bash $R/tools/pmc_sq_deepk.sh gpurun_out/r05_final c5 c5 > $O/deepk_sq_counters.txt 2>&1 || exit 1
 echo done b
@@ -92,6 +95,8 @@ if [ "$1" = c ]; then
 cd $R
 step "off the uniform cube"
 ( timeout -k 10 300 python3 tools/distribution_check.py 2>&1 | grep -v amdgpu.ids > $O/distribution_check.txt ) || exit 1
+( KNN_DC_OPTS=cells_centre=2 timeout -k 10 300 python3 tools/distribution_check.py 2>&1 | grep -v amdgpu.ids > $O/distribution_check_one_frame.txt ) || exit 1
+( KNN_DC_OPTS=cells_centre=1 timeout -k 10 300 python3 tools/distribution_check.py 2>&1 | grep -v amdgpu.ids > $O/distribution_check_cell_frames.txt ) || exit 1
 for c in clusters64 heavy_tail; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$c -- python3 $R/tools/distribution_check.py $c > /dev/null 2>&1 || exit 1
 done

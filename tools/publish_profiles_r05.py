@@ -24,7 +24,7 @@ def one(pattern):
 
 for path in sorted(glob.glob(os.path.join(src, "*_bench.json"))):
     shutil.copy(path, os.path.join(dst, f"{tag}_{os.path.basename(path)}"))
-for name in ("build_trace", "cells_trace", "dropin_timing", "ingest_timing", "distribution_check", "deepk_sq_counters", "scan_timeline",
+for name in ("build_trace", "cells_trace", "dropin_timing", "ingest_timing", "distribution_check", "distribution_check_one_frame", "distribution_check_cell_frames", "deepk_sq_counters", "scan_timeline",
              "pipeline_gaps_rank_0_of_8", "fuzz"):
     p = os.path.join(src, name + ".txt")
     if os.path.exists(p):
@@ -32,7 +32,7 @@ for name in ("build_trace", "cells_trace", "dropin_timing", "ingest_timing", "di
 for d, out in (("kt_c3", "c3_kernel_stats"), ("kt_c2", "c2_kernel_stats"), ("kt_c5", "c5_kernel_stats"),
                ("kt_c3_serial", "c3_serial_kernel_stats"), ("kt_2097152_serial", "16_1024_2097152_serial_kernel_stats"),
                ("kt_c3_rank_0_of_8", "c3_rank_0_of_8_kernel_stats"), ("kt_c3_rank_0_of_8_serial", "c3_rank_0_of_8_serial_kernel_stats"),
-               ("kt_clusters64", "clusters64_kernel_stats"), ("kt_heavy_tail", "heavy_tail_kernel_stats"), ("kt_build", "build_kernel_stats")):
+               ("kt_20_1024_16777216_serial", "20_1024_16777216_serial_kernel_stats"), ("kt_clusters64", "clusters64_kernel_stats"), ("kt_heavy_tail", "heavy_tail_kernel_stats"), ("kt_build", "build_kernel_stats")):
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, f"{tag}_{out}.csv"))
