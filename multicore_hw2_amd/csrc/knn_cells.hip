@@ -2342,43 +2342,69 @@ __global__ __launch_bounds__(256) void knn_cells_tile_cell_kernel(const unsigned
 }
 
 // box[c][0..15] = min, box[c][16..31] = max of the cell's rows (ordered-uint images; rows outside the robust box — +INF norm —
-// and padding positions do not count).  One wave per tile: lane = (row, half of the dimensions).
+// and padding positions do not count).  One wave per run of CELL_BOX_RUN consecutive tiles, lane = (row, half of the
+// dimensions): the lanes keep their own minima while the run stays in one cell (tiles are in cell order) and fold them — 5
+// shuffle steps, 16 guarded atomics per half — when the cell changes or the run ends.  (One wave per tile, folding every tile:
+// 4.0 ms for the 131 072 tiles of 64 clusters — 32 atomics per tile on 64 cells' words; this form 0.2 ms.)
+#define CELL_BOX_RUN 32u
 __global__ __launch_bounds__(256) void knn_cells_box_kernel(const float *__restrict__ R, int k, const unsigned *__restrict__ perm,
                                                             const float *__restrict__ norms, unsigned ntiles,
                                                             const unsigned *__restrict__ tile_cell, unsigned *__restrict__ box)
 {
-    const unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned t0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * CELL_BOX_RUN;
     const int lane = threadIdx.x & 63, half = lane >> 5;
-    if (t >= ntiles)
+    if (t0 >= ntiles)
         return;
-    const size_t pos = (size_t)t * 32 + (lane & 31);
-    const unsigned row = perm[pos];
-    const bool real = row != 0xFFFFFFFFu && norms[pos] < INFINITY;
+    const unsigned t1 = min(t0 + CELL_BOX_RUN, ntiles);
     float lo[8], hi[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int d = 8 * half + j;
-        const float x = real && d < k ? R[(size_t)row * k + d] : 0.0f;
-        lo[j] = real && d < k ? x : INFINITY;
-        hi[j] = real && d < k ? x : -INFINITY;
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
+    auto reset = [&]() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, KNN_WAVE));
-            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, KNN_WAVE));
+            lo[j] = INFINITY;
+            hi[j] = -INFINITY;
         }
-    if ((lane & 31) == 0) {
-        unsigned *__restrict__ b = box + (size_t)tile_cell[t] * 32;
+    };
+    auto fold = [&](unsigned cell) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (lo[j] < INFINITY)
-                guarded_atomic_min(&b[8 * half + j], f2ord(lo[j]));
-            if (hi[j] > -INFINITY)
-                guarded_atomic_max(&b[16 + 8 * half + j], f2ord(hi[j]));
+        for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, KNN_WAVE));
+                hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, KNN_WAVE));
+            }
+        if ((lane & 31) == 0) {
+            unsigned *__restrict__ b = box + (size_t)cell * 32;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (lo[j] < INFINITY)
+                    guarded_atomic_min(&b[8 * half + j], f2ord(lo[j]));
+                if (hi[j] > -INFINITY)
+                    guarded_atomic_max(&b[16 + 8 * half + j], f2ord(hi[j]));
+            }
+        }
+    };
+    reset();
+    unsigned cur = tile_cell[t0];
+    for (unsigned t = t0; t < t1; ++t) {
+        const unsigned cell = tile_cell[t];   // wave-uniform
+        if (cell != cur) {
+            fold(cur);
+            reset();
+            cur = cell;
+        }
+        const size_t pos = (size_t)t * 32 + (lane & 31);
+        const unsigned row = perm[pos];
+        if (row != 0xFFFFFFFFu && norms[pos] < INFINITY) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (8 * half + j < k) {
+                    const float x = R[(size_t)row * k + 8 * half + j];
+                    lo[j] = fminf(lo[j], x);
+                    hi[j] = fmaxf(hi[j], x);
+                }
         }
     }
+    fold(cur);
 }
 
 // frame[c] = { centre[16], scale, 2^e, 0 (bmax), 0 (nmax) }: the centre is the middle of the cell's box, e the largest
@@ -2495,7 +2521,8 @@ hipError_t knn_cells_recentre(FilterState &st, const float *r, hipStream_t s)
         e = hipMemset2DAsync(box + 16, 32 * sizeof(unsigned), 0, 16 * sizeof(unsigned), c.ncells, s);
     if (e == hipSuccess && ntiles != 0u) {
         hipLaunchKernelGGL(knn_cells_tile_cell_kernel, dim3((c.ncells * 32u + 255u) / 256u), dim3(256), 0, s, c.tile_start, c.ncells, c.tile_cell);
-        hipLaunchKernelGGL(knn_cells_box_kernel, dim3((ntiles + 3u) / 4u), dim3(256), 0, s, r, st.k, c.perm, st.ref_norms, ntiles, c.tile_cell, box);
+        hipLaunchKernelGGL(knn_cells_box_kernel, dim3(((ntiles + CELL_BOX_RUN - 1u) / CELL_BOX_RUN + 3u) / 4u), dim3(256), 0, s, r, st.k, c.perm, st.ref_norms,
+                           ntiles, c.tile_cell, box);
         hipLaunchKernelGGL(knn_cells_frame_kernel, dim3((c.ncells + 255u) / 256u), dim3(256), 0, s, box, c.ncells, st.k, st.sigma, c.cell_frame);
         hipLaunchKernelGGL(knn_cells_recentre_kernel, dim3((ntiles + 3u) / 4u), dim3(256), 0, s, r, st.k, c.perm, ntiles, c.tile_cell,
                            c.cell_frame, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2);

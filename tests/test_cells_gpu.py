@@ -690,21 +690,26 @@ def test_library_policy_gives_tight_clusters_their_own_frames_and_the_filter_sep
 
 def test_per_cell_frames_with_dense_cells_and_queries_that_do_not_fit_a_cells_frame(oracle):
     """Tight clusters (frames scaled by the full 2^8) and a batch that crowds one cell's list beyond its room — 700 near-copies of
-    one row — beside queries elsewhere in the box, far outside it, and not finite: the crowded cell is scored against the whole
-    batch, and the queries that do not fit its frame (|coordinate| > 1024 cell units) are ruled out by their distance along that
-    coordinate or pass everything; the non-finite query sends the batch to the exact scan.  Every answer against the oracle."""
+    one row — beside queries 20 box widths away (5 000-10 000 units in a cell's frame: they fit, coarsely), 100 box widths away
+    (beyond 16384 cell units: ruled out along that coordinate, passed wholesale, bounded through the triangle inequality in the
+    prep kernel) and, in a second batch, not finite.  The crowded cell is scored against the whole batch.  A far query cannot
+    tell the rows of its nearest tight cluster apart in fp16 — a few of them and the batch ends in the exact evaluation of its
+    listed pairs (stats[2] == 2), never in the exact scan of the shard; the non-finite query does send its batch there.  Every
+    answer against the oracle."""
     k, m, n = 16, 1024, 1 << 22      # (2^14 cells: a list holds 512 queries)
     rng = np.random.default_rng(5)
     Q, R = _clusters(rng, k, m, n, 16, 2e-4)
     Q[:700] = R[12345] + rng.normal(0, 1e-5, (700, k)).astype(np.float32)
-    Q[700:716] = rng.random((16, k), dtype=np.float32) * 40.0 - 20.0      # far outside the box
+    Q[700:708] = rng.random((8, k), dtype=np.float32) * 40.0 - 20.0
+    Q[708:716] = rng.random((8, k), dtype=np.float32) * 200.0 - 100.0
     want = oracle.v0(k, Q, R, threads=THREADS)
     pkg.set_option("cells_centre", 1)
     try:
         ix = pkg.KnnIndex(k, R)
         got, st = _query(ix, Q)
-        assert st[0] == 4 and st[2] == 0, st      # (the far queries are bounded through the triangle inequality: no exact scan)
         dense = ix.debug_counters()[1]
+        got_near, st_near = _query(ix, Q[:700])
+        dense_near = ix.debug_counters()[1]
         Qn = Q.copy()
         Qn[5, 3] = np.float32("nan")
         got_n, st_n = _query(ix, Qn)
@@ -712,6 +717,9 @@ def test_per_cell_frames_with_dense_cells_and_queries_that_do_not_fit_a_cells_fr
     finally:
         pkg.set_option("cells_centre", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
-    assert dense > 0, "the crowded cell did not overflow its list: the test does not reach the dense path"
+    assert st[0] == 4 and st[2] in (0, 2), st
+    np.testing.assert_array_equal(got_near, want[:700], err_msg=f"stats={st_near}")
+    assert st_near[0] == 4 and st_near[2] == 0, st_near      # the crowded batch alone stays on the filter
+    assert dense_near > 0, "the crowded cell did not overflow its list: the test does not reach the dense path"
     keep = np.arange(m) != 5
     np.testing.assert_array_equal(got_n[keep], want[keep])
