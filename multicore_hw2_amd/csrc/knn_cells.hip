@@ -1029,8 +1029,9 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 (&a)[KT], const f4v *__re
 // bmax_c, nmax_c), evaluated in fp32 with everything rounded towards "pass":
 //     thr = Dup + 2 eta sqrt(Dup) + eta^2 + rho - mq (1 - gamma)          (Dup in the cell's units: Dup_q x ratio^2)
 // P = the positive terms: eight fp32 operations on positive numbers, constants rounded up — within 2^-20 of exact, taken
-// 10^-5 larger; mq x 0.999998 <= mq (1 - gamma)(1 - 2^-22) (gamma = 18 x 2^-24 = 1.07 x 10^-6); the last subtraction rounds by
-// at most 2^-24 (P + mq), 2.4 x 10^-7 (P + mq) is added.  A pair whose query does not fit the cell's frame: see the end.
+// 10^-5 larger; mq x 0.999996 <= mq (1 - gamma)(1 - 10^-6)(1 - 2^-22) (gamma = 18 x 2^-24 = 1.07 x 10^-6; the 10^-6 is the slack
+// knn_threshold gives its own double arithmetic: the fp32 value is never below the double one — tests/test_cells_logic.py checks
+// 200 000 random pairs); the last subtraction rounds by at most 2^-24 (P + mq), 2.4 x 10^-7 (P + mq) is added.  A pair whose query does not fit the cell's frame: see the end.
 __device__ __forceinline__ void cell_centred_operand(const float *__restrict__ s_q32, int k, unsigned qid, int half, bool valid,
                                                      const float (&cc)[8], float scale, float ratio, float bmaxc, float nmaxc,
                                                      float dupq, float sqdq, h8 &b, float &th)
@@ -1063,7 +1064,7 @@ __device__ __forceinline__ void cell_centred_operand(const float *__restrict__ s
     const float rho = 1.1921e-5f * (nmaxc + 16.0f * a * a) + 1.79e-7f + 4.77e-7f * nmaxc;
     const float dupc = dupq * ratio * ratio, sqdc = sqdq * ratio;
     const float P = dupc + 2.0f * eta * sqdc + eta2 + rho;
-    const float T = (P * 1.00001f + (P + mq) * 2.4e-7f + 1e-30f) - mq * 0.999998f;
+    const float T = (P * 1.00001f + (P + mq) * 2.4e-7f + 1e-30f) - mq * 0.999996f;
     // A query that does not fit the cell's frame (a coordinate beyond CELL_FRAME_AMAX cell units, or not finite): along that coordinate it
     // is at least a32 (1 - 2^-22) - bmax_c - (rounding of the rows: 2^-11 bmax_c) away from every row of the cell, in exact
     // arithmetic.  Further than sqrt(Dup): no row of this cell can be its answer (a `dense` cell is scored against the whole

@@ -376,14 +376,18 @@ def test_cells_policy_and_option(oracle):
     np.testing.assert_array_equal(pkg.cudaCallback(k, 64, n, Q16, R), oracle.v0(k, Q16, R, threads=THREADS))
 
 
-def test_two_batches_in_flight_on_their_own_slots_and_streams(oracle):
+@pytest.mark.parametrize("centre", [0, 1])
+def test_two_batches_in_flight_on_their_own_slots_and_streams(oracle, centre):
+    """(centre = 1: per-cell frames — with batches in flight the two-wave prep kernel bounds two seed cells per wave)"""
     k, n, m = 16, 1 << 18, 512
     dev = torch.device("cuda:0")
     R = oracle.synth(n * k, 51).reshape(n, k)
     r_d = torch.from_numpy(R).to(dev)
     pkg.set_option("cells", 1)
+    pkg.set_option("cells_centre", centre)
     ix = pkg.KnnIndex(k, r_d.data_ptr(), n_local=n, refs_on_device=True)
     pkg.set_option("cells", 0)
+    pkg.set_option("cells_centre", 0)
     try:
         streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
         Qs = [oracle.synth(m * k, 60 + i).reshape(m, k) for i in range(3)]

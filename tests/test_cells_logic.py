@@ -194,3 +194,66 @@ def test_chunked_scan_block_order_covers_every_pair_once(ranges, qgroups):
         mine = by[(xcd == c) & live]
         for start in range(0, max(1, len(mine) - 64), 64):
             assert len(set(mine[start:start + 64].tolist())) <= (64 + ranges - 1) // ranges + 1
+
+
+def test_centred_pair_threshold_in_fp32_is_never_below_the_double_formula():
+    """Per-cell frames (round 5): the scan makes the threshold of a (query, cell) pair in fp32 (cell_centred_operand,
+    knn_cells.hip) where the prep kernel and every other path use knn_threshold's double arithmetic (knn_filter_dev.h).  The fp32
+    value only has to be an UPPER bound of the double one — a looser threshold passes more candidates, a tighter one could lose
+    the answer.  Both formulas restated here (numpy float32 operation by operation / Python floats), 200 000 random pairs over
+    the whole range of their inputs, and the constants of the fp32 form against the ones knn_bound_consts derives."""
+    rng = np.random.default_rng(11)
+    u, f32 = 2.0 ** -24, np.float32
+    theta = 2.0 ** -11 + 2.0 ** -23
+    thp, nu0 = theta / (1.0 - theta), 2.0 ** -14 * 1.001
+    assert float(f32(4.8865e-4)) >= thp and float(f32(1.2220e-4)) >= 2.0 * nu0
+    omega, gam = 2.0 ** -18, 18.0 * u                       # kt = 1: kp = 16
+    assert float(f32(1.1921e-5)) >= (omega + 2.0 * gam) * 2.0
+    assert float(f32(1.79e-7)) >= 16.0 * 2.0 ** -27 + 2.0 ** -24 and float(f32(4.77e-7)) >= 2.0 ** -21
+    assert float(f32(0.999996)) <= (1.0 - gam) * (1.0 - 1e-6) * (1.0 - 2.0 ** -22)
+    n = 200000
+    k = rng.integers(1, 17, n)
+    a = np.where(rng.random(n) < 0.1, 0.0, 10.0 ** rng.uniform(-6, np.log10(16384.0), n))      # the pair's amax (fp16 values)
+    b = 10.0 ** rng.uniform(-5, 0.3, n)                                                         # the cell's bmax
+    nmax = (k * b * b) * rng.uniform(0.05, 1.0, n)
+    mq = (k * a * a) * rng.uniform(1.0 / 16, 1.0, n)
+    dup = np.where(rng.random(n) < 0.05, 0.0, 10.0 ** rng.uniform(-12, 9, n))
+    ratio = 2.0 ** rng.integers(0, 9, n)
+    # --- double: knn_bound_consts + the last lines of knn_threshold, in the cell's units
+    dupc = dup * ratio * ratio
+    emax = thp * (a + b) + 2.0 * nu0
+    eta2 = k * emax * emax
+    eta = np.sqrt(eta2)
+    rho = (omega + 2.0 * gam) * 2.0 * (nmax + 16.0 * a * a) + 16.0 * 2.0 ** -27 + 2.0 ** -21 * nmax + 2.0 ** -24
+    thr = dupc + 2.0 * eta * np.sqrt(dupc) + eta2 + rho - mq * (1.0 - gam)
+    thr = thr + np.abs(thr) * 1e-6 + 1e-30
+    thr_f = thr.astype(f32)
+    thr_f = np.where(thr_f.astype(np.float64) < thr, np.nextafter(thr_f, f32(np.inf)), thr_f)
+    thr_f = np.nextafter(thr_f, f32(np.inf))
+    # --- fp32: cell_centred_operand, operation by operation (inputs as the kernel gets them: Dup rounded up, sqrt rounded up twice)
+    dupq = dup.astype(f32)
+    dupq = np.where(dupq.astype(np.float64) < dup, np.nextafter(dupq, f32(np.inf)), dupq)
+    sqd = np.nextafter(np.nextafter(np.sqrt(dupq), f32(np.inf)), f32(np.inf))
+    A, B, NM, MQ, R_, KF = a.astype(f32), b.astype(f32), nmax.astype(f32), mq.astype(f32), ratio.astype(f32), k.astype(f32)
+    B = np.where(B.astype(np.float64) < b, np.nextafter(B, f32(np.inf)), B)     # (bmax / nmax are exact fp32 maxima in the kernel; here rounded up)
+    NM = np.where(NM.astype(np.float64) < nmax, np.nextafter(NM, f32(np.inf)), NM)
+    A = np.where(A.astype(np.float64) < a, np.nextafter(A, f32(np.inf)), A)
+    MQ = np.where(MQ.astype(np.float64) > mq, np.nextafter(MQ, f32(-np.inf)), MQ)
+    emax32 = f32(4.8865e-4) * (A + B) + f32(1.2220e-4)
+    sqk = np.where(k <= 1, 1.0, np.where(k <= 4, 2.0, np.where(k <= 9, 3.0, 4.0))).astype(f32)
+    eta32, eta232 = sqk * emax32, KF * emax32 * emax32
+    rho32 = f32(1.1921e-5) * (NM + f32(16.0) * A * A) + f32(1.79e-7) + f32(4.77e-7) * NM
+    dupc32, sqdc32 = dupq * R_ * R_, sqd * R_
+    P = dupc32 + f32(2.0) * eta32 * sqdc32 + eta232 + rho32
+    T = (P * f32(1.00001) + (P + MQ) * f32(2.4e-7) + f32(1e-30)) - MQ * f32(0.999996)
+    assert T.dtype == np.float32 and P.dtype == np.float32
+    ok = np.isfinite(thr_f) & np.isfinite(T)
+    assert ok.mean() > 0.99
+    bad = ok & (T < thr_f)
+    assert not bad.any(), (int(bad.sum()), [(float(x[bad][0])) for x in (dup, a, b, nmax, mq, ratio, thr, T)])
+    # and not vacuous: within 10^-3 of the double value wherever the threshold is not a small difference of large terms (k a
+    # square: the kernel takes ceil(sqrt(k)) for sqrt(k), up to 1.41x on the 2 eta sqrt(Dup) term at k = 2)
+    big = ok & (thr > 0.1 * (dupc + mq)) & np.isin(k, (1, 4, 9, 16))
+    assert float(np.max((T[big] - thr[big]) / thr[big])) < 2e-2     # (the additive constants of rho are rounded up to three digits)
+    rest = ok & (thr > 0.1 * (dupc + mq))
+    assert float(np.max((T[rest] - thr[rest]) / thr[rest])) < 1.0
