@@ -1040,23 +1040,19 @@ __device__ __forceinline__ void cell_centred_operand(const float *__restrict__ s
     // the query's fp32 row, padded to 16 dimensions with zeros, from LDS (the centre is zero there too: no masks)
     const f4v x0 = *(const f4v *)(s_q32 + (size_t)qid * 16 + 8 * half), x1 = *(const f4v *)(s_q32 + (size_t)qid * 16 + 8 * half + 4);
     const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-    float a = 0.0f, a32 = 0.0f, mq = 0.0f;
-    bool bad = false;
+    float sc[8], a = 0.0f, mq = 0.0f;
+    h8 hv;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float sc = (x[j] - cc[j]) * scale;
-        const _Float16 hval = (_Float16)sc;
-        const float back = (float)hval;
-        bad = bad || !(fabsf(back) < INFINITY);
-        a = fmaxf(a, fabsf(back));
-        a32 = fmaxf(a32, fabsf(sc));
+        sc[j] = (x[j] - cc[j]) * scale;
+        hv[j] = (_Float16)sc[j];
+        const float back = (float)hv[j];
+        a = fmaxf(a, fabsf(back));   // (+INF where a coordinate left the fp16 range; a NaN — a query that is not finite: the prep kernel has sent its batch to the exact scan — is skipped)
         mq = mq + back * back;
-        b[j] = (_Float16)(back * -2.0f);
     }
     a = fmaxf(a, __shfl_xor(a, 32, KNN_WAVE));
-    a32 = fmaxf(a32, __shfl_xor(a32, 32, KNN_WAVE));
     mq = mq + __shfl_xor(mq, 32, KNN_WAVE);
-    bad = bad || __shfl_xor((int)bad, 32, KNN_WAVE) != 0;
+    b = hv * (_Float16)-2.0f;   // exact: |coordinate| <= CELL_FRAME_AMAX = 2^14 below
     const float kf = (float)k;
     const float emax = 4.8865e-4f * (a + bmaxc) + 1.2220e-4f;          // theta' (amax + bmax) + 2 nu0
     const float sqk = k <= 1 ? 1.0f : k <= 4 ? 2.0f : k <= 9 ? 3.0f : 4.0f;   // >= sqrt(k), k <= 16 (no square root here: the exact kernels' ISA is checked for FMAs)
@@ -1064,14 +1060,25 @@ __device__ __forceinline__ void cell_centred_operand(const float *__restrict__ s
     const float rho = 1.1921e-5f * (nmaxc + 16.0f * a * a) + 1.79e-7f + 4.77e-7f * nmaxc;
     const float dupc = dupq * ratio * ratio, sqdc = sqdq * ratio;
     const float P = dupc + 2.0f * eta * sqdc + eta2 + rho;
-    const float T = (P * 1.00001f + (P + mq) * 2.4e-7f + 1e-30f) - mq * 0.999996f;
-    // A query that does not fit the cell's frame (a coordinate beyond CELL_FRAME_AMAX cell units, or not finite): along that coordinate it
-    // is at least a32 (1 - 2^-22) - bmax_c - (rounding of the rows: 2^-11 bmax_c) away from every row of the cell, in exact
-    // arithmetic.  Further than sqrt(Dup): no row of this cell can be its answer (a `dense` cell is scored against the whole
-    // batch, queries that never listed it included).  Else everything passes — its rows are re-ranked exactly, as any candidate is.
-    const float lb = a32 * 0.999f - bmaxc * 1.001f - 0.001f;
-    const bool beyond = lb > 0.0f && lb * lb > dupc * 1.001f;   // (a32 = +INF: beyond any finite Dup; NaN: not beyond)
-    th = !valid ? -INFINITY : (bad || !(a <= CELL_FRAME_AMAX)) ? (dupq > -INFINITY && !beyond ? INFINITY : -INFINITY) : T;
+    th = (P * 1.00001f + (P + mq) * 2.4e-7f + 1e-30f) - mq * 0.999996f;
+    if (!(a <= CELL_FRAME_AMAX)) {   // (both lanes of a query take this together: `a` is the pair's)
+        // The query does not fit the cell's frame (a coordinate beyond CELL_FRAME_AMAX cell units): along that coordinate it is
+        // at least a32 (1 - 2^-22) - bmax_c (1 + 2^-10) - nu0 away from every row of the cell, in exact arithmetic.  Further than
+        // sqrt(Dup): no row of this cell can be its answer (a `dense` cell is scored against the whole batch, queries that never
+        // listed it included).  Else every real row passes — a ZERO operand leaves the rows' norms as scores (finite; an operand
+        // of fp16 infinities would make them NaN, which no threshold passes) — and is re-ranked exactly, as any candidate is.
+        float a32 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            a32 = fmaxf(a32, fabsf(sc[j]));
+        a32 = fmaxf(a32, __shfl_xor(a32, 32, KNN_WAVE));
+        const float lb = a32 * 0.999f - bmaxc * 1.001f - 0.001f;
+        const bool beyond = lb > 0.0f && lb * lb > dupc * 1.001f;   // (a32 = +INF: beyond any finite Dup)
+        b = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        th = dupq > -INFINITY && !beyond ? INFINITY : -INFINITY;
+    }
+    if (!valid)
+        th = -INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1837,7 +1844,8 @@ __global__ __launch_bounds__(64 * (KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN
             // (round 3: blocks three and four of the list too — lists average 120 entries on the 2^21-row shards of an
             // 8-GPU run, and every block beyond the second was a dependent read from memory)
             const unsigned l1 = SELF ? 0u : dense ? 64u + (unsigned)lane : (unsigned)list[min(64u + (unsigned)lane, nq - 1u)];
-            float ccv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c_scale = 0.f, c_ratio = 0.f, c_bmax = 0.f, c_nmax = 0.f;
+            float ccv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c_scale = 0.f, c_ratio = 0.f, c_bmax = 0.f, c_nmax = 0.f, th_kept = 0.f;
+            h8 b_kept = {0, 0, 0, 0, 0, 0, 0, 0};
             if constexpr (CTR) {   // the cell's frame: this lane's half of the centre, the scale, the cell's bounds
                 const float *__restrict__ fr = self.frame + (size_t)cellj * KNN_CELL_FRAME_WORDS;
 #pragma unroll
@@ -1890,8 +1898,13 @@ __global__ __launch_bounds__(64 * (KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN
                     h8 b[KT];
                     float th;
                     if constexpr (CTR) {
-                        cell_centred_operand((const float *)s_dyn, K > 0 ? K : krt, qid, half, valid, ccv, c_scale, c_ratio, c_bmax, c_nmax, s_dup[qid],
-                                             s_thr[qid], b[0], th);
+                        // (an item of several passes whose list is one block of queries — 16 queries per cluster cell on 64 tight
+                        // clusters — keeps the block's operand from its first pass)
+                        if (t0 == tb || nq > 32u)
+                            cell_centred_operand((const float *)s_dyn, K > 0 ? K : krt, qid, half, valid, ccv, c_scale, c_ratio, c_bmax, c_nmax,
+                                                 s_dup[qid], s_thr[qid], b_kept, th_kept);
+                        b[0] = b_kept;
+                        th = th_kept;
                     } else {
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk)

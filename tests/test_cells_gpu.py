@@ -727,3 +727,26 @@ def test_per_cell_frames_with_dense_cells_and_queries_that_do_not_fit_a_cells_fr
     assert dense_near > 0, "the crowded cell did not overflow its list: the test does not reach the dense path"
     keep = np.arange(m) != 5
     np.testing.assert_array_equal(got_n[keep], want[keep])
+
+
+def test_per_cell_frames_pass_every_row_of_a_cell_whose_frame_a_far_query_does_not_fit(oracle):
+    """One query 100 box widths away among 64 ordinary ones, tight clusters, per-cell frames: in the frame of its nearest
+    cluster's cell the query's coordinates are beyond fp16 (x -2: infinities, and scores made of them would be NaN, which no
+    threshold passes), so the scan scores that pair with a ZERO operand — the rows' norms — against +INF: every real row of the
+    cell becomes a candidate (32 768 here: the batch stays on the filter, stats[2] == 0) and the exact re-rank picks v0's."""
+    k, m, n = 16, 65, 1 << 19
+    rng = np.random.default_rng(77)
+    Q, R = _clusters(rng, k, m, n, 16, 2e-4)
+    Q[64] = np.float32(100.0) * rng.choice([-1.0, 1.0], k).astype(np.float32)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("cells", 1)
+    pkg.set_option("cells_centre", 1)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got, st = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("cells", 0)
+        pkg.set_option("cells_centre", 0)
+    np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
+    assert st[0] == 4 and st[2] == 0 and st[1] >= n // 16 // 2, st
