@@ -1093,6 +1093,7 @@ __device__ __forceinline__ void cell_centred_operand(const float *__restrict__ s
 #define CELL_PREP_WAVES 4
 #define CELL_PREP_TILES 9     // seed tiles a wave requests at once (a cell of 144 .. 288 rows: one round trip)
 #define CELL_SEED_MAX_TILES 36u   // tiles of one seed cell a query looks at (a larger cell: every stride-th tile)
+#define CELL_SEED_MAX_TILES_CTR 144u   // the same with per-cell frames (clustered data: cells of thousands of tiles)
 #define CELL_OUTER_SEED_TILES 2   // cell-range shards: tiles an outer seed cell of this rank contributes (the layer's depth by default)
 
 // Where the seed tiles of cells OUTSIDE this index's range come from (cell-range shards; all zero otherwise): every rank's
@@ -1468,7 +1469,12 @@ __global__ __launch_bounds__(64 * PW, KT == 1 && !CTR ? 4 : 3) void knn_cells_pr
                                               (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v_fa, sl);
                 const unsigned long long n0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v_na >> 32), sl) << 32) |
                                               (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v_na, sl);
-                const unsigned st0 = (nt + CELL_SEED_MAX_TILES - 1u) / CELL_SEED_MAX_TILES;
+                // (a fat cell — a whole cluster — leaves about (its rows / the rows sampled here) candidates per query: 1/56 of its
+                // tiles, between 36 and 144, keeps a batch of 1024 near 16 records per scan wave.  n 2^24, 64 clusters: 36 tiles
+                // 0.318 ms per step, 248 k records; 144 tiles 0.208, 60 k.  n 2^22: 36 tiles 0.105; 144 tiles 0.121 — the prep
+                // kernel's extra 16 us buy nothing there)
+                const unsigned scap = min(CELL_SEED_MAX_TILES_CTR, max(CELL_SEED_MAX_TILES, (nt * 9u) >> 9));
+                const unsigned st0 = (nt + scap - 1u) / scap;
                 best = fminf(best, cell_bound(fv_seed[c], f0, n0, (nt + st0 - 1u) / st0, st0));
             }
         }

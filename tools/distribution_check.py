@@ -15,7 +15,7 @@ from tests.oracle_lib import Oracle      # noqa: E402
 
 o = Oracle(os.path.join(ROOT, "oracle", "libknn_oracle.so"))
 dev = torch.device("cuda:0")
-k, m, n = 16, 1024, 1 << 22
+k, m, n = 16, 1024, int(os.environ.get("KNN_DC_N", 1 << 22))
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 
