@@ -853,17 +853,18 @@ template <int CELL_MATCH_WAVES>   // 8, or 16 for shards of few cells (one block
 __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     const float *__restrict__ lo_tab, const float *__restrict__ hi_tab, const float *__restrict__ dup, int m,
     int m_padded, CellGeom g, unsigned ncells, unsigned cap, unsigned short *__restrict__ lists,
-    unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl)
+    unsigned *__restrict__ cell_counts, unsigned *__restrict__ ctl,
+    unsigned stage)   // entries of a list assembled in LDS (<= cap; 0: none): the launch's dynamic LDS holds 64 x (stage + 2) of them
 {
     __shared__ unsigned short s_q[1024];
     __shared__ float s_hv[1024], s_dq[1024];
     __shared__ unsigned s_npass, s_flag, s_wcnt[CELL_MATCH_WAVES][64];
-    // lists of up to 640 entries are put together in LDS (dynamic: 64 rows of cap + 2 entries — a row stride of an odd number
-    // of dwords, 65 at cap 128: lanes appending at the same depth hit different banks) and written out as whole rows;
-    // longer ones (few, large cells) go straight to memory.  (16 < k <= 32, lists of 384 / 640: written straight to memory —
+    // the first `stage` entries of every list are put together in LDS (dynamic: 64 rows of stage + 2 entries — a row stride of an
+    // odd number of dwords, 65 at 128: lanes appending at the same depth hit different banks) and written out as whole rows;
+    // what lies beyond goes straight to memory (k <= 16: stage = 128, lists are 25-125 entries long on uniform data).  (16 < k <= 32, lists of 384 / 640: written straight to memory —
     // ten million two-byte stores 768 bytes apart at k = 20 — the launch took 75 us at C3's shape; staged in LDS 0.326 -> 0.304 ms per step at k = 20, 0.810 -> 0.709 at k = 24)
     extern __shared__ __attribute__((aligned(16))) unsigned short s_list[];
-    const unsigned lstride = cap + 2u;
+    const unsigned lstride = stage + 2u;
     // (the flag is read ONCE per block: other blocks of this launch may raise it, and threads of one block must not
     // disagree about leaving before the barriers below)
     if (threadIdx.x == 0)
@@ -912,8 +913,7 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     }
     __syncthreads();
     const unsigned npass = s_npass;
-    const bool staged = cap <= CELL_MATCH_STAGED_CAP;
-    unsigned short *__restrict__ my = staged ? s_list + (size_t)lane * lstride : lists + (size_t)cell * cap;
+    unsigned short *__restrict__ my_lds = s_list + (size_t)lane * lstride, *__restrict__ my_mem = lists + (size_t)cell * cap;
     // pass 2: the queue in contiguous runs, one per wave (<= 1024 / WAVES entries); a lane keeps "my cell could not
     // rule entry j out" as bit j of a mask, the waves' counts are prefix-summed through LDS, and the second sweep
     // writes every survivor to its final place — no LDS atomics (16 waves adding to the same 64 counters cost
@@ -965,20 +965,22 @@ __global__ __launch_bounds__(64 * CELL_MATCH_WAVES) void knn_cells_match_kernel(
     for (int w64 = 0; w64 < EPW / 64; ++w64)
         for (u64 bits = keep[w64]; bits != 0ull; bits &= bits - 1ull) {
             const unsigned e = e_begin + (unsigned)w64 * 64u + (unsigned)__builtin_ctzll(bits);
-            if (pos < cap)
-                my[pos] = s_q[e];
+            if (pos < stage)
+                my_lds[pos] = s_q[e];
+            else if (pos < cap)
+                my_mem[pos] = s_q[e];   // (beyond the staged part: rare where the lists are short, the rule where nothing is staged)
             ++pos;
         }
     if (wib == 0) {
         cell_counts[cell] = total;   // (> cap: the list is cut short and the scan scores the cell against the whole batch)
     }
     __syncthreads();
-    if (staged) {
+    if (stage != 0u) {
         for (int j = wib; j < 64; j += CELL_MATCH_WAVES) {
             unsigned cj = 0u;
             for (int w = 0; w < CELL_MATCH_WAVES; ++w)
                 cj += s_wcnt[w][j];
-            cj = min(cj, cap);
+            cj = min(cj, stage);
             for (unsigned d = (unsigned)lane; d * 2u < cj; d += 64u)
                 ((unsigned *)(lists + (size_t)(c0 + (unsigned)j) * cap))[d] = ((const unsigned *)(s_list + (size_t)j * lstride))[d];
         }
@@ -2678,7 +2680,10 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
     }
     // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
     // in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
-    c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
+    // (round 5: 384 entries at >= 2^15 cells, was 128 — heavy-tailed rows with gaussian queries, n 2^24: lists of 121 .. 213
+    // queries, nearly every cell `dense` (scored against all 1024), 1.16 ms per step; 0.36 with room for the lists.  The match
+    // kernel assembles the first 128 entries of a list in LDS as before and writes the rest straight to memory)
+    c->cap = std::min(1024u, std::max(384u, (1u << 23) / c->ncells));
     if (k > 16)   // (more dimensions, fewer cells ruled out: lists of ~100-200 of 1024 queries at k = 20 — 128 entries made most cells dense)
         c->cap = std::min(1024u, std::max(k > 20 ? 640u : 384u, (1u << 24) / c->ncells));
     // (k = 24, n 2^24: lists of 384 left most cells dense, 1.19 ms per step; 640 or 1024 entries 0.75 — the full scan takes 0.97)
@@ -2759,7 +2764,7 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         c->bits = lbits;
         c->ncells = 1u << lbits;
         cell_grid_shape(kc, lbits, c->nb, c->shift, &c->sa);
-        c->cap = std::min(1024u, std::max(128u, (1u << 23) / c->ncells));
+        c->cap = std::min(1024u, std::max(384u, (1u << 23) / c->ncells));
     }
     unsigned *code = nullptr, *counts = nullptr;
     std::vector<unsigned> hcounts((size_t)c->ncells), hstart((size_t)c->ncells + 1);
@@ -3106,17 +3111,22 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
     if (self_lists) {
         // no match launch: the scan's waves list their own items
     } else {
-        const size_t mlds = c.cap <= CELL_MATCH_STAGED_CAP ? (size_t)64 * (c.cap + 2u) * sizeof(unsigned short) : 0;   // the lists of a block's 64 cells
+        // entries of a list assembled in LDS: k <= 16 the first 128 (16.6 KiB: four or five blocks per CU), 16 < k <= 32 the whole
+        // list up to 640 entries (lists of 150-400 are the rule there)
+        // (a rank of 8 of C3 — 2^13 cells, room for 1024 entries, lists of ~25 — on one box, ms per pipelined step: nothing staged (rounds
+        // 2-5) 0.0290 / 0.0301, 128 entries 0.0266 / 0.0269, 256 entries 0.0274 / 0.0280)
+        const unsigned stage = st.kt == 1 ? std::min(c.cap, 128u) : c.cap <= CELL_MATCH_STAGED_CAP ? c.cap : 0u;
+        const size_t mlds = stage ? (size_t)64 * (stage + 2u) * sizeof(unsigned short) : 0;
         if (c.ncells <= 16384u) {
             if (mlds > (size_t)(48u << 10))   // (12-20 KiB of static LDS in front of it; the attribute is per device, so per launch)
                 FTRY(hipFuncSetAttribute((const void *)knn_cells_match_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(knn_cells_match_kernel<16>, dim3(c.ncells / 64u), dim3(64 * 16), mlds, s, w.lo_tab, w.hi_tab, w.dup, m,
-                               m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
+                               m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur, stage);
         } else {
             if (mlds > (size_t)(48u << 10))
                 FTRY(hipFuncSetAttribute((const void *)knn_cells_match_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(knn_cells_match_kernel<8>, dim3(c.ncells / 64u), dim3(64 * 8), mlds, s, w.lo_tab, w.hi_tab, w.dup, m,
-                               m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur);
+                               m_padded, g, c.ncells, c.cap, w.cell_lists, w.cell_counts, w.ctl_cur, stage);
         }
     }
     FTRY(hipGetLastError());
