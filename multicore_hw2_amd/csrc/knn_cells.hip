@@ -2678,8 +2678,8 @@ hipError_t knn_cells_build(CellIndex **out, int k, long long n, const float *r, 
         }
         cell_quantile_cuts(k, c->nb, samp.data(), samples, bounds.data());
     }
-    // list capacity per cell and batch: 16 MiB of lists per slot — 128 queries per cell at 2^16 cells (uniform data
-    // in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
+    // list capacity per cell and batch: 384 queries per cell at >= 2^15 cells (48 MiB of lists per slot at 2^16 cells; uniform
+    // data in 16 dimensions keeps 25 of 1024 on average, 53 at most), every query of a batch at <= 2^13 cells
     // (round 5: 384 entries at >= 2^15 cells, was 128 — heavy-tailed rows with gaussian queries, n 2^24: lists of 121 .. 213
     // queries, nearly every cell `dense` (scored against all 1024), 1.16 ms per step; 0.36 with room for the lists.  The match
     // kernel assembles the first 128 entries of a list in LDS as before and writes the rest straight to memory)

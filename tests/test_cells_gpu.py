@@ -237,7 +237,7 @@ def test_both_ways_of_dealing_items_to_the_scan_waves_are_bit_exact(oracle, deal
 @pytest.mark.parametrize("centre", [0, 1])
 def test_a_thousand_copies_of_one_query_stay_on_the_pruned_path(oracle, centre):
     """1024 copies of one query want the same ~4 % of the cells, with all 1024 on each of their lists: far beyond a
-    list's on-chip room (256 entries at 2^16 cells).  Round 2 answered such a batch with the exact scan and sent the
+    list's room (384 entries at 2^16 cells).  Round 2 answered such a batch with the exact scan and sent the
     index to full scans for its next 256 calls; now the crowded cells are scored `dense` — against the whole batch,
     which is what their lists asked for — the batch stays on the pruned path with no fallback, and so does the next.
     (centre = 1: the same with per-cell frames — a dense cell there meets queries that never listed it.)"""
