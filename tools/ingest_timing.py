@@ -19,6 +19,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import multicore_hw2_amd as pkg
 from tests.oracle_lib import Oracle
 
+for _opt in os.environ.get("KNN_IT_OPTS", "").split(","):   # e.g. KNN_IT_OPTS=cells_centre=2
+    if _opt:
+        pkg.set_option(_opt.split("=")[0], int(_opt.split("=")[1]))
+
 o = Oracle(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "libknn_oracle.so"))
 k, m, n = 16, 1024, 1 << 24
 R, Q = o.synth(n * k, 1001), o.synth(m * k, 1000)
