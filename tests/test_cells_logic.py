@@ -257,3 +257,48 @@ def test_centred_pair_threshold_in_fp32_is_never_below_the_double_formula():
     assert float(np.max((T[big] - thr[big]) / thr[big])) < 2e-2     # (the additive constants of rho are rounded up to three digits)
     rest = ok & (thr > 0.1 * (dupc + mq))
     assert float(np.max((T[rest] - thr[rest]) / thr[rest])) < 1.0
+
+
+@pytest.mark.parametrize("width", [1.0, 1e-2, 1e-4, 3e-7])
+@pytest.mark.parametrize("k", [16, 11, 3])
+def test_rounding_in_a_cells_own_frame_stays_inside_eta(width, k):
+    """Per-cell frames (round 5), the operand-rounding half of the bound (the accumulation half, rho, is frame-independent and
+    measured on the GPU: test_parity_gpu.py).  Rows of a cell `width` wide somewhere in a unit box and queries in and around
+    it are rounded exactly as knn_cells_recentre_kernel / cell_centred_operand round them — fp32 subtract of the cell's centre,
+    power-of-two scale, fp16 to nearest even — and the distance between the ROUNDED points must stay within eta = sqrt(k)
+    (theta' (amax + bmax) + 2 nu0) of the true one, in the cell's units: |sqrt(D~) - sqrt(D)| <= eta for every pair, where the
+    derivation of knn_filter_dev.h starts.  Down to cells whose coordinates are fp16 subnormals after the 2^8 cap of the scale."""
+    rng = np.random.default_rng(int(k * 1000 + width * 1e7) % (2 ** 31))
+    f32, f16 = np.float32, np.float16
+    n, m = 4000, 300
+    sigma = f32(2.0)                                   # the shard's frame: a unit box scaled to [-1, 1]
+    where = rng.random(k).astype(f32)
+    R = (where + (rng.random((n, k)) - 0.5) * width).astype(f32)
+    Q = (where + (rng.random((m, k)) - 0.5) * width * rng.choice([0.5, 2.0, 30.0], (m, 1))).astype(f32)
+    lo, hi = R.min(axis=0), R.max(axis=0)
+    ctr = (f32(0.5) * lo + f32(0.5) * hi).astype(f32)  # knn_cells_frame_kernel
+    hw = float(np.max(np.maximum(hi - ctr, ctr - lo)))
+    ratio = 1.0
+    for _ in range(8):
+        if f32(hw) * sigma * f32(2.0 * ratio) <= f32(0.999):
+            ratio *= 2.0
+    scale = f32(sigma * f32(ratio))
+    a = ((R - ctr).astype(f32) * scale).astype(f32).astype(f16)          # the fragments
+    b = ((Q - ctr).astype(f32) * scale).astype(f32).astype(f16)          # the queries in the cell's frame
+    fits = np.isfinite(b.astype(np.float64)).all(axis=1) & (np.abs(b.astype(np.float64)).max(axis=1) <= 16384.0)
+    assert fits.mean() > 0.5
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)[fits]
+    Qf = Q.astype(np.float64)[fits]
+    d_true = np.sqrt(((Qf[:, None, :] - R.astype(np.float64)[None, :, :]) ** 2).sum(-1)) * float(scale)
+    d_round = np.sqrt(((b64[:, None, :] - a64[None, :, :]) ** 2).sum(-1))
+    theta = 2.0 ** -11 + 2.0 ** -23
+    thp, nu0 = theta / (1.0 - theta), 2.0 ** -14 * 1.001
+    amax = np.abs(b64).max(axis=1)
+    bmax = np.abs(a64).max()
+    eta = np.sqrt(k) * (thp * (amax + bmax) + 2.0 * nu0)
+    worst = float((np.abs(d_round - d_true) / eta[:, None]).max())
+    assert worst <= 1.0, (width, k, worst)
+    # and the frame earns its keep: in the shard's one frame the same bound would be 2^-11 of the BOX
+    eta_one_frame = np.sqrt(k) * (thp * 2.0 + 2.0 * nu0) * ratio       # in the cell's units
+    if width <= 1e-2:
+        assert float(np.median(eta)) < 0.2 * eta_one_frame
