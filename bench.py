@@ -741,8 +741,9 @@ def roofline_block(k, m, n_local, path_taken, kern_ms, launches, alone_ms, alone
                 "flops_per_launch": flops}
     elif path_taken == 4:
         # cell-pruned scan: ~4 % of the pairs are scored; the kernel reads the cell-sorted fp16 layout once —
-        # 32 B of fragment (k <= 16; 64 B for 16 < k <= 32) + 4 B of norm per position, cells padded to whole tiles (~4 %)
-        per_pos = 32.0 * ((k + 15) // 16) + 4.0
+        # 32 B of fragment (k <= 16; 64 B for 16 < k <= 32) + 4 B of norm per position, cells padded to whole tiles (~4 %);
+        # 16 < k <= 30: the norm rides in the fragment's free K-slots (KNN_NIF_MAX_K, knn_cells.hip) — no norm array is read
+        per_pos = 32.0 * ((k + 15) // 16) + (0.0 if 16 < k <= 30 else 4.0)
         phys = per_pos * n_local * 1.04
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
                 "kernel": "knn_cells_scan (f16 MFMA 32x32x16 over the cells each query could not rule out)",

@@ -253,6 +253,11 @@ __global__ __launch_bounds__(256) void knn_cells_scatter_frag2_kernel(
             vmax = 0.0f;
             nrm = 0.0f;
         }
+        if (k <= KNN_NIF_MAX_K) {   // the norm's two fp16 halves in the free K-slots 30, 31 (see cell_tile_step_nif); a row that is out: a score no threshold passes
+            const unsigned nw = real ? pack_norm22(nrm) : 0x00007BFFu;   // (65504, 0)
+            v[3][6] = __builtin_bit_cast(_Float16, (unsigned short)(nw & 0xFFFFu));
+            v[3][7] = __builtin_bit_cast(_Float16, (unsigned short)(nw >> 16));
+        }
         const unsigned c = code[i];
         const size_t pos = (size_t)tile_start[c] * 32 + atomicAdd(&fill[c], 1u);
         h8 *__restrict__ tile = frag + (pos >> 5) * 128;   // two K-steps of 64 lanes
@@ -814,15 +819,19 @@ __global__ __launch_bounds__(256) void knn_cells_place_kernel(
 // placed).  Rounds 2-3 memset the whole layout first: 0.76 GB of writes for 46 MB of padding at C3.
 __global__ __launch_bounds__(256) void knn_cells_pad_kernel(const unsigned *__restrict__ tile_start, const unsigned *__restrict__ fill,
                                                             unsigned ncells, h8 *__restrict__ frag, float *__restrict__ norms,
-                                                            unsigned *__restrict__ norms2, unsigned *__restrict__ perm, int kt)
+                                                            unsigned *__restrict__ norms2, unsigned *__restrict__ perm, int kt, int nif)
 {
     const unsigned c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, j = threadIdx.x & 31u;   // 32 threads per cell: at most 31 pads
     if (c >= ncells)
         return;
     const size_t pos = (size_t)tile_start[c] * 32 + fill[c] + j, end = (size_t)tile_start[c + 1u] * 32;
     if (pos < end) {
-        for (int t = 0; t < 2 * kt; ++t)   // (kt K-steps x two halves of 32 lanes)
-            frag[(pos >> 5) * 64 * kt + t * 32 + (pos & 31)] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < 2 * kt; ++t) {   // (kt K-steps x two halves of 32 lanes)
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (nif && t == 3)   // (kt = 2, k <= 30: K-slot 30 carries the norm — a padding row's: 65504, above every threshold)
+                z[6] = __builtin_bit_cast(_Float16, (unsigned short)0x7BFFu);
+            frag[(pos >> 5) * 64 * kt + t * 32 + (pos & 31)] = z;
+        }
         norms[pos] = INFINITY;
         norms2[pos] = 0x00007C00u;
         perm[pos] = 0xFFFFFFFFu;
@@ -1020,6 +1029,22 @@ __device__ __forceinline__ u64 cell_tile_step(const h8 (&a)[KT], const f4v *__re
     return __ballot(mn < th);
 }
 
+// 16 < k <= 30 (round 5): the norm rides in the fragment — K-slots 30 and 31 of a row hold its norm's two fp16 halves
+// (pack_norm22: hi + mid 2^-11 = N to 2^-22 N, in rho since round 3), the scan's B operands 1 and 2^-11 there — so the two
+// MFMAs of a step give N - 2 a.b out of a ZERO C tile: no norm window, no LDS reads for it.  Every (tile, block of 32 queries)
+// step read 4 KiB of LDS for its C tile; at the 5-10 blocks per tile of these dimensions that was the scan's bound (k 20:
+// 2.9 M steps x 4.2 KiB = 176 us of the LDS pipe's time under a 165 us HBM floor).
+template <int KT>
+__device__ __forceinline__ u64 cell_tile_step_nif(const h8 (&a)[KT], const h8 (&b)[KT], float th)
+{
+    f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], zero_acc(), 0, 0, 0);
+#pragma unroll
+    for (int kk = 1; kk < KT; ++kk)
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], b[kk], d, 0, 0, 0);
+    const float mn = min_tree16(d, th);
+    return __ballot(mn < th);
+}
+
 // |coordinate| a query may have in a cell's frame: twice that must stay an fp16 number (the B operand is -2 x the query); the
 // bounds do not mind the size — every error term is relative to the pair's own amax (64 box half-widths at the largest scale).
 #define CELL_FRAME_AMAX 16384.0f
@@ -1194,7 +1219,14 @@ __global__ __launch_bounds__(64 * PW, KT == 1 && !CTR ? 4 : 3) void knn_cells_pr
     if (wib == 0 && (lane & 31) == 0) {
 #pragma unroll
         for (int t = 0; t < KT; ++t)
-            qfg[frag_at + 64 * t] = bq[t];   // for the scan (lanes 0 and 32 hold the two halves of every K-step)
+        {
+            h8 o = bq[t];
+            if (KT == 2 && t == 1 && half == 1 && g.k <= KNN_NIF_MAX_K) {   // K-slots 30, 31 of the scan's B operand: 1, 2^-11 (x the norm's halves)
+                o[6] = (_Float16)1.0f;
+                o[7] = __builtin_bit_cast(_Float16, (unsigned short)0x1000u);
+            }
+            qfg[frag_at + 64 * t] = o;   // for the scan (lanes 0 and 32 hold the two halves of every K-step)
+        }
     }
 
     // ---- squared gaps to every bin of every dimension (scaled units, rounded down): 256 entries over the block's threads
@@ -1659,7 +1691,8 @@ extern "C" int knn_debug_scan_stamps(unsigned long long *out)
 // CTR:  per-cell frames (knn_cells_recentre; KT = 1, lists from the match launch): the B operand and the threshold of a (query,
 //       cell) pair are made here, from the fp32 query, the cell's frame and Dup_q (cell_centred_operand) — s_thr holds the
 //       batch's sqrt(Dup) bounds, s_dup the Dup values, the B operands' room in LDS stays unused
-template <bool DYN, int K, bool SELF, int KT = 1, bool CTR = false>
+// NIF:  16 < k <= 30: the norms ride in the fragments' K-slots 30, 31 (cell_tile_step_nif): no norm window
+template <bool DYN, int K, bool SELF, int KT = 1, bool CTR = false, bool NIF = false>
 __global__ __launch_bounds__(64 * (KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN_WAVES_KT2), CTR ? 4 : KT == 1 ? 6 : 4) void knn_cells_scan_kernel(
     const h8 *__restrict__ rf, const float *__restrict__ rn, const u64 *__restrict__ items, unsigned nitems,
     const h8 *__restrict__ qfg, const float *__restrict__ thrg, int m, int m_padded,
@@ -1874,7 +1907,7 @@ __global__ __launch_bounds__(64 * (KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN
                         for (int kk = 0; kk < KT; ++kk)
                             ar[p][kk] = __builtin_nontemporal_load(&rf[((size_t)(t0 + (unsigned)p) * KT + kk) * 64 + lane]);
                     }
-                {
+                if constexpr (!NIF) {
                     const f4v *__restrict__ rn4 = (const f4v *)rn + (size_t)t0 * 8;
                     const f4v n0 = lane < nt * 8 ? __builtin_nontemporal_load(&rn4[lane]) : (f4v){0.f, 0.f, 0.f, 0.f};
                     f4v n1 = {0.f, 0.f, 0.f, 0.f};
@@ -1924,7 +1957,7 @@ __global__ __launch_bounds__(64 * (KT == 1 && !CTR ? CELL_SCAN_WAVES : CELL_SCAN
 #pragma unroll
                     for (int p = 0; p < TPP; ++p) {
                         if (p < nt) {
-                            const u64 mask = cell_tile_step<KT>(ar[p], my_nrm, p, half, b, th);
+                            const u64 mask = NIF ? cell_tile_step_nif<KT>(ar[p], b, th) : cell_tile_step<KT>(ar[p], my_nrm, p, half, b, th);
                             if (__builtin_expect(mask != 0ull, 0)) {
                                 const bool hit = (mask >> lane) & 1ull;
                                 const unsigned pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
@@ -2944,7 +2977,8 @@ hipError_t knn_cells_place_rows(FilterState &st, const float *r, const unsigned 
                            st.cells->perm, out, st.outliers, ocap);
     FTRY(hipGetLastError());
     hipLaunchKernelGGL(knn_cells_pad_kernel, dim3((st.cells->ncells + 7u) / 8u), dim3(256), 0, s, st.cells->tile_start, fill,
-                       st.cells->ncells, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, st.kt);
+                       st.cells->ncells, (h8 *)st.ref_frags, st.ref_norms, st.ref_norms2, st.cells->perm, st.kt,
+                       st.kt == 2 && st.k <= KNN_NIF_MAX_K ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -3218,7 +3252,18 @@ hipError_t knn_cells_query(FilterState &st, FilterWorkspace &w, int m, const flo
             KNN_SCAN_LAUNCH_K5(true);
         else
             KNN_SCAN_LAUNCH_K5(false);
-    } else if (st.kt == 2) {   // 16 < k <= 32: run-time k, lists from the match launch
+    } else if (st.kt == 2 && st.k <= KNN_NIF_MAX_K) {   // 16 < k <= 30: run-time k, lists from the match launch, norms in the fragments
+        if (lds > (size_t)(64u << 10)) {   // (more than the default limit of dynamic LDS: say so, per launch — the attribute is per device)
+            if (dyn)
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<true, 0, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            else
+                FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<false, 0, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (dyn)
+            KNN_SCAN_LAUNCH(true, 0, false, 2, false, true);
+        else
+            KNN_SCAN_LAUNCH(false, 0, false, 2, false, true);
+    } else if (st.kt == 2) {   // k 31, 32: no free K-slots — the norm window
         if (lds > (size_t)(64u << 10)) {   // (more than the default limit of dynamic LDS: say so, per launch — the attribute is per device)
             if (dyn)
                 FTRY(hipFuncSetAttribute((const void *)knn_cells_scan_kernel<true, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -206,6 +206,7 @@ struct CellIndex {
     unsigned *tile_cell = nullptr;        // device [ntiles]
 };
 #define KNN_CELL_FRAME_WORDS 20
+#define KNN_NIF_MAX_K 30   // 16 < k <= 30: the cell-sorted fragments carry the rows' norms in K-slots 30, 31 (knn_cells.hip: cell_tile_step_nif)
 
 struct FilterState {
     bool usable = false;       // references finite and in a sane range: filter layouts exist
