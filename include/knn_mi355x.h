@@ -223,8 +223,8 @@ int knn_index_query_host(knn_index *idx, int m, const float *queries_host, int *
  *   "cells"   the MFMA filter's cell-pruned form (k <= 32): the index sorts the shard into 2^B cells (every
  *             dimension — the first 16 when k > 16 — cut at sample quantiles), and a batch scores only the cells each query
  *             could not rule out by its distance to the cell's box.  0 = library policy: indexes created with
- *             knn_index_create of >= 2^19 rows (k <= 12), >= 2^20 rows (k = 13 .. 16), >= 2^22 rows (k = 17 .. 20), >= 2^23 rows
- *             (k = 21, 22) or >= 2^24 rows (k = 23, 24; beyond that too few cells are ruled out for the pruned scan to win); for the one-shot
+ *             knn_index_create of >= 2^19 rows (k <= 12), >= 2^20 rows (k = 13 .. 16), >= 2^22 rows (k = 17 .. 21), >= 2^23 rows
+ *             (k = 22, 23) or >= 2^24 rows (k = 24, 25; beyond that too few cells are ruled out for the pruned scan to win); for the one-shot
  *             cudaCallback on shards of that size when the cost model says the batch repays the sort (the bucket pass of
  *             the sort runs under the host-to-device copy, ~1 ms per 2^24 rows stays behind the last byte: from about
  *             2500 queries on at n = 2^24; knn_get_option("last_cells") counts the shards of the most recent call

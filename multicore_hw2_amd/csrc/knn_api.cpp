@@ -522,10 +522,10 @@ int index_create_impl(knn_index **out, int device, int k, long long n_local, con
     // the pruned scan wins from 2^19 rows for k <= 12 and from 2^20 rows for k = 13..16; below that the lists
     // hold most of the batch and the full scan's register-resident loop is the faster way to score them.
     // (16 < k <= 32, round 5: the cells cut the first 16 dimensions; policy from the measurements in profiles/r05_cells_k17_32.txt:
-    // uniform data, m = 1024, ms per step pruned / full scan on one box — n = 2^24: k 17 0.222 / 0.992, 20 0.304 / 1.023, 22 0.485 / 1.039,
-    // 24 0.709 / 1.050, 26 1.36 / 1.07 (loses); n = 2^23: k 20 0.223 / 0.493, 22 0.363 / 0.505, 23 0.461 / 0.510, 24 0.578 / 0.514 (loses);
-    // n = 2^22: k 17 0.087 / 0.242, 20 0.163 / 0.253, 21 0.202 / 0.256, 22 0.252 / 0.260, 23 0.268 / 0.262 (loses))
-    const long long cells_from = k <= 12 ? (1ll << 19) : k <= 16 ? (1ll << 20) : k <= 20 ? (1ll << 22) : k <= 22 ? (1ll << 23)
+    // uniform data, m = 1024, ms per step pruned / full scan on one box — n = 2^24: k 17 0.211 / 0.94, 20 0.265 / 0.96, 22 0.424 / 0.962,
+    // 24 0.625 / 0.976, 25 0.716 / 0.980, 26 1.06 / 0.99 (loses); n = 2^23: k 21 0.238 / 0.465, 23 0.354 / 0.476, 24 0.445 / 0.477 (a wash),
+    // 25 0.579 / 0.480 (loses); n = 2^22: k 20 0.143 / 0.25, 21 0.174 / 0.236, 22 0.220 / 0.240 and 23 0.219 / 0.243 (a wash), 24 loses)
+    const long long cells_from = k <= 12 ? (1ll << 19) : k <= 16 ? (1ll << 20) : k <= 21 ? (1ll << 22) : k <= 23 ? (1ll << 23)
                                  : k <= KNN_CELLS_AUTO_MAX_K ? (1ll << 24) : (1ll << 62);
     const bool want_cells = k <= 32 && n_local >= (1ll << 17) &&
                             (g_opt_cells == 1 || (g_opt_cells == 0 && build_filter == 2) ||

@@ -243,7 +243,7 @@ struct FilterState {
 };
 
 // ---- cell-pruned form of the filter (knn_cells.hip) -----------------------------------------
-#define KNN_CELLS_AUTO_MAX_K 24   // library policy: cell-sorted layouts for resident indexes up to this dimension (`cells` = 1: up to 32)
+#define KNN_CELLS_AUTO_MAX_K 25   // library policy: cell-sorted layouts for resident indexes up to this dimension (`cells` = 1: up to 32)
 #define KNN_CELL_BATCH 1024   // queries per pass: their B operands + thresholds sit in 36 KiB of LDS (68 KiB for 16 < k <= 32)
 #ifdef __cplusplus
 #include <vector>

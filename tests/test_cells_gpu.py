@@ -549,7 +549,7 @@ def test_drop_in_takes_the_pruned_path_when_the_batch_repays_the_sort(oracle):
         np.testing.assert_array_equal(got[sel], oracle.v0(k, Q[sel], R, threads=THREADS), err_msg=f"m={m}")
 
 
-@pytest.mark.parametrize("k", [17, 18, 20, 24, 29, 32])
+@pytest.mark.parametrize("k", [17, 18, 20, 24, 29, 30, 31, 32])
 @pytest.mark.parametrize("dist,n,m", [("uniform", (1 << 18) + 77, 700), ("uniform", 1 << 20, 1024), ("clustered", 1 << 17, 600),
                                       ("copies", (1 << 17) + 7, 513), ("queries_outside", 1 << 18, 64), ("tight_clusters", 1 << 20, 1024)])
 def test_pruned_scan_for_17_to_32_dimensions_is_bit_exact(oracle, k, dist, n, m):
@@ -575,11 +575,11 @@ def test_pruned_scan_for_17_to_32_dimensions_is_bit_exact(oracle, k, dist, n, m)
     assert st[0] == 4, st
 
 
-@pytest.mark.parametrize("k", [20, 24])
+@pytest.mark.parametrize("k", [20, 25])
 def test_c3_shape_with_20_dimensions_every_query_on_the_pruned_path(oracle, k):
-    """k = 20 and 24, m = 1024, n = 2^24 (C3's shape with four / eight more dimensions): library policy puts them on the pruned
-    scan since round 5 (two K-steps per tile, cuts on the first 16 dimensions; k 23, 24 from 2^24 rows, lists of up to 640
-    queries per cell); every answer against the oracle."""
+    """k = 20 and 25, m = 1024, n = 2^24 (C3's shape with four / nine more dimensions): library policy puts them on the pruned
+    scan since round 5 (two K-steps per tile, cuts on the first 16 dimensions, the norms in the fragments' free K-slots; k 24, 25
+    from 2^24 rows, lists of up to 640 queries per cell); every answer against the oracle."""
     m, n = 1024, 1 << 24
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
