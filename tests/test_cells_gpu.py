@@ -750,3 +750,28 @@ def test_per_cell_frames_pass_every_row_of_a_cell_whose_frame_a_far_query_does_n
         pkg.set_option("cells_centre", 0)
     np.testing.assert_array_equal(got, want, err_msg=f"stats={st}")
     assert st[0] == 4 and st[2] == 0 and st[1] >= n // 16 // 2, st
+
+
+@pytest.mark.parametrize("k", [16, 20, 31])
+def test_full_scan_over_a_cell_sorted_layout(oracle, k):
+    """`cells` = 2 set AFTER the index was built sends its batches to the full scan over the cell-sorted layout (the option is
+    read per call).  For 16 < k <= 30 that layout carries the rows' norms in K-slots 30, 31 of its fragments (round 5): the
+    full scan's own B operands are zero there and it takes its C tile from the norm array, so nothing may change for it."""
+    m, n = 300, (1 << 18) + 5
+    rng = np.random.default_rng(k)
+    Q, R = _cases(rng, "uniform", k, m, n)
+    want = oracle.v0(k, Q, R, threads=THREADS)
+    pkg.set_option("path", 2)
+    pkg.set_option("cells", 1)
+    try:
+        ix = pkg.KnnIndex(k, R)
+        got_cells, st_cells = _query(ix, Q)
+        pkg.set_option("cells", 2)
+        got_full, st_full = _query(ix, Q)
+        ix.close()
+    finally:
+        pkg.set_option("path", 0)
+        pkg.set_option("cells", 0)
+    assert st_cells[0] == 4 and st_full[0] == 2, (st_cells, st_full)
+    np.testing.assert_array_equal(got_cells, want)
+    np.testing.assert_array_equal(got_full, want)
