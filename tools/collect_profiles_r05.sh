@@ -49,6 +49,7 @@ step "pmc passes keyed by workload: C3, rank 0 of 8 of C3, C4 on one GPU"
 PMCSET c3
 PMCSET c3_rank_0_of_8 --emulate 8:0
 PMCSET c4_1gpu --workload c4
+PMCSET k20 --workload 20,1024,16777216
 step "SQ counters (C3, one batch at a time)"
 SQ sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES
 SQ sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD
@@ -117,10 +118,16 @@ step "fuzz (bounded)"
   echo "== cell-pruned scan (k <= 32, both list makers, three builds)"; FUZZ_CELLS=1 timeout -k 10 420 python3 tools/fuzz_parity.py 400 27182 2>&1 | tail -3; } > $O/fuzz.txt 2>&1 || true
 echo done c
 fi
+if [ "$1" = k20 ]; then   # (only the k = 20 PMC passes: added after the round's last full collection)
+step "pmc passes: k 20"
+PMCSET k20 --workload 20,1024,16777216
+echo done k20
+fi
 if [ "$1" = d ]; then
 step "bench lines that quote the PMC files of this collection"
 B c3
 B c4_1gpu --workload c4 --cpu-queries 0
 B c3_rank_0_of_8 --emulate 8:0 --cpu-queries 0
+B 20_1024_16777216 --workload 20,1024,16777216 --cpu-queries 0 --steps 60
 echo done d
 fi

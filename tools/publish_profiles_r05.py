@@ -36,7 +36,7 @@ for d, out in (("kt_c3", "c3_kernel_stats"), ("kt_c2", "c2_kernel_stats"), ("kt_
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, f"{tag}_{out}.csv"))
-for w, args in (("c3", ""), ("c3_rank_0_of_8", "--emulate 8:0"), ("c4_1gpu", "--workload c4")):
+for w, args in (("c3", ""), ("c3_rank_0_of_8", "--emulate 8:0"), ("c4_1gpu", "--workload c4"), ("k20", "--workload 20,1024,16777216")):
     if os.path.isdir(os.path.join(src, f"pmc_{w}_fetch")):
         subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), f"{tag}_{w}",
                                os.path.join(src, f"pmc_{w}_fetch"), os.path.join(src, f"pmc_{w}_write"), os.path.join(src, f"pmc_{w}_l2"),
